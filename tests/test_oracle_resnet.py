@@ -1,0 +1,107 @@
+"""Pin oracle/resnet_ref.py and oracle/train_ref.py to reference-generated vectors."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import recipe, resnet_ref, train_ref
+
+T = torch.from_numpy
+
+
+def _summary_close(got, want, rtol, atol):
+    np.testing.assert_allclose(recipe.summary(got), want, rtol=rtol, atol=atol)
+
+
+@pytest.mark.parametrize("tag", ["s1", "s2"])
+def test_basicblock(golden, tag):
+    g = golden("basicblock_" + tag)
+    cin, cout, stride, hw = int(g["cin"]), int(g["cout"]), int(g["stride"]), int(g["hw"])
+    has_ds = stride != 1 or cin != cout
+    spec = [("conv1.weight", (cin, cin, 3, 3), "conv")] + resnet_ref._bn_spec("bn1", cin) + \
+           [("conv2.weight", (cout, cin, 3, 3), "conv")] + resnet_ref._bn_spec("bn2", cout)
+    if has_ds:
+        spec += [("downsample.0.weight", (cout, cin, 1, 1), "conv")] + resnet_ref._bn_spec("downsample.1", cout)
+    sd0 = recipe.fill_state(spec, 900 + stride)
+    sd = {"blk." + k: v.clone() for k, v in sd0.items()}
+    names = resnet_ref.trainable_names(sd)
+    for k in names:
+        sd[k].requires_grad_(True)
+    x = recipe.normal(901, (3, cin, hw, hw)).requires_grad_(True)
+    y = resnet_ref.basic_block(sd, "blk", x, stride, has_ds, True)
+    y.backward(recipe.normal(902, y.shape))
+    np.testing.assert_allclose(y.detach().numpy(), g["train_out"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(x.grad.numpy(), g["train_dx"], rtol=1e-3, atol=1e-5)
+    for k in names:
+        np.testing.assert_allclose(sd[k].grad.numpy(), g["grad." + k[4:]], rtol=1e-3, atol=2e-5)
+    for k in sd:
+        if k not in names:
+            np.testing.assert_allclose(sd[k].detach().numpy(), g["after." + k[4:]], rtol=1e-5, atol=1e-6)
+    sd = {"blk." + k: v.clone() for k, v in sd0.items()}
+    ye = resnet_ref.basic_block(sd, "blk", x.detach(), stride, has_ds, False)
+    np.testing.assert_allclose(ye.numpy(), g["eval_out"], rtol=1e-4, atol=1e-5)
+
+
+def test_spec_matches_reference_key_count(golden):
+    g = golden("resnet50_b2_eval")
+    assert len(resnet_ref.resnet_spec(resnet_ref.BLOCKS["ResNet50"])) == int(g["n_keys"]) == 336
+
+
+def test_resnet18_train_and_eval(golden):
+    blocks = resnet_ref.BLOCKS["ResNet18"]
+    sd0 = recipe.fill_state(resnet_ref.resnet_spec(blocks), 4242)
+    x = recipe.images(4243, 4)
+    g = golden("resnet18_b4_train")
+    sd = {k: v.clone() for k, v in sd0.items()}
+    names = resnet_ref.trainable_names(sd)
+    for k in names:
+        sd[k].requires_grad_(True)
+    y = resnet_ref.resnet_forward(sd, x, blocks, True)
+    y.backward(recipe.normal(4244, (4, 512), 0.05))
+    np.testing.assert_allclose(y.detach().numpy(), g["out"], rtol=1e-3, atol=1e-4)
+    for k in names:
+        _summary_close(sd[k].grad, g["gsum." + k], 2e-3, 2e-5)
+    for k in sd:
+        if k not in names:
+            _summary_close(sd[k].detach().float(), g["after." + k], 1e-4, 1e-6)
+    ge = golden("resnet18_b4_eval")
+    sd = {k: v.clone() for k, v in sd0.items()}
+    with torch.no_grad():
+        ye = resnet_ref.resnet_forward(sd, x, blocks, False)
+    np.testing.assert_allclose(ye.numpy(), ge["out"], rtol=1e-3, atol=1e-4)
+
+
+def test_resnet50_eval(golden):
+    blocks = resnet_ref.BLOCKS["ResNet50"]
+    sd = recipe.fill_state(resnet_ref.resnet_spec(blocks), 5050)
+    with torch.no_grad():
+        y = resnet_ref.resnet_forward(sd, recipe.images(5051, 2), blocks, False)
+    np.testing.assert_allclose(y.numpy(), golden("resnet50_b2_eval")["out"], rtol=1e-3, atol=1e-4)
+
+
+@pytest.mark.parametrize("tag", ["rate10", "rate03"])
+def test_train_steps(golden, tag):
+    """BASELINE cfg 1: ResNet-18 + ArcFace head, 256 ids, fp32 CPU, world_size 1, 3 SGD steps."""
+    g = golden("train_step_resnet18_c256_" + tag)
+    C, B, steps, rate = int(g["C"]), int(g["B"]), int(g["steps"]), float(g["rate"])
+    blocks = resnet_ref.BLOCKS["ResNet18"]
+    spec = resnet_ref.resnet_spec(blocks)
+    sd = recipe.fill_state(spec, 777)
+    for k, _, kind in spec:
+        if kind in ("bn_w", "bn_rv"):
+            sd[k].fill_(1.0)
+        elif kind in ("bn_b", "bn_rm"):
+            sd[k].zero_()
+    W = recipe.normal(778, (C, 512), 0.01)
+    img, ids = recipe.images(779, B), recipe.labels(780, B, C)
+    opt = train_ref.SGDState(float(g["lr"]), float(g["momentum"]), float(g["wd"]))
+    for st in range(steps):
+        u = [T(g["u"][st])] if rate < 1 else None
+        out = train_ref.train_step(sd, W, img, ids, blocks, C, opt, sample_rate=rate, uniforms=u)
+        np.testing.assert_allclose(out["loss"].item(), g["losses"][st], rtol=2e-3)
+        np.testing.assert_allclose(out["grad_norm"].item(), g["grad_norms"][st], rtol=5e-3)
+        if rate < 1:
+            assert np.array_equal(out["index"].numpy(), g["index_step%d" % st])
+    for k in ("conv1.weight", "layer2.0.downsample.0.weight", "layer4.1.bn2.weight", "fc.weight",
+              "bn3.running_var", "bn1.running_mean"):
+        _summary_close(sd[k].float(), g["after." + k], 5e-3, 5e-5)
+    _summary_close(W, g["after.head_weight"], 5e-3, 5e-5)

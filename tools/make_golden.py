@@ -1,0 +1,282 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REAL reference modules (build container only).
+
+Usage:  PYTHONDONTWRITEBYTECODE=1 python tools/make_golden.py [--only NAME]
+
+The reference (/root/reference, read-only) is imported as namespace packages.  Two
+container-only shims are applied, exactly as recorded in SURVEY.md section 8c / Appendix B:
+  * torch.Tensor.cuda -> identity  (nets/PartialFC.py hard-codes .cuda(); no GPU here)
+  * torch.distributed on gloo with a file:// rendezvous (multi-rank cases use real processes)
+Inputs come from oracle/recipe.py (numpy PCG64), so fixtures store OUTPUTS (+ the few
+RNG draws the reference takes from torch's CPU generator).  Nothing from the reference
+is copied into the repo: fixtures are data only.
+"""
+import argparse
+import os
+import sys
+import tempfile
+import types
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.dont_write_bytecode = True
+REF = "/root/reference"
+OUT = os.path.join(ROOT, "tests", "golden")
+
+from oracle import recipe, resnet_ref  # noqa: E402  (spec + portable inputs only)
+
+
+def _ref():
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    import nets.ArcFace as A
+    import nets.PartialFC as P
+    import nets.resnet as R
+    return A, P, R
+
+
+def _init_pg(rank, ws, path):
+    dist.init_process_group("gloo", init_method="file://" + path, rank=rank, world_size=ws)
+
+
+def save(name, **arrs):
+    os.makedirs(OUT, exist_ok=True)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"),
+                        **{k: (v.detach().numpy() if torch.is_tensor(v) else np.asarray(v))
+                           for k, v in arrs.items()})
+    print("wrote", name, "(%d arrays)" % len(arrs))
+
+
+# ----------------------------------------------------------------------------- ArcFace edge cases
+def gen_arcface_edge():
+    A, _, _ = _ref()
+    for tag, (s, m) in {"s30_m035": (30.0, 0.35), "s64_m05": (64.0, 0.5)}.items():
+        theta = np.cos(np.pi - m)
+        t = torch.tensor([0.3, -0.2, 0.999, -0.999, theta, np.nextafter(np.float32(theta), np.float32(1)),
+                          np.nextafter(np.float32(theta), np.float32(-1)), 0.0, 1.0, -1.0],
+                         dtype=torch.float32)
+        n, c = t.numel() + 2, 12
+        logits = recipe.normal(77, (n, c), 0.3).clamp_(-1, 1)
+        labels = torch.full((n, 1), -1, dtype=torch.int64)
+        for i in range(t.numel()):
+            labels[i, 0] = (i * 5) % c
+            logits[i, labels[i, 0]] = t[i]
+        inp = logits.clone()
+        out = A.ArcFace(s, m)(logits, labels)
+        save("arcface_edge_" + tag, s=s, m=m, logits_in=inp, labels=labels, logits_out=out)
+
+
+# ----------------------------------------------------------------------------- head, multi-rank
+def _head_worker(rank, ws, path, cfg, ret):
+    _, P, _ = _ref()
+    _init_pg(rank, ws, path)
+    C, B, D, rate, s, m = cfg["C"], cfg["B"], cfg["D"], cfg["rate"], cfg["s"], cfg["m"]
+    conf = types.SimpleNamespace(emd_size=D, sample_rate=rate, mixed_precision=False, loss_s=s, loss_m=m)
+    pfc = P.PartialFC(conf, C)
+    W = recipe.normal(500 + rank, (pfc.num_local, D), 0.05)
+    with torch.no_grad():
+        if rate < 1:
+            pfc.weight.copy_(W)
+        else:
+            pfc.weight_activated.data.copy_(W)
+    dummy = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.SGD([{"params": [dummy]}, {"params": pfc.parameters()}], lr=0.1, momentum=0.9)
+    emb = recipe.normal(100 + rank, (B, D)).requires_grad_(True)
+    lab = recipe.labels(200 + rank, B, C)
+    if cfg.get("dup_labels"):      # make two ranks share identities and repeat one inside a rank
+        lab[0] = 3
+        lab[1] = 3
+    torch.manual_seed(1000 + rank)
+    u = torch.rand(pfc.num_local) if rate < 1 else torch.zeros(0)
+    torch.manual_seed(1000 + rank)
+    loss = pfc(emb, lab.clone(), opt)
+    loss.backward()
+    idx = pfc.weight_index if rate < 1 else torch.arange(pfc.num_local)
+    ret[rank] = dict(loss=loss.detach().clone(), d_emb=emb.grad.clone(),
+                     d_w_act=pfc.weight_activated.grad.clone(), index=idx.clone().long(), u=u,
+                     class_start=pfc.class_start, num_local=pfc.num_local, num_sample=pfc.num_sample)
+    dist.destroy_process_group()
+
+
+def gen_head(ws, rate, C=1003, B=6, D=128, s=30.0, m=0.35, dup=True):
+    cfg = dict(C=C, B=B, D=D, rate=rate, s=s, m=m, dup_labels=dup)
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "pg")
+        if ws == 1:
+            _head_worker(0, 1, path, cfg, ret)
+        else:
+            mp.spawn(_head_worker, args=(ws, path, cfg, ret), nprocs=ws, join=True)
+    arrs = dict(C=C, B=B, D=D, rate=rate, s=s, m=m, ws=ws, dup=int(dup))
+    for r in range(ws):
+        for k, v in ret[r].items():
+            arrs["r%d_%s" % (r, k)] = v
+    save("head_ws%d_rate%s" % (ws, str(rate).replace(".", "")), **arrs)
+
+
+# ----------------------------------------------------------------------------- dist CE alone
+def gen_distce():
+    _, P, _ = _ref()
+    with tempfile.TemporaryDirectory() as td:
+        _init_pg(0, 1, os.path.join(td, "pg"))
+        z = (recipe.normal(31, (7, 19)) * 8).requires_grad_(True)
+        lab = recipe.labels(32, 7, 19).view(-1, 1)
+        lab[2, 0] = -1
+        zin = z.detach().clone()
+        loss = P.DistCrossEntropy()(z.clone(), lab)
+        (loss * 2.5).backward()
+        save("distce_ws1", z=zin, labels=lab, loss=loss.detach(), grad=z.grad, upstream=2.5)
+        dist.destroy_process_group()
+
+
+# ----------------------------------------------------------------------------- BasicBlock
+def gen_basicblock():
+    _, _, R = _ref()
+    for tag, (cin, cout, stride, hw) in {"s1": (64, 64, 1, 8), "s2": (64, 128, 2, 8)}.items():
+        ds = None
+        if stride != 1 or cin != cout:
+            ds = torch.nn.Sequential(R.conv1x1(cin, cout, stride), torch.nn.BatchNorm2d(cout))
+        blk = R.BasicBlock(cin, cout, stride, ds)
+        spec = [("conv1.weight", (cin, cin, 3, 3), "conv")] + resnet_ref._bn_spec("bn1", cin) + \
+               [("conv2.weight", (cout, cin, 3, 3), "conv")] + resnet_ref._bn_spec("bn2", cout)
+        if ds is not None:
+            spec += [("downsample.0.weight", (cout, cin, 1, 1), "conv")] + resnet_ref._bn_spec("downsample.1", cout)
+        sd = recipe.fill_state(spec, 900 + stride)
+        blk.load_state_dict(sd, strict=True)
+        x = recipe.normal(901, (3, cin, hw, hw)).requires_grad_(True)
+        g = recipe.normal(902, (3, cout, hw // stride, hw // stride))
+        arrs = {}
+        blk.train()
+        y = blk(x)
+        y.backward(g)
+        arrs.update(train_out=y.detach(), train_dx=x.grad.clone())
+        for k, p in blk.named_parameters():
+            arrs["grad." + k] = p.grad.clone()
+        for k, b in blk.named_buffers():
+            arrs["after." + k] = b.clone()
+        blk.load_state_dict(sd, strict=True)
+        blk.eval()
+        arrs["eval_out"] = blk(x.detach()).detach()
+        save("basicblock_" + tag, cin=cin, cout=cout, stride=stride, hw=hw, **arrs)
+
+
+# ----------------------------------------------------------------------------- whole backbone
+def gen_resnet():
+    _, _, R = _ref()
+    conf = types.SimpleNamespace(network="ResNet18", emd_size=512)
+    net = R.ResNet18(conf)
+    spec = resnet_ref.resnet_spec(resnet_ref.BLOCKS["ResNet18"])
+    assert [k for k, _, _ in spec] == list(net.state_dict().keys())
+    sd = recipe.fill_state(spec, 4242)
+    net.load_state_dict(sd, strict=True)
+    x = recipe.images(4243, 4)
+    g = recipe.normal(4244, (4, 512), 0.05)
+    net.train()
+    y = net(x)
+    y.backward(g)
+    arrs = dict(out=y.detach())
+    for k, p in net.named_parameters():
+        arrs["gsum." + k] = recipe.summary(p.grad)
+    for k, b in net.named_buffers():
+        arrs["after." + k] = recipe.summary(b.float())
+    save("resnet18_b4_train", **arrs)
+
+    net.load_state_dict(sd, strict=True)
+    net.eval()
+    with torch.no_grad():
+        save("resnet18_b4_eval", out=net(x))
+
+    conf50 = types.SimpleNamespace(network="ResNet50", emd_size=512)
+    net50 = R.Encoder(conf50)
+    spec50 = resnet_ref.resnet_spec(resnet_ref.BLOCKS["ResNet50"])
+    assert [k for k, _, _ in spec50] == list(net50.state_dict().keys())
+    assert [tuple(s) for _, s, _ in spec50] == [tuple(v.shape) for v in net50.state_dict().values()]
+    net50.load_state_dict(recipe.fill_state(spec50, 5050), strict=True)
+    net50.eval()
+    with torch.no_grad():
+        save("resnet50_b2_eval", out=net50(recipe.images(5051, 2)), n_keys=len(spec50))
+
+
+# ----------------------------------------------------------------------------- training steps
+def gen_train_steps():
+    _, P, R = _ref()
+    import torch.nn.functional as F
+    for tag, rate in {"rate10": 1.0, "rate03": 0.3}.items():
+        with tempfile.TemporaryDirectory() as td:
+            _init_pg(0, 1, os.path.join(td, "pg"))
+            C, B, steps = 256, 16, 3
+            conf = types.SimpleNamespace(network="ResNet18", emd_size=512, sample_rate=rate,
+                                         mixed_precision=False, loss_s=30.0, loss_m=0.35)
+            enc = R.ResNet18(conf)
+            spec = resnet_ref.resnet_spec(resnet_ref.BLOCKS["ResNet18"])
+            sd = recipe.fill_state(spec, 777)
+            # cfg-1 starts from the reference's init statistics for BN (gamma 1, beta 0, rm 0, rv 1)
+            for k, _, kind in spec:
+                if kind == "bn_w" or kind == "bn_rv":
+                    sd[k].fill_(1.0)
+                elif kind in ("bn_b", "bn_rm"):
+                    sd[k].zero_()
+            enc.load_state_dict(sd, strict=True)
+            pfc = P.PartialFC(conf, C)
+            W = recipe.normal(778, (C, 512), 0.01)
+            with torch.no_grad():
+                (pfc.weight if rate < 1 else pfc.weight_activated.data).copy_(W)
+            opt = torch.optim.SGD([{"params": enc.parameters()}, {"params": pfc.parameters()}],
+                                  lr=0.1, momentum=0.9, weight_decay=5e-4)
+            img = recipe.images(779, B)
+            ids = recipe.labels(780, B, C)
+            arrs = dict(C=C, B=B, steps=steps, rate=rate, lr=0.1, momentum=0.9, wd=5e-4)
+            losses, gnorms, us = [], [], []
+            for st in range(steps):
+                opt.zero_grad()
+                enc.train()
+                feat = F.normalize(enc(img))
+                torch.manual_seed(3000 + st)
+                us.append(torch.rand(C) if rate < 1 else torch.zeros(0))
+                torch.manual_seed(3000 + st)
+                loss = pfc(feat, ids.clone(), opt)
+                loss.backward()
+                gn = torch.nn.utils.clip_grad_norm_(enc.parameters(), 5)
+                opt.step()
+                losses.append(loss.detach().clone())
+                gnorms.append(gn.detach().clone())
+                if rate < 1:
+                    arrs["index_step%d" % st] = pfc.weight_index.clone()
+            pfc.update() if rate < 1 else None
+            arrs.update(losses=torch.stack(losses), grad_norms=torch.stack(gnorms), u=torch.stack(us))
+            for k, v in enc.state_dict().items():
+                arrs["after." + k] = recipe.summary(v.float())
+            wfin = pfc.weight if rate < 1 else pfc.weight_activated.data
+            arrs["after.head_weight"] = recipe.summary(wfin)
+            save("train_step_resnet18_c256_" + tag, **arrs)
+            dist.destroy_process_group()
+
+
+GENS = {
+    "arcface": gen_arcface_edge,
+    "distce": gen_distce,
+    "head_ws1_rate10": lambda: gen_head(1, 1.0),
+    "head_ws1_rate03": lambda: gen_head(1, 0.3),
+    "head_ws2_rate10": lambda: gen_head(2, 1.0),
+    "head_ws2_rate03": lambda: gen_head(2, 0.3),
+    "head_ws8_rate01": lambda: gen_head(8, 0.1, C=4003, B=4),
+    "basicblock": gen_basicblock,
+    "resnet": gen_resnet,
+    "train": gen_train_steps,
+}
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default=None)
+    a = ap.parse_args()
+    torch.set_num_threads(8)
+    for name, fn in GENS.items():
+        if a.only is None or a.only == name:
+            fn()
