@@ -1,0 +1,333 @@
+// BatchNorm (training + eval) and the element-wise glue of the NHWC backbone, for gfx950.
+// HBM-bound kernels: 16 bytes per lane, channels fastest (NHWC), per-channel parameters in registers.
+// Reference semantics: nn.BatchNorm2d / nn.BatchNorm1d defaults (eps 1e-5, momentum 0.1, biased batch variance
+// for normalisation, unbiased for running_var) as used by /root/reference/nets/resnet.py:81-86, :187, :196-199,
+// and the residual add of BasicBlock.forward (:89-103).
+#include "common.h"
+#include "frhip.h"
+
+namespace frhip {
+
+constexpr int EW_THREADS = 256;
+constexpr int RED_GROUPS = 64;      // second-level partial count
+
+template <typename T> struct EW {
+    static constexpr int EPV = 16 / (int)sizeof(T);
+};
+
+// ------------------------------------------------------------------------------------------------
+// Column statistics of a [rows][C] tensor: partial[blk][0][c] = sum x, partial[blk][1][c] = sum x^2.
+// Optional second operand turns it into the BN-backward reduction:
+//   d_eff = dout * (relu ? (y*scale+shift > 0) : 1);  partial = { sum d_eff, sum d_eff * (y-mean)*invstd }.
+template <typename T, bool BWD>
+__global__ __launch_bounds__(EW_THREADS) void colreduce_kernel(const T* __restrict__ x, const T* __restrict__ y,
+                                                               const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                               const float* __restrict__ mscale, const float* __restrict__ mshift,
+                                                               float* __restrict__ partial, int rows, int C) {
+    constexpr int EPV = EW<T>::EPV;
+    const int vpr = C / EPV;                     // vectors per row (<= 256, divides 256)
+    const int cg = threadIdx.x % vpr, rl = threadIdx.x / vpr, rlanes = EW_THREADS / vpr;
+    float s1[EPV], s2[EPV], mu[EPV], is[EPV], ms[EPV], mb[EPV];
+#pragma unroll
+    for (int e = 0; e < EPV; ++e) {
+        s1[e] = 0.f; s2[e] = 0.f;
+        if (BWD) {
+            mu[e] = mean[cg * EPV + e]; is[e] = invstd[cg * EPV + e];
+            ms[e] = mscale ? mscale[cg * EPV + e] : 0.f; mb[e] = mscale ? mshift[cg * EPV + e] : 1.f;
+        }
+    }
+    for (int r = blockIdx.x * rlanes + rl; r < rows; r += gridDim.x * rlanes) {
+        const size_t idx = (size_t)r * C + cg * EPV;
+        const Vec16<T> a = *reinterpret_cast<const Vec16<T>*>(x + idx);
+        if (BWD) {
+            const Vec16<T> b = *reinterpret_cast<const Vec16<T>*>(y + idx);
+#pragma unroll
+            for (int e = 0; e < EPV; ++e) {
+                const float yy = b.get(e);
+                const float d = (yy * ms[e] + mb[e] > 0.f) ? a.get(e) : 0.f;
+                s1[e] += d; s2[e] += d * (yy - mu[e]) * is[e];
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < EPV; ++e) { const float v = a.get(e); s1[e] += v; s2[e] += v * v; }
+        }
+    }
+    __shared__ float red[2][EW_THREADS][EPV + 1];
+#pragma unroll
+    for (int e = 0; e < EPV; ++e) { red[0][threadIdx.x][e] = s1[e]; red[1][threadIdx.x][e] = s2[e]; }
+    __syncthreads();
+    for (int t = threadIdx.x; t < 2 * C; t += EW_THREADS) {
+        const int st = t / C, c = t - st * C;
+        float acc = 0.f;
+        for (int k = 0; k < rlanes; ++k) acc += red[st][k * vpr + c / EPV][c % EPV];
+        partial[((size_t)blockIdx.x * 2 + st) * C + c] = acc;
+    }
+}
+
+// partial[nparts][2][C] -> out[RED_GROUPS][2][C]
+__global__ void reduce_partials_kernel(const float* __restrict__ in, float* __restrict__ out, int nparts, int C) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;     // over 2*C
+    if (t >= 2 * C) return;
+    float acc = 0.f;
+    for (int p = blockIdx.y; p < nparts; p += gridDim.y) acc += in[(size_t)p * 2 * C + t];
+    out[(size_t)blockIdx.y * 2 * C + t] = acc;
+}
+
+// Finalise forward batch statistics.
+__global__ void bn_finalize_kernel(const float* __restrict__ parts, int nparts, int C, float count,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                   float* __restrict__ running_mean, float* __restrict__ running_var,
+                                   float momentum, float eps, float* __restrict__ mean_out,
+                                   float* __restrict__ invstd_out, float* __restrict__ scale, float* __restrict__ shift) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float s1 = 0.f, s2 = 0.f;
+    for (int p = 0; p < nparts; ++p) { s1 += parts[(size_t)p * 2 * C + c]; s2 += parts[(size_t)p * 2 * C + C + c]; }
+    const float mu = s1 / count;
+    float var = s2 / count - mu * mu;
+    var = var < 0.f ? 0.f : var;
+    const float is = rsqrtf(var + eps);
+    mean_out[c] = mu; invstd_out[c] = is;
+    const float sc = gamma[c] * is;
+    scale[c] = sc; shift[c] = beta[c] - mu * sc;
+    if (running_mean) {
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mu;
+        const float unbiased = count > 1.f ? var * count / (count - 1.f) : var;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
+    }
+}
+
+// Eval-mode scale/shift from running statistics.
+__global__ void bn_eval_kernel(int C, const float* __restrict__ gamma, const float* __restrict__ beta,
+                               const float* __restrict__ rm, const float* __restrict__ rv, float eps,
+                               float* __restrict__ scale, float* __restrict__ shift) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float sc = gamma[c] * rsqrtf(rv[c] + eps);
+    scale[c] = sc; shift[c] = beta[c] - rm[c] * sc;
+}
+
+// Finalise backward sums: dgamma, dbeta and the per-channel affine of  dy = ca*d_eff + cb*y + cc.
+__global__ void bn_bwd_finalize_kernel(const float* __restrict__ parts, int nparts, int C, float count,
+                                       const float* __restrict__ gamma, const float* __restrict__ mean,
+                                       const float* __restrict__ invstd, float* __restrict__ dgamma,
+                                       float* __restrict__ dbeta, float* __restrict__ ca, float* __restrict__ cb,
+                                       float* __restrict__ cc) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float s1 = 0.f, s2 = 0.f;
+    for (int p = 0; p < nparts; ++p) { s1 += parts[(size_t)p * 2 * C + c]; s2 += parts[(size_t)p * 2 * C + C + c]; }
+    dgamma[c] += s2; dbeta[c] += s1;                 // accumulate into (caller-zeroed) .grad
+    const float gi = gamma[c] * invstd[c], m2 = s2 / count, m1 = s1 / count;
+    ca[c] = gi; cb[c] = -gi * invstd[c] * m2; cc[c] = gi * (mean[c] * invstd[c] * m2 - m1);
+}
+
+// out = act( y*scale + shift  [+ res  |  + res*rscale + rshift] )
+template <typename T>
+__global__ __launch_bounds__(EW_THREADS) void bn_apply_kernel(const T* __restrict__ y, const float* __restrict__ scale,
+                                                              const float* __restrict__ shift, const T* __restrict__ res,
+                                                              const float* __restrict__ rscale, const float* __restrict__ rshift,
+                                                              int relu, T* __restrict__ out, size_t nvec, int C) {
+    constexpr int EPV = EW<T>::EPV;
+    const int vpr = C / EPV;
+    for (size_t v = (size_t)blockIdx.x * EW_THREADS + threadIdx.x; v < nvec; v += (size_t)gridDim.x * EW_THREADS) {
+        const int c0 = (int)(v % vpr) * EPV;
+        Vec16<T> a = *reinterpret_cast<const Vec16<T>*>(y + v * EPV);
+        Vec16<T> r;
+        if (res) r = *reinterpret_cast<const Vec16<T>*>(res + v * EPV);
+#pragma unroll
+        for (int e = 0; e < EPV; ++e) {
+            float o = a.get(e) * scale[c0 + e] + shift[c0 + e];
+            if (res) o += rscale ? r.get(e) * rscale[c0 + e] + rshift[c0 + e] : r.get(e);
+            if (relu) o = o > 0.f ? o : 0.f;
+            a.set(e, o);
+        }
+        *reinterpret_cast<Vec16<T>*>(out + v * EPV) = a;
+    }
+}
+
+// dy = ca * d_eff + cb * y + cc,  d_eff = dout * mask
+template <typename T>
+__global__ __launch_bounds__(EW_THREADS) void bn_bwd_apply_kernel(const T* __restrict__ dout, const T* __restrict__ y,
+                                                                  const float* __restrict__ ca, const float* __restrict__ cb,
+                                                                  const float* __restrict__ cc, const float* __restrict__ mscale,
+                                                                  const float* __restrict__ mshift, T* __restrict__ dy,
+                                                                  size_t nvec, int C) {
+    constexpr int EPV = EW<T>::EPV;
+    const int vpr = C / EPV;
+    for (size_t v = (size_t)blockIdx.x * EW_THREADS + threadIdx.x; v < nvec; v += (size_t)gridDim.x * EW_THREADS) {
+        const int c0 = (int)(v % vpr) * EPV;
+        const Vec16<T> d = *reinterpret_cast<const Vec16<T>*>(dout + v * EPV);
+        Vec16<T> b = *reinterpret_cast<const Vec16<T>*>(y + v * EPV);
+#pragma unroll
+        for (int e = 0; e < EPV; ++e) {
+            const float yy = b.get(e);
+            float de = d.get(e);
+            if (mscale && !(yy * mscale[c0 + e] + mshift[c0 + e] > 0.f)) de = 0.f;
+            b.set(e, ca[c0 + e] * de + cb[c0 + e] * yy + cc[c0 + e]);
+        }
+        *reinterpret_cast<Vec16<T>*>(dy + v * EPV) = b;
+    }
+}
+
+// x[rows][C] += bias[C]  (fp32 tail of the backbone: fc bias)
+__global__ void add_bias_kernel(float* __restrict__ x, const float* __restrict__ bias, size_t n, int C) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        x[i] += bias[i % C];
+}
+
+template <typename T>
+__global__ void cast_from_f32_kernel(const float* __restrict__ src, T* __restrict__ dst, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        dst[i] = from_f32<T>(src[i]);
+}
+template <typename T>
+__global__ void cast_to_f32_kernel(const T* __restrict__ src, float* __restrict__ dst, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        dst[i] = to_f32<T>(src[i]);
+}
+
+static int grid_for(size_t work_items, int per_block) {
+    size_t b = (work_items + per_block - 1) / per_block;
+    if (b > 2048) b = 2048;            // 256 CUs x 8 blocks, grid-stride the rest
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+static bool shape_ok(int dtype, int C, const char* who) {
+    const int epv = dtype == FRHIP_DT_BF16 ? 8 : 4;
+    if ((dtype != FRHIP_DT_BF16 && dtype != FRHIP_DT_F32) || C <= 0 || (C % epv) || (C / epv) > EW_THREADS ||
+        (EW_THREADS % (C / epv))) {
+        set_error("%s: unsupported dtype/channels (dtype=%d C=%d)", who, dtype, C);
+        return false;
+    }
+    return true;
+}
+
+}  // namespace frhip
+
+using namespace frhip;
+
+extern "C" int frhip_colreduce_blocks(int rows, int c, int dtype) {
+    const int epv = dtype == FRHIP_DT_BF16 ? 8 : 4;
+    const int rlanes = EW_THREADS / (c / epv);
+    int b = (rows + rlanes * 8 - 1) / (rlanes * 8);
+    if (b > 1024) b = 1024;
+    if (b < 1) b = 1;
+    return b;
+}
+
+extern "C" int frhip_colstats(int dtype, const void* x, int rows, int c, float* partial, hipStream_t stream) {
+    if (!shape_ok(dtype, c, "frhip_colstats")) return FRHIP_EINVAL;
+    const int blocks = frhip_colreduce_blocks(rows, c, dtype);
+    if (dtype == FRHIP_DT_BF16)
+        hipLaunchKernelGGL((colreduce_kernel<bf16_t, false>), dim3(blocks), dim3(EW_THREADS), 0, stream,
+                           (const bf16_t*)x, nullptr, nullptr, nullptr, nullptr, nullptr, partial, rows, c);
+    else
+        hipLaunchKernelGGL((colreduce_kernel<float, false>), dim3(blocks), dim3(EW_THREADS), 0, stream,
+                           (const float*)x, nullptr, nullptr, nullptr, nullptr, nullptr, partial, rows, c);
+    return check_launch("frhip_colstats");
+}
+
+extern "C" int frhip_bn_bwd_reduce(int dtype, const void* dout, const void* y, const float* mean, const float* invstd,
+                                   const float* mask_scale, const float* mask_shift, int rows, int c, float* partial,
+                                   hipStream_t stream) {
+    if (!shape_ok(dtype, c, "frhip_bn_bwd_reduce")) return FRHIP_EINVAL;
+    const int blocks = frhip_colreduce_blocks(rows, c, dtype);
+    if (dtype == FRHIP_DT_BF16)
+        hipLaunchKernelGGL((colreduce_kernel<bf16_t, true>), dim3(blocks), dim3(EW_THREADS), 0, stream,
+                           (const bf16_t*)dout, (const bf16_t*)y, mean, invstd, mask_scale, mask_shift, partial, rows, c);
+    else
+        hipLaunchKernelGGL((colreduce_kernel<float, true>), dim3(blocks), dim3(EW_THREADS), 0, stream,
+                           (const float*)dout, (const float*)y, mean, invstd, mask_scale, mask_shift, partial, rows, c);
+    return check_launch("frhip_bn_bwd_reduce");
+}
+
+static const float* fold_partials(const float* partial, int& nparts, int c, float* scratch, hipStream_t stream) {
+    if (nparts <= RED_GROUPS) return partial;
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((2 * c + 255) / 256, RED_GROUPS), dim3(256), 0, stream,
+                       partial, scratch, nparts, c);
+    nparts = RED_GROUPS;
+    return scratch;
+}
+
+extern "C" int frhip_bn_finalize(const float* partial, int nparts, float* scratch, int c, float count,
+                                 const float* gamma, const float* beta, float* running_mean, float* running_var,
+                                 float momentum, float eps, float* mean, float* invstd, float* scale, float* shift,
+                                 hipStream_t stream) {
+    // scratch: RED_GROUPS*2*c floats
+    const float* p = fold_partials(partial, nparts, c, scratch, stream);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((c + 63) / 64), dim3(64), 0, stream, p, nparts, c, count, gamma, beta,
+                       running_mean, running_var, momentum, eps, mean, invstd, scale, shift);
+    return check_launch("frhip_bn_finalize");
+}
+
+extern "C" int frhip_bn_eval_affine(int c, const float* gamma, const float* beta, const float* running_mean,
+                                    const float* running_var, float eps, float* scale, float* shift, hipStream_t stream) {
+    hipLaunchKernelGGL(bn_eval_kernel, dim3((c + 63) / 64), dim3(64), 0, stream, c, gamma, beta, running_mean,
+                       running_var, eps, scale, shift);
+    return check_launch("frhip_bn_eval_affine");
+}
+
+extern "C" int frhip_bn_bwd_finalize(const float* partial, int nparts, float* scratch, int c, float count,
+                                     const float* gamma, const float* mean, const float* invstd, float* dgamma,
+                                     float* dbeta, float* ca, float* cb, float* cc, hipStream_t stream) {
+    const float* p = fold_partials(partial, nparts, c, scratch, stream);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((c + 63) / 64), dim3(64), 0, stream, p, nparts, c, count, gamma,
+                       mean, invstd, dgamma, dbeta, ca, cb, cc);
+    return check_launch("frhip_bn_bwd_finalize");
+}
+
+extern "C" int frhip_bn_apply(int dtype, const void* y, const float* scale, const float* shift, const void* res,
+                              const float* res_scale, const float* res_shift, int relu, void* out, int rows, int c,
+                              hipStream_t stream) {
+    if (!shape_ok(dtype, c, "frhip_bn_apply")) return FRHIP_EINVAL;
+    const int epv = dtype == FRHIP_DT_BF16 ? 8 : 4;
+    const size_t nvec = (size_t)rows * c / epv;
+    const int blocks = grid_for(nvec, EW_THREADS);
+    if (dtype == FRHIP_DT_BF16)
+        hipLaunchKernelGGL(bn_apply_kernel<bf16_t>, dim3(blocks), dim3(EW_THREADS), 0, stream, (const bf16_t*)y, scale,
+                           shift, (const bf16_t*)res, res_scale, res_shift, relu, (bf16_t*)out, nvec, c);
+    else
+        hipLaunchKernelGGL(bn_apply_kernel<float>, dim3(blocks), dim3(EW_THREADS), 0, stream, (const float*)y, scale,
+                           shift, (const float*)res, res_scale, res_shift, relu, (float*)out, nvec, c);
+    return check_launch("frhip_bn_apply");
+}
+
+extern "C" int frhip_bn_bwd_apply(int dtype, const void* dout, const void* y, const float* ca, const float* cb,
+                                  const float* cc, const float* mask_scale, const float* mask_shift, void* dy,
+                                  int rows, int c, hipStream_t stream) {
+    if (!shape_ok(dtype, c, "frhip_bn_bwd_apply")) return FRHIP_EINVAL;
+    const int epv = dtype == FRHIP_DT_BF16 ? 8 : 4;
+    const size_t nvec = (size_t)rows * c / epv;
+    const int blocks = grid_for(nvec, EW_THREADS);
+    if (dtype == FRHIP_DT_BF16)
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(blocks), dim3(EW_THREADS), 0, stream, (const bf16_t*)dout,
+                           (const bf16_t*)y, ca, cb, cc, mask_scale, mask_shift, (bf16_t*)dy, nvec, c);
+    else
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(blocks), dim3(EW_THREADS), 0, stream, (const float*)dout,
+                           (const float*)y, ca, cb, cc, mask_scale, mask_shift, (float*)dy, nvec, c);
+    return check_launch("frhip_bn_bwd_apply");
+}
+
+extern "C" int frhip_add_bias(float* x, const float* bias, int rows, int c, hipStream_t stream) {
+    const size_t n = (size_t)rows * c;
+    hipLaunchKernelGGL(add_bias_kernel, dim3(grid_for(n, 256)), dim3(256), 0, stream, x, bias, n, c);
+    return check_launch("frhip_add_bias");
+}
+
+extern "C" int frhip_cast_from_f32(int dtype, const float* src, void* dst, size_t n, hipStream_t stream) {
+    if (dtype == FRHIP_DT_BF16)
+        hipLaunchKernelGGL(cast_from_f32_kernel<bf16_t>, dim3(grid_for(n, 256)), dim3(256), 0, stream, src, (bf16_t*)dst, n);
+    else
+        hipLaunchKernelGGL(cast_from_f32_kernel<float>, dim3(grid_for(n, 256)), dim3(256), 0, stream, src, (float*)dst, n);
+    return check_launch("frhip_cast_from_f32");
+}
+
+extern "C" int frhip_cast_to_f32(int dtype, const void* src, float* dst, size_t n, hipStream_t stream) {
+    if (dtype == FRHIP_DT_BF16)
+        hipLaunchKernelGGL(cast_to_f32_kernel<bf16_t>, dim3(grid_for(n, 256)), dim3(256), 0, stream, (const bf16_t*)src, dst, n);
+    else
+        hipLaunchKernelGGL(cast_to_f32_kernel<float>, dim3(grid_for(n, 256)), dim3(256), 0, stream, (const float*)src, dst, n);
+    return check_launch("frhip_cast_to_f32");
+}

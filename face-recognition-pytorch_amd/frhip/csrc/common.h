@@ -1,0 +1,109 @@
+// frhip -- shared device helpers for the gfx950 (MI355X / CDNA4) kernels.
+// One target only: wave = 64 lanes, MFMA 16x16x32 bf16 / 16x16x4 f32, LDS-DMA via buffer_load ... lds.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+typedef __attribute__((ext_vector_type(4))) short i16x4_t;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2_t;
+
+#define FRHIP_OK 0
+#define FRHIP_EINVAL (-1)
+#define FRHIP_ELAUNCH (-2)
+#define FRHIP_DT_BF16 0
+#define FRHIP_DT_F32 1
+
+#define LDS_ADDR(p) ((__attribute__((address_space(3))) void*)(p))
+
+namespace frhip {
+
+void set_error(const char* fmt, ...);
+int check_launch(const char* what);
+
+// ---- buffer resource (raw, stride 0).  OOB reads return 0 -- used for conv zero padding.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
+}
+constexpr uint32_t OOB_OFFSET = 0x80000000u;   // >= any num_records we use (< 2 GiB per tensor)
+
+// 16 bytes per lane, global -> LDS without touching VGPRs.  LDS dest = lds_base + lane*16.
+__device__ __forceinline__ void glds16(__amdgpu_buffer_rsrc_t rsrc, void* lds_base, uint32_t voff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_ADDR(lds_base), 16, voff, 0, 0, 0);
+}
+
+// ---- element <-> float
+template <typename T> __device__ __forceinline__ float to_f32(T v);
+template <> __device__ __forceinline__ float to_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ float to_f32<bf16_t>(bf16_t v) { return (float)v; }
+template <typename T> __device__ __forceinline__ T from_f32(float v);
+template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float v) { return (bf16_t)v; }
+
+// 16-byte vector of T viewed as floats
+template <typename T> struct Vec16;
+template <> struct Vec16<float> {
+    static constexpr int N = 4;
+    f32x4_t v;
+    __device__ __forceinline__ float get(int i) const { return v[i]; }
+    __device__ __forceinline__ void set(int i, float x) { v[i] = x; }
+};
+template <> struct Vec16<bf16_t> {
+    static constexpr int N = 8;
+    bf16x8_t v;
+    __device__ __forceinline__ float get(int i) const { return (float)v[i]; }
+    __device__ __forceinline__ void set(int i, float x) { v[i] = (bf16_t)x; }
+};
+
+// ---- MFMA wrappers: one "K group" = one 16-byte fragment per lane for each operand.
+//  bf16: 8 k-values / lane, one v_mfma_f32_16x16x32_bf16.
+//  f32 : 4 k-values / lane, four v_mfma_f32_16x16x4_f32 (exact f32, validation mode).
+// Operand map (both): lane l supplies A[row l&15][k-slot (l>>4)] and B[k-slot (l>>4)][col l&15];
+// D: col = l&15, row = 4*(l>>4) + reg.
+template <typename T> struct Mma;
+template <> struct Mma<bf16_t> {
+    typedef bf16x8_t Frag;
+    __device__ static __forceinline__ void run(const Frag& a, const Frag& b, f32x4_t& c) {
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+    }
+};
+template <> struct Mma<float> {
+    typedef f32x4_t Frag;
+    __device__ static __forceinline__ void run(const Frag& a, const Frag& b, f32x4_t& c) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], b[e], c, 0, 0, 0);
+    }
+};
+
+__device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
+
+// XCD-aware remap of a linear workgroup id (bijective for any nwg): consecutive logical ids land on one XCD
+// so neighbouring tiles share that XCD's L2 (blocks b and b+8 share an XCD under round-robin dispatch).
+__device__ __forceinline__ uint32_t xcd_remap(uint32_t bid, uint32_t nwg) {
+    const uint32_t q = nwg >> 3, r = nwg & 7u, xcd = bid & 7u, k = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+}
+
+struct FastDiv {      // n / d for 0 <= n < 2^31, d >= 1
+    uint32_t mul, shr, d;
+};
+inline FastDiv make_fastdiv(uint32_t d) {
+    FastDiv f; f.d = d;
+    if (d == 1) { f.mul = 0; f.shr = 0; return f; }
+    uint32_t l = 0; while ((1u << l) < d) ++l;          // ceil(log2 d)
+    uint64_t m = ((uint64_t(1) << (31 + l)) + d - 1) / d;   // ceil(2^(31+l)/d) fits in 32 bits for n < 2^31
+    f.mul = (uint32_t)m; f.shr = l - 1 + 0; f.shr = 31 + l - 32;
+    return f;
+}
+__device__ __forceinline__ uint32_t fdiv(uint32_t n, const FastDiv& f) {
+    return f.d == 1 ? n : (__umulhi(n, f.mul) >> f.shr);
+}
+
+}  // namespace frhip

@@ -1,0 +1,206 @@
+// Implicit-GEMM "NT" main loop for gfx950:  OUT[m][n] = sum_k A[m][k] * B[n][k]
+//   A rows are gathered from an NHWC activation tensor by convolution geometry (one filter tap x one
+//   128-byte channel slice per K step), B rows are K-contiguous packed weights [n][tap][c].
+//   Covers: conv forward, conv data-gradient (transposed-stride gather), plain GEMM (R=S=1, H=W=1).
+//
+// Tile: 4 waves (256 threads), each wave owns a 64 (m) x 64 (n) sub-tile = 4x4 MFMA 16x16 tiles.
+//   WM x WN waves: 2x2 -> 128x128, 4x1 -> 256x64.
+// LDS: two stages of [BM + BN] rows x 128 bytes, filled by LDS-DMA (buffer_load ... lds, 16 B per lane,
+//   out-of-range lanes read 0 = convolution zero padding), 16-byte chunks XOR-swizzled by (row & 7) on the
+//   SOURCE side so the lane-linear LDS image is conflict-free for ds_read_b128.
+// Loop (one barrier per K step):  issue DMA for step t+1 -> MFMA on step t -> vmcnt(0) -> s_barrier.
+// MFMA operand roles are swapped (weights = "A", pixels = "B") so a lane ends up holding 4 consecutive
+// output CHANNELS of one pixel: the epilogue packs them, stages the wave's 64x64 tile through LDS and
+// writes whole 128/256-byte rows.
+#pragma once
+#include "common.h"
+
+namespace frhip {
+
+struct NtGeom {
+    // activation tensor (the gathered operand)
+    int H, W, C;            // spatial size and channels of the tensor being gathered
+    int Ho, Wo;             // spatial size of the GEMM rows (output pixels)
+    int R, S, stride, pad;
+    int mode;               // 0: forward gather (hi = ho*stride - pad + r); 1: data-grad gather (hi = (ho + pad - r)/stride)
+    int M, Nout, Ktot;      // GEMM sizes: rows, cols, taps*C
+    int ksteps, ksteps_per_split;
+    uint32_t a_bytes, b_bytes;
+};
+
+constexpr int NT_ROWB = 128;                 // bytes per LDS row = one K step
+constexpr int NT_THREADS = 256;
+
+template <typename T, int WM, int WN>
+struct NtTile {
+    static constexpr int BM = WM * 64, BN = WN * 64;
+    static constexpr int BKE = NT_ROWB / (int)sizeof(T);       // K elements per step
+    static constexpr int STAGE_BYTES = (BM + BN) * NT_ROWB;
+    static constexpr int A_PIECES = BM / 32, B_PIECES = BN / 32;   // 1-KiB DMA pieces per thread... per wave: /4 waves *8 rows
+    template <typename TS> static constexpr int stage_pitch() { return 64 * (int)sizeof(TS) + 16; }
+    template <typename TS> static constexpr int lds_bytes() {
+        return (2 * STAGE_BYTES > 4 * 64 * stage_pitch<TS>()) ? 2 * STAGE_BYTES : 4 * 64 * stage_pitch<TS>();
+    }
+};
+
+// Per-thread bookkeeping of the rows this thread DMA-loads.
+template <int NPIECE>
+struct RowSet {
+    int pixbase[NPIECE];     // n*H*W (element-row index of image n), or -1 when the GEMM row is out of range
+    int hb[NPIECE], wb[NPIECE];
+};
+
+template <typename T, int WM, int WN>
+struct NtMainloop {
+    typedef NtTile<T, WM, WN> Tile;
+    typedef typename Mma<T>::Frag Frag;
+    static constexpr int BM = Tile::BM, BN = Tile::BN, BKE = Tile::BKE;
+
+    // acc[nt][mt]: D rows = channels (nt*16 + 4*(lane>>4) + reg), D col = pixel (mt*16 + (lane&15))
+    f32x4_t acc[4][4];
+
+    __device__ __forceinline__ void run(const NtGeom& g, const void* __restrict__ a_ptr,
+                                        const void* __restrict__ b_ptr, char* smem,
+                                        int mtile, int ntile, int ks_begin, int ks_end) {
+        const int lane = lane_id();
+        const int wave = wave_id();
+        const int wm = wave / WN, wn = wave % WN;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        if (ks_begin >= ks_end) return;
+
+        const __amdgpu_buffer_rsrc_t ra = make_rsrc(a_ptr, g.a_bytes);
+        const __amdgpu_buffer_rsrc_t rb = make_rsrc(b_ptr, g.b_bytes);
+
+        // ---- rows this thread stages.  piece q covers tile rows 8q..8q+7; lane -> row 8q + (lane>>3),
+        //      physical chunk (lane&7), logical (source) chunk (lane&7) ^ (row&7).
+        const int sub = lane >> 3;
+        const uint32_t chunk_bytes = (uint32_t)(((lane & 7) ^ sub) * 16);
+        RowSet<Tile::A_PIECES> ar;
+        const int HoWo = g.Ho * g.Wo;
+#pragma unroll
+        for (int j = 0; j < Tile::A_PIECES; ++j) {
+            const int row = (wave * Tile::A_PIECES + j) * 8 + sub;
+            const int m = mtile * BM + row;
+            if (m < g.M) {
+                const int n = m / HoWo, rem = m - n * HoWo;
+                const int ho = rem / g.Wo, wo = rem - ho * g.Wo;
+                ar.pixbase[j] = n * g.H * g.W;
+                if (g.mode == 0) { ar.hb[j] = ho * g.stride - g.pad; ar.wb[j] = wo * g.stride - g.pad; }
+                else             { ar.hb[j] = ho + g.pad;            ar.wb[j] = wo + g.pad; }
+            } else {
+                ar.pixbase[j] = -1; ar.hb[j] = 0; ar.wb[j] = 0;
+            }
+        }
+        uint32_t brow_off[Tile::B_PIECES];
+#pragma unroll
+        for (int j = 0; j < Tile::B_PIECES; ++j) {
+            const int row = (wave * Tile::B_PIECES + j) * 8 + sub;
+            const int n = ntile * BN + row;
+            brow_off[j] = (n < g.Nout) ? (uint32_t)n * (uint32_t)g.Ktot * (uint32_t)sizeof(T) + chunk_bytes
+                                       : OOB_OFFSET;
+        }
+
+        const int cchunks = g.C / BKE;
+        int tap = ks_begin / cchunks;
+        int c0 = (ks_begin - tap * cchunks) * BKE;
+        int fr = tap / g.S, fs = tap - fr * g.S;
+
+        auto stage = [&](int buf) {
+            char* sa = smem + buf * Tile::STAGE_BYTES;
+            char* sb = sa + BM * NT_ROWB;
+#pragma unroll
+            for (int j = 0; j < Tile::A_PIECES; ++j) {
+                int hi, wi; bool ok = ar.pixbase[j] >= 0;
+                if (g.mode == 0) {
+                    hi = ar.hb[j] + fr; wi = ar.wb[j] + fs;
+                } else {
+                    const int th = ar.hb[j] - fr, tw = ar.wb[j] - fs;
+                    ok = ok && th >= 0 && tw >= 0;
+                    if (g.stride == 2) { ok = ok && !((th | tw) & 1); hi = th >> 1; wi = tw >> 1; }
+                    else { hi = th; wi = tw; }
+                }
+                ok = ok && (unsigned)hi < (unsigned)g.H && (unsigned)wi < (unsigned)g.W;
+                const uint32_t off = ok ? (uint32_t)((ar.pixbase[j] + hi * g.W + wi) * g.C + c0) * (uint32_t)sizeof(T) + chunk_bytes
+                                        : OOB_OFFSET;
+                glds16(ra, sa + (wave * Tile::A_PIECES + j) * 1024, off);
+            }
+            const uint32_t kb = (uint32_t)(tap * g.C + c0) * (uint32_t)sizeof(T);
+#pragma unroll
+            for (int j = 0; j < Tile::B_PIECES; ++j) {
+                const uint32_t off = brow_off[j] == OOB_OFFSET ? OOB_OFFSET : brow_off[j] + kb;
+                glds16(rb, sb + (wave * Tile::B_PIECES + j) * 1024, off);
+            }
+            // advance to the next K step
+            c0 += BKE;
+            if (c0 == g.C) { c0 = 0; ++tap; ++fs; if (fs == g.S) { fs = 0; ++fr; } }
+        };
+
+        // fragment read addresses (bytes inside a stage): row = base + i, chunk (g + 4s) ^ (row & 7)
+        const int fi = lane & 15, fg = lane >> 4;
+        const int xoff = ((wm * 64 + fi) * NT_ROWB);                 // pixel rows (MFMA "B" operand)
+        const int woff = BM * NT_ROWB + ((wn * 64 + fi) * NT_ROWB);  // weight rows (MFMA "A" operand)
+        const int sw = fi & 7;   // (row & 7) == (fi & 7) because tile bases are multiples of 16
+
+        auto compute = [&](int buf) {
+            const char* base = smem + buf * Tile::STAGE_BYTES;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const int ch = ((fg + 4 * s) ^ sw) * 16;
+                Frag xf[4], wf[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    xf[t] = *reinterpret_cast<const Frag*>(base + xoff + t * 16 * NT_ROWB + ch);
+                    wf[t] = *reinterpret_cast<const Frag*>(base + woff + t * 16 * NT_ROWB + ch);
+                }
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt) Mma<T>::run(wf[nt], xf[mt], acc[nt][mt]);
+            }
+        };
+
+        stage(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        int cur = 0;
+        for (int ks = ks_begin; ks < ks_end - 1; ++ks) {
+            stage(cur ^ 1);
+            compute(cur);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            cur ^= 1;
+        }
+        compute(cur);
+    }
+
+    // Write this wave's 64x64 tile to its private LDS staging area as TS (row = pixel, 64 channels).
+    template <typename TS>
+    __device__ __forceinline__ char* stage_out(char* smem) {
+        constexpr int P = Tile::template stage_pitch<TS>();
+        const int lane = lane_id();
+        const int fi = lane & 15, fg = lane >> 4;
+        char* mine = smem + wave_id() * 64 * P;
+        __syncthreads();        // every wave is done reading the operand stages
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                char* p = mine + (mt * 16 + fi) * P + (nt * 16 + 4 * fg) * (int)sizeof(TS);
+                if constexpr (sizeof(TS) == 4) {
+                    *reinterpret_cast<f32x4_t*>(p) = acc[nt][mt];
+                } else {
+                    bf16x4_t v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = (bf16_t)acc[nt][mt][e];
+                    *reinterpret_cast<bf16x4_t*>(p) = v;
+                }
+            }
+        __syncthreads();
+        return mine;
+    }
+};
+
+}  // namespace frhip

@@ -1,0 +1,201 @@
+// Convolution forward / data-gradient and plain NT GEMM on the shared implicit-GEMM main loop.
+// Replaces what the reference gets from cuDNN/cuBLAS behind nn.Conv2d / F.linear:
+//   /root/reference/nets/resnet.py:23-46 (conv3x3 / conv1x1), :89-103 (BasicBlock), :244 (fc).
+#include "igemm_nt.h"
+#include "frhip.h"
+
+namespace frhip {
+
+enum { EPI_STORE = 0, EPI_ATOMIC = 1 };
+
+template <typename T, int WM, int WN, int EPI>
+__global__ __launch_bounds__(NT_THREADS, 2) void nt_kernel(NtGeom g, const void* __restrict__ a,
+                                                           const void* __restrict__ b, void* __restrict__ out,
+                                                           const void* __restrict__ res, float* __restrict__ stats,
+                                                           int mtiles, int ntiles) {
+    typedef NtTile<T, WM, WN> Tile;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const uint32_t lin = xcd_remap(blockIdx.x, gridDim.x);
+    const int ntile = (int)(lin % (uint32_t)ntiles), mtile = (int)(lin / (uint32_t)ntiles);
+    const int ks_begin = blockIdx.y * g.ksteps_per_split;
+    const int ks_end = min(g.ksteps, ks_begin + g.ksteps_per_split);
+
+    NtMainloop<T, WM, WN> ml;
+    ml.run(g, a, b, smem, mtile, ntile, ks_begin, ks_end);
+
+    const int lane = lane_id(), wave = wave_id();
+    const int wm = wave / WN, wn = wave % WN;
+    const int m0 = mtile * Tile::BM + wm * 64, n0 = ntile * Tile::BN + wn * 64;
+
+    if constexpr (EPI == EPI_STORE) {
+        constexpr int P = Tile::template stage_pitch<T>();
+        constexpr int EPV = 16 / (int)sizeof(T);          // elements per 16-byte vector
+        constexpr int LPR = 64 / EPV;                     // lanes per 64-channel row
+        constexpr int RPI = 64 / LPR;                     // rows per wave instruction
+        const char* mine = ml.template stage_out<T>(smem);
+        const int chunk = lane % LPR, rsub = lane / LPR;
+        const int n = n0 + chunk * EPV;
+        float s1[EPV], s2[EPV];
+#pragma unroll
+        for (int e = 0; e < EPV; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
+        T* o = reinterpret_cast<T*>(out);
+        const T* r = reinterpret_cast<const T*>(res);
+#pragma unroll 4
+        for (int it = 0; it < 64 / RPI; ++it) {
+            const int row = it * RPI + rsub;
+            const int m = m0 + row;
+            Vec16<T> v = *reinterpret_cast<const Vec16<T>*>(mine + row * P + chunk * 16);
+            if (m < g.M && n < g.Nout) {
+                const size_t idx = (size_t)m * g.Nout + n;
+                if (r) {
+                    const Vec16<T> rv = *reinterpret_cast<const Vec16<T>*>(r + idx);
+#pragma unroll
+                    for (int e = 0; e < EPV; ++e) v.set(e, v.get(e) + rv.get(e));
+                }
+                *reinterpret_cast<Vec16<T>*>(o + idx) = v;
+            }
+#pragma unroll
+            for (int e = 0; e < EPV; ++e) { const float x = v.get(e); s1[e] += x; s2[e] += x * x; }
+        }
+        if (stats) {
+            // rows beyond M were gathered as zeros -> contribute 0.  Reduce over the lanes that share `chunk`.
+#pragma unroll
+            for (int e = 0; e < EPV; ++e) {
+#pragma unroll
+                for (int d = LPR; d < 64; d <<= 1) {
+                    s1[e] += __shfl_xor(s1[e], d);
+                    s2[e] += __shfl_xor(s2[e], d);
+                }
+            }
+            __syncthreads();                                // staging area is free again
+            float* red = reinterpret_cast<float*>(smem);   // [wave][2][64]
+            if (lane < LPR) {
+#pragma unroll
+                for (int e = 0; e < EPV; ++e) {
+                    red[(wave * 2 + 0) * 64 + chunk * EPV + e] = s1[e];
+                    red[(wave * 2 + 1) * 64 + chunk * EPV + e] = s2[e];
+                }
+            }
+            __syncthreads();
+            // one thread per (wn, stat, channel): sum over the WM waves that share wn
+            for (int t = threadIdx.x; t < WN * 2 * 64; t += NT_THREADS) {
+                const int c = t & 63, st = (t >> 6) & 1, w_n = t >> 7;
+                float acc = 0.f;
+#pragma unroll
+                for (int w_m = 0; w_m < WM; ++w_m) acc += red[((w_m * WN + w_n) * 2 + st) * 64 + c];
+                const int nn = ntile * Tile::BN + w_n * 64 + c;
+                if (nn < g.Nout) stats[((size_t)mtile * 2 + st) * g.Nout + nn] = acc;
+            }
+        }
+    } else {
+        constexpr int P = Tile::template stage_pitch<float>();
+        const char* mine = ml.template stage_out<float>(smem);
+        float* o = reinterpret_cast<float*>(out);
+        const int n = n0 + lane;
+        for (int row = 0; row < 64; ++row) {
+            const int m = m0 + row;
+            if (m < g.M && n < g.Nout)
+                atomicAdd(o + (size_t)m * g.Nout + n, *reinterpret_cast<const float*>(mine + row * P + lane * 4));
+        }
+    }
+}
+
+template <typename T, int WM, int WN, int EPI>
+static int nt_launch_cfg(const NtGeom& g, const void* a, const void* b, void* out, const void* res,
+                         float* stats, int splits, hipStream_t stream) {
+    typedef NtTile<T, WM, WN> Tile;
+    const int mtiles = (g.M + Tile::BM - 1) / Tile::BM, ntiles = (g.Nout + Tile::BN - 1) / Tile::BN;
+    const int lds = (EPI == EPI_STORE) ? Tile::template lds_bytes<T>() : Tile::template lds_bytes<float>();
+    auto kern = nt_kernel<T, WM, WN, EPI>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
+            set_error("igemm_nt: cannot raise dynamic LDS to %d bytes", lds);
+            return FRHIP_ELAUNCH;
+        }
+        attr_done = true;
+    }
+    dim3 grid(mtiles * ntiles, splits);
+    hipLaunchKernelGGL(kern, grid, dim3(NT_THREADS), lds, stream, g, a, b, out, res, stats, mtiles, ntiles);
+    return check_launch("igemm_nt");
+}
+
+static int nt_dispatch(int dtype, const NtGeom& g, const void* a, const void* b, void* out, const void* res,
+                       float* stats, int splits, bool atomic, hipStream_t stream) {
+    const bool wide = (g.Nout % 128) == 0 || g.Nout > 256;     // 128x128 tile, else 256x64
+#define NT_CASE(T)                                                                                         \
+    do {                                                                                                   \
+        if (atomic) return wide ? nt_launch_cfg<T, 2, 2, EPI_ATOMIC>(g, a, b, out, res, stats, splits, stream)  \
+                                : nt_launch_cfg<T, 4, 1, EPI_ATOMIC>(g, a, b, out, res, stats, splits, stream); \
+        return wide ? nt_launch_cfg<T, 2, 2, EPI_STORE>(g, a, b, out, res, stats, splits, stream)           \
+                    : nt_launch_cfg<T, 4, 1, EPI_STORE>(g, a, b, out, res, stats, splits, stream);          \
+    } while (0)
+    if (dtype == FRHIP_DT_BF16) NT_CASE(bf16_t);
+    if (dtype == FRHIP_DT_F32) NT_CASE(float);
+#undef NT_CASE
+    set_error("igemm_nt: bad dtype %d", dtype);
+    return FRHIP_EINVAL;
+}
+
+static int esize(int dtype) { return dtype == FRHIP_DT_BF16 ? 2 : 4; }
+
+static int fill_geom(NtGeom& g, int dtype, int n, int h, int w, int c, int ho, int wo, int k, int r, int s,
+                     int stride, int pad, int mode, const char* who) {
+    const int bke = NT_ROWB / esize(dtype);
+    if (n <= 0 || h <= 0 || w <= 0 || c <= 0 || k <= 0 || (c % bke) != 0 || (k % 8) != 0 || (stride != 1 && stride != 2)) {
+        set_error("%s: unsupported shape n=%d h=%d w=%d c=%d k=%d stride=%d (c must be a multiple of %d, k of 8)",
+                  who, n, h, w, c, k, stride, bke);
+        return FRHIP_EINVAL;
+    }
+    const long long a_bytes = 1LL * n * h * w * c * esize(dtype), b_bytes = 1LL * k * r * s * c * esize(dtype);
+    if (a_bytes > 0x7fffffffLL || b_bytes > 0x7fffffffLL || 1LL * n * ho * wo > 0x7fffffffLL) {
+        set_error("%s: tensor exceeds the 2 GiB buffer-addressing window", who);
+        return FRHIP_EINVAL;
+    }
+    g.H = h; g.W = w; g.C = c; g.Ho = ho; g.Wo = wo; g.R = r; g.S = s; g.stride = stride; g.pad = pad; g.mode = mode;
+    g.M = n * ho * wo; g.Nout = k; g.Ktot = r * s * c;
+    g.ksteps = r * s * (c / bke); g.ksteps_per_split = g.ksteps;
+    g.a_bytes = (uint32_t)a_bytes; g.b_bytes = (uint32_t)b_bytes;
+    return FRHIP_OK;
+}
+
+}  // namespace frhip
+
+using namespace frhip;
+
+extern "C" int frhip_nt_block_m(int nout) { return ((nout % 128) == 0 || nout > 256) ? 128 : 256; }
+
+extern "C" int frhip_conv_fwd(int dtype, const void* x, const void* w, void* y, float* stats_partial,
+                              int n, int h, int wd, int c, int k, int r, int s, int stride, int pad,
+                              hipStream_t stream) {
+    NtGeom g;
+    const int ho = (h + 2 * pad - r) / stride + 1, wo = (wd + 2 * pad - s) / stride + 1;
+    int rc = fill_geom(g, dtype, n, h, wd, c, ho, wo, k, r, s, stride, pad, 0, "frhip_conv_fwd");
+    if (rc) return rc;
+    return nt_dispatch(dtype, g, x, w, y, nullptr, stats_partial, 1, false, stream);
+}
+
+extern "C" int frhip_conv_dgrad(int dtype, const void* dy, const void* wt, void* dx, const void* residual,
+                                int n, int h, int wd, int c, int k, int r, int s, int stride, int pad,
+                                hipStream_t stream) {
+    // dx is [n,h,wd,c]; dy is [n,ho,wo,k]; wt is the transposed pack [c][r][s][k].
+    NtGeom g;
+    const int ho = (h + 2 * pad - r) / stride + 1, wo = (wd + 2 * pad - s) / stride + 1;
+    int rc = fill_geom(g, dtype, n, ho, wo, k, h, wd, c, r, s, stride, pad, 1, "frhip_conv_dgrad");
+    if (rc) return rc;
+    return nt_dispatch(dtype, g, dy, wt, dx, residual, nullptr, 1, false, stream);
+}
+
+extern "C" int frhip_gemm_nt(int dtype, const void* a, const void* b, void* out, int m, int n, int k,
+                             int splits, int atomic_f32, hipStream_t stream) {
+    // out[m][n] = sum_k a[m][k] * b[n][k].  atomic_f32 == 0: out has dtype and is overwritten;
+    // atomic_f32 == 1: out is fp32, zeroed by the caller, K is split and partial sums are added atomically.
+    NtGeom g;
+    int rc = fill_geom(g, dtype, m, 1, 1, k, 1, 1, n, 1, 1, 1, 0, 0, "frhip_gemm_nt");
+    if (rc) return rc;
+    if (!atomic_f32 || splits < 1) splits = 1;
+    if (splits > g.ksteps) splits = g.ksteps;
+    g.ksteps_per_split = (g.ksteps + splits - 1) / splits;
+    splits = (g.ksteps + g.ksteps_per_split - 1) / g.ksteps_per_split;
+    return nt_dispatch(dtype, g, a, b, out, nullptr, nullptr, splits, atomic_f32 != 0, stream);
+}

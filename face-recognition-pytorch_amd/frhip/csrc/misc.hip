@@ -1,0 +1,195 @@
+// Layout packs (fp32 master weights -> compute-dtype operand packs), 2-D transposes, row gather/scatter for the
+// PartialFC sampled rows, and the library's error plumbing.  All HBM-bound byte movers.
+#include <stdarg.h>
+#include <stdio.h>
+#include "common.h"
+#include "frhip.h"
+
+namespace frhip {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("%s: launch failed: %s", what, hipGetErrorString(e));
+        return FRHIP_ELAUNCH;
+    }
+    return FRHIP_OK;
+}
+
+// w[K][RS][C] fp32 -> wt[C][RS][K] T   (data-gradient operand: K-contiguous over output channels)
+template <typename T>
+__global__ void pack_wt_kernel(const float* __restrict__ w, T* __restrict__ wt, int K, int RS, int C) {
+    __shared__ float tile[32][33];
+    const int rs = blockIdx.z, c0 = blockIdx.x * 32, k0 = blockIdx.y * 32;
+    for (int j = threadIdx.y; j < 32; j += blockDim.y) {
+        const int k = k0 + j, c = c0 + threadIdx.x;
+        tile[j][threadIdx.x] = (k < K && c < C) ? w[((size_t)k * RS + rs) * C + c] : 0.f;
+    }
+    __syncthreads();
+    for (int j = threadIdx.y; j < 32; j += blockDim.y) {
+        const int c = c0 + j, k = k0 + threadIdx.x;
+        if (c < C && k < K) wt[((size_t)c * RS + rs) * K + k] = from_f32<T>(tile[threadIdx.x][j]);
+    }
+}
+
+// generic 2-D transpose in[rows][cols] -> out[cols][rows]
+template <typename TI, typename TO>
+__global__ void transpose2d_kernel(const TI* __restrict__ in, TO* __restrict__ out, int rows, int cols) {
+    __shared__ float tile[32][33];
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    for (int j = threadIdx.y; j < 32; j += blockDim.y) {
+        const int r = r0 + j, c = c0 + threadIdx.x;
+        tile[j][threadIdx.x] = (r < rows && c < cols) ? to_f32<TI>(in[(size_t)r * cols + c]) : 0.f;
+    }
+    __syncthreads();
+    for (int j = threadIdx.y; j < 32; j += blockDim.y) {
+        const int c = c0 + j, r = r0 + threadIdx.x;
+        if (c < cols && r < rows) out[(size_t)c * rows + r] = from_f32<TO>(tile[threadIdx.x][j]);
+    }
+}
+
+// stem weight: w[64][27] fp32 -> wp[64][KP] T zero padded;  grad: dw[64][27] += dwp[64][KP]
+template <typename T>
+__global__ void pack_stem_kernel(const float* __restrict__ w, T* __restrict__ wp, int K, int kin, int kp) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= K * kp) return;
+    const int k = i / kp, j = i - k * kp;
+    wp[i] = from_f32<T>(j < kin ? w[k * kin + j] : 0.f);
+}
+__global__ void unpack_stem_grad_kernel(const float* __restrict__ dwp, float* __restrict__ dw, int K, int kin, int kp) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= K * kin) return;
+    const int k = i / kin, j = i - k * kin;
+    dw[i] += dwp[k * kp + j];
+}
+
+// fc weight: W[n][c*HW + p] fp32 (NCHW flatten order of the reference, nets/resnet.py:243)
+//        ->  Wp[n][p*C + c] T (NHWC flatten order used by this backbone).  One block per (n, 64-channel chunk).
+template <typename T>
+__global__ __launch_bounds__(256) void fc_permute_kernel(const float* __restrict__ w, T* __restrict__ wp, int C, int HW) {
+    extern __shared__ float sh[];      // [64][HW]
+    const int n = blockIdx.x, c0 = blockIdx.y * 64;
+    const size_t row = (size_t)n * C * HW;
+    for (int i = threadIdx.x; i < 64 * HW; i += 256) sh[i] = w[row + (size_t)c0 * HW + i];
+    __syncthreads();
+    for (int i = threadIdx.x; i < 64 * HW; i += 256) {
+        const int p = i / 64, c = i - p * 64;
+        wp[row + (size_t)p * C + c0 + c] = from_f32<T>(sh[c * HW + p]);
+    }
+}
+// grad back: dW[n][c*HW + p] += dWp[n][p*C + c]
+__global__ __launch_bounds__(256) void fc_unpermute_grad_kernel(const float* __restrict__ dwp, float* __restrict__ dw, int C, int HW) {
+    extern __shared__ float sh[];      // [HW][64]
+    const int n = blockIdx.x, c0 = blockIdx.y * 64;
+    const size_t row = (size_t)n * C * HW;
+    for (int i = threadIdx.x; i < 64 * HW; i += 256) {
+        const int p = i / 64, c = i - p * 64;
+        sh[i] = dwp[row + (size_t)p * C + c0 + c];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 64 * HW; i += 256) {
+        const int c = i / HW, p = i - c * HW;
+        dw[row + (size_t)c0 * HW + i] += sh[p * 64 + c];
+    }
+}
+
+// rows: dst[i][:] = src[index[i]][:]   /   dst[index[i]][:] = src[i][:]     (fp32 rows of D floats, D % 4 == 0)
+__global__ void gather_rows_kernel(const float* __restrict__ src, const int64_t* __restrict__ index,
+                                   float* __restrict__ dst, int n, int D) {
+    const int vpr = D / 4;
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < (size_t)n * vpr; t += (size_t)gridDim.x * blockDim.x) {
+        const int i = (int)(t / vpr), v = (int)(t - (size_t)i * vpr);
+        reinterpret_cast<f32x4_t*>(dst)[t] = reinterpret_cast<const f32x4_t*>(src)[(size_t)index[i] * vpr + v];
+    }
+}
+__global__ void scatter_rows_kernel(const float* __restrict__ src, const int64_t* __restrict__ index,
+                                    float* __restrict__ dst, int n, int D) {
+    const int vpr = D / 4;
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < (size_t)n * vpr; t += (size_t)gridDim.x * blockDim.x) {
+        const int i = (int)(t / vpr), v = (int)(t - (size_t)i * vpr);
+        reinterpret_cast<f32x4_t*>(dst)[(size_t)index[i] * vpr + v] = reinterpret_cast<const f32x4_t*>(src)[t];
+    }
+}
+
+}  // namespace frhip
+
+using namespace frhip;
+
+extern "C" const char* frhip_last_error(void) { return g_err; }
+extern "C" int frhip_abi_version(void) { return 1; }
+
+extern "C" int frhip_pack_wt(int dtype, const float* w, void* wt, int k, int rs, int c, hipStream_t stream) {
+    dim3 grid((c + 31) / 32, (k + 31) / 32, rs), block(32, 8);
+    if (dtype == FRHIP_DT_BF16) hipLaunchKernelGGL(pack_wt_kernel<bf16_t>, grid, block, 0, stream, w, (bf16_t*)wt, k, rs, c);
+    else if (dtype == FRHIP_DT_F32) hipLaunchKernelGGL(pack_wt_kernel<float>, grid, block, 0, stream, w, (float*)wt, k, rs, c);
+    else { set_error("frhip_pack_wt: bad dtype %d", dtype); return FRHIP_EINVAL; }
+    return check_launch("frhip_pack_wt");
+}
+
+extern "C" int frhip_transpose2d(int dtype_in, int dtype_out, const void* in, void* out, int rows, int cols, hipStream_t stream) {
+    dim3 grid((cols + 31) / 32, (rows + 31) / 32), block(32, 8);
+    const int key = dtype_in * 2 + dtype_out;
+    switch (key) {
+        case 0: hipLaunchKernelGGL((transpose2d_kernel<bf16_t, bf16_t>), grid, block, 0, stream, (const bf16_t*)in, (bf16_t*)out, rows, cols); break;
+        case 1: hipLaunchKernelGGL((transpose2d_kernel<bf16_t, float>), grid, block, 0, stream, (const bf16_t*)in, (float*)out, rows, cols); break;
+        case 2: hipLaunchKernelGGL((transpose2d_kernel<float, bf16_t>), grid, block, 0, stream, (const float*)in, (bf16_t*)out, rows, cols); break;
+        case 3: hipLaunchKernelGGL((transpose2d_kernel<float, float>), grid, block, 0, stream, (const float*)in, (float*)out, rows, cols); break;
+        default: set_error("frhip_transpose2d: bad dtypes"); return FRHIP_EINVAL;
+    }
+    return check_launch("frhip_transpose2d");
+}
+
+extern "C" int frhip_pack_stem(int dtype, const float* w, void* wp, int k, int kin, int kp, hipStream_t stream) {
+    const int n = k * kp;
+    if (dtype == FRHIP_DT_BF16) hipLaunchKernelGGL(pack_stem_kernel<bf16_t>, dim3((n + 255) / 256), dim3(256), 0, stream, w, (bf16_t*)wp, k, kin, kp);
+    else if (dtype == FRHIP_DT_F32) hipLaunchKernelGGL(pack_stem_kernel<float>, dim3((n + 255) / 256), dim3(256), 0, stream, w, (float*)wp, k, kin, kp);
+    else { set_error("frhip_pack_stem: bad dtype %d", dtype); return FRHIP_EINVAL; }
+    return check_launch("frhip_pack_stem");
+}
+
+extern "C" int frhip_unpack_stem_grad(const float* dwp, float* dw, int k, int kin, int kp, hipStream_t stream) {
+    const int n = k * kin;
+    hipLaunchKernelGGL(unpack_stem_grad_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, dwp, dw, k, kin, kp);
+    return check_launch("frhip_unpack_stem_grad");
+}
+
+extern "C" int frhip_fc_permute(int dtype, const float* w, void* wp, int nout, int c, int hw, hipStream_t stream) {
+    if (c % 64) { set_error("frhip_fc_permute: channels must be a multiple of 64"); return FRHIP_EINVAL; }
+    dim3 grid(nout, c / 64);
+    const int lds = 64 * hw * 4;
+    if (dtype == FRHIP_DT_BF16) hipLaunchKernelGGL(fc_permute_kernel<bf16_t>, grid, dim3(256), lds, stream, w, (bf16_t*)wp, c, hw);
+    else if (dtype == FRHIP_DT_F32) hipLaunchKernelGGL(fc_permute_kernel<float>, grid, dim3(256), lds, stream, w, (float*)wp, c, hw);
+    else { set_error("frhip_fc_permute: bad dtype %d", dtype); return FRHIP_EINVAL; }
+    return check_launch("frhip_fc_permute");
+}
+
+extern "C" int frhip_fc_unpermute_grad(const float* dwp, float* dw, int nout, int c, int hw, hipStream_t stream) {
+    if (c % 64) { set_error("frhip_fc_unpermute_grad: channels must be a multiple of 64"); return FRHIP_EINVAL; }
+    hipLaunchKernelGGL(fc_unpermute_grad_kernel, dim3(nout, c / 64), dim3(256), 64 * hw * 4, stream, dwp, dw, c, hw);
+    return check_launch("frhip_fc_unpermute_grad");
+}
+
+extern "C" int frhip_gather_rows(const float* src, const int64_t* index, float* dst, int n, int d, hipStream_t stream) {
+    if (d % 4) { set_error("frhip_gather_rows: row length must be a multiple of 4"); return FRHIP_EINVAL; }
+    if (n == 0) return FRHIP_OK;
+    size_t total = (size_t)n * (d / 4); int blocks = (int)((total + 255) / 256); if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(blocks), dim3(256), 0, stream, src, index, dst, n, d);
+    return check_launch("frhip_gather_rows");
+}
+
+extern "C" int frhip_scatter_rows(const float* src, const int64_t* index, float* dst, int n, int d, hipStream_t stream) {
+    if (d % 4) { set_error("frhip_scatter_rows: row length must be a multiple of 4"); return FRHIP_EINVAL; }
+    if (n == 0) return FRHIP_OK;
+    size_t total = (size_t)n * (d / 4); int blocks = (int)((total + 255) / 256); if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(scatter_rows_kernel, dim3(blocks), dim3(256), 0, stream, src, index, dst, n, d);
+    return check_launch("frhip_scatter_rows");
+}

@@ -1,0 +1,321 @@
+"""Tensor-level wrappers over the C ABI (torch is used for device memory + the current HIP stream only)."""
+import torch
+
+from . import _abi
+from ._abi import DT_BF16, DT_F32, check, lib
+
+_DT = {torch.bfloat16: DT_BF16, torch.float32: DT_F32}
+
+
+def dt_of(t):
+    return _DT[t.dtype]
+
+
+def epv(dtype):
+    return 8 if dtype == torch.bfloat16 else 4
+
+
+def _s():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t):
+    if t is None:
+        return None
+    assert t.is_cuda and t.is_contiguous(), "frhip ops need contiguous CUDA tensors"
+    return t.data_ptr()
+
+
+def nt_block_m(k):
+    return lib().frhip_nt_block_m(k)
+
+
+# ------------------------------------------------------------------------------------------ convolution
+def conv_out_hw(h, w, r, s, stride, pad):
+    return (h + 2 * pad - r) // stride + 1, (w + 2 * pad - s) // stride + 1
+
+
+def conv_fwd(x, w, stride, pad, want_stats=True):
+    """x [N,H,W,C], w [K,R,S,C] (same dtype) -> y [N,Ho,Wo,K], stats partial [tiles,2,K] fp32 or None"""
+    n, h, wd, c = x.shape
+    k, r, s, c2 = w.shape
+    assert c == c2 and x.dtype == w.dtype
+    ho, wo = conv_out_hw(h, wd, r, s, stride, pad)
+    y = torch.empty((n, ho, wo, k), dtype=x.dtype, device=x.device)
+    part = None
+    if want_stats:
+        bm = nt_block_m(k)
+        part = torch.empty(((n * ho * wo + bm - 1) // bm, 2, k), dtype=torch.float32, device=x.device)
+    check(lib().frhip_conv_fwd(dt_of(x), _p(x), _p(w), _p(y), _p(part), n, h, wd, c, k, r, s, stride, pad, _s()),
+          "frhip_conv_fwd")
+    return y, part
+
+
+def conv_dgrad(dy, wt, x_shape, r, s, stride, pad, residual=None, out=None):
+    """dy [N,Ho,Wo,K], wt [C,R,S,K] -> dx [N,H,W,C] (+ residual)"""
+    n, h, wd, c = x_shape
+    k = dy.shape[3]
+    dx = out if out is not None else torch.empty(x_shape, dtype=dy.dtype, device=dy.device)
+    check(lib().frhip_conv_dgrad(dt_of(dy), _p(dy), _p(wt), _p(dx), _p(residual), n, h, wd, c, k, r, s, stride, pad, _s()),
+          "frhip_conv_dgrad")
+    return dx
+
+
+def conv_wgrad(dy, x, dw, r, s, stride, pad, splits=0):
+    """dw [K,R,S,C] fp32 (zeroed by caller) += wgrad(dy [N,Ho,Wo,K], x [N,H,W,C])"""
+    n, h, wd, c = x.shape
+    k = dy.shape[3]
+    check(lib().frhip_conv_wgrad(dt_of(x), _p(dy), _p(x), _p(dw), n, h, wd, c, k, r, s, stride, pad, splits, _s()),
+          "frhip_conv_wgrad")
+    return dw
+
+
+def gemm_nt(a, b, out=None, splits=1, atomic_f32=False):
+    m, k = a.shape
+    n = b.shape[0]
+    if out is None:
+        out = (torch.zeros((m, n), dtype=torch.float32, device=a.device) if atomic_f32
+               else torch.empty((m, n), dtype=a.dtype, device=a.device))
+    check(lib().frhip_gemm_nt(dt_of(a), _p(a), _p(b), _p(out), m, n, k, splits, int(atomic_f32), _s()), "frhip_gemm_nt")
+    return out
+
+
+def gemm_tn(p, q, out, kc=None, splits=0):
+    """out[kc][c] fp32 += sum_m p[m][:kc] * q[m][:c]"""
+    m, ldp = p.shape
+    c = q.shape[1]
+    kc = ldp if kc is None else kc
+    check(lib().frhip_gemm_tn(dt_of(p), _p(p), _p(q), _p(out), m, kc, ldp, c, splits, _s()), "frhip_gemm_tn")
+    return out
+
+
+# ------------------------------------------------------------------------------------------ batch norm
+def colstats(x2d):
+    rows, c = x2d.shape
+    nb = lib().frhip_colreduce_blocks(rows, c, dt_of(x2d))
+    part = torch.empty((nb, 2, c), dtype=torch.float32, device=x2d.device)
+    check(lib().frhip_colstats(dt_of(x2d), _p(x2d), rows, c, _p(part), _s()), "frhip_colstats")
+    return part
+
+
+class BNState:
+    """Per-layer fp32 vectors produced by the forward finalize and consumed by apply / backward."""
+    __slots__ = ("mean", "invstd", "scale", "shift", "count")
+
+
+def bn_finalize(part, count, gamma, beta, running_mean, running_var, momentum=0.1, eps=1e-5, scratch=None):
+    c = gamma.numel()
+    dev = gamma.device
+    st = BNState()
+    buf = torch.empty((4, c), dtype=torch.float32, device=dev)
+    st.mean, st.invstd, st.scale, st.shift = buf[0], buf[1], buf[2], buf[3]
+    st.count = float(count)
+    if scratch is None:
+        scratch = torch.empty((64 * 2 * c,), dtype=torch.float32, device=dev)
+    check(lib().frhip_bn_finalize(_p(part), part.shape[0], _p(scratch), c, float(count), _p(gamma), _p(beta),
+                                  _p(running_mean), _p(running_var), momentum, eps, _p(st.mean), _p(st.invstd),
+                                  _p(st.scale), _p(st.shift), _s()), "frhip_bn_finalize")
+    return st
+
+
+def bn_eval_affine(gamma, beta, running_mean, running_var, eps=1e-5):
+    c = gamma.numel()
+    st = BNState()
+    buf = torch.empty((2, c), dtype=torch.float32, device=gamma.device)
+    st.scale, st.shift = buf[0], buf[1]
+    st.mean = st.invstd = None
+    st.count = 0.0
+    check(lib().frhip_bn_eval_affine(c, _p(gamma), _p(beta), _p(running_mean), _p(running_var), eps, _p(st.scale),
+                                     _p(st.shift), _s()), "frhip_bn_eval_affine")
+    return st
+
+
+def bn_apply(y, st, relu=False, res=None, res_st=None, out=None):
+    c = y.shape[-1]
+    rows = y.numel() // c
+    out = torch.empty_like(y) if out is None else out
+    check(lib().frhip_bn_apply(dt_of(y), _p(y), _p(st.scale), _p(st.shift), _p(res),
+                               _p(res_st.scale) if res_st is not None else None,
+                               _p(res_st.shift) if res_st is not None else None,
+                               int(relu), _p(out), rows, c, _s()), "frhip_bn_apply")
+    return out
+
+
+def bn_backward(dout, y, st, gamma, dgamma, dbeta, relu_mask=False, out=None, scratch=None):
+    """dy of BN (optionally through the ReLU that follows it); accumulates dgamma/dbeta (fp32, caller-zeroed)."""
+    c = y.shape[-1]
+    rows = y.numel() // c
+    dev = y.device
+    nb = lib().frhip_colreduce_blocks(rows, c, dt_of(y))
+    part = torch.empty((nb, 2, c), dtype=torch.float32, device=dev)
+    ms = _p(st.scale) if relu_mask else None
+    mb = _p(st.shift) if relu_mask else None
+    check(lib().frhip_bn_bwd_reduce(dt_of(y), _p(dout), _p(y), _p(st.mean), _p(st.invstd), ms, mb, rows, c, _p(part), _s()),
+          "frhip_bn_bwd_reduce")
+    coef = torch.empty((3, c), dtype=torch.float32, device=dev)
+    if scratch is None:
+        scratch = torch.empty((64 * 2 * c,), dtype=torch.float32, device=dev)
+    check(lib().frhip_bn_bwd_finalize(_p(part), nb, _p(scratch), c, float(rows), _p(gamma), _p(st.mean), _p(st.invstd),
+                                      _p(dgamma), _p(dbeta), _p(coef[0]), _p(coef[1]), _p(coef[2]), _s()),
+          "frhip_bn_bwd_finalize")
+    dy = torch.empty_like(y) if out is None else out
+    check(lib().frhip_bn_bwd_apply(dt_of(y), _p(dout), _p(y), _p(coef[0]), _p(coef[1]), _p(coef[2]), ms, mb, _p(dy),
+                                   rows, c, _s()), "frhip_bn_bwd_apply")
+    return dy
+
+
+def add_bias(x, bias):
+    check(lib().frhip_add_bias(_p(x), _p(bias), x.shape[0], x.shape[1], _s()), "frhip_add_bias")
+    return x
+
+
+def cast_from_f32(src, dtype, out=None):
+    out = torch.empty(src.shape, dtype=dtype, device=src.device) if out is None else out
+    check(lib().frhip_cast_from_f32(_DT[dtype], _p(src), _p(out), src.numel(), _s()), "frhip_cast_from_f32")
+    return out
+
+
+def cast_to_f32(src, out=None):
+    out = torch.empty(src.shape, dtype=torch.float32, device=src.device) if out is None else out
+    check(lib().frhip_cast_to_f32(dt_of(src), _p(src), _p(out), src.numel(), _s()), "frhip_cast_to_f32")
+    return out
+
+
+# ------------------------------------------------------------------------------------------ stem
+def stem_im2col(x_nchw, dtype):
+    b, c, h, w = x_nchw.shape
+    assert c == 3 and x_nchw.dtype == torch.float32
+    kp = 64 if dtype == torch.bfloat16 else 32
+    col = torch.empty((b * h * w, kp), dtype=dtype, device=x_nchw.device)
+    check(lib().frhip_stem_im2col(_DT[dtype], _p(x_nchw), _p(col), b, h, w, _s()), "frhip_stem_im2col")
+    return col
+
+
+def bn_relu_maxpool_fwd(y, st):
+    b, h, w, c = y.shape
+    hp, wp = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    out = torch.empty((b, hp, wp, c), dtype=y.dtype, device=y.device)
+    arg = torch.empty((b, hp, wp, c), dtype=torch.uint8, device=y.device)
+    check(lib().frhip_bn_relu_maxpool_fwd(dt_of(y), _p(y), _p(st.scale), _p(st.shift), _p(out), _p(arg), b, h, w, c, _s()),
+          "frhip_bn_relu_maxpool_fwd")
+    return out, arg
+
+
+def maxpool_bwd(dpool, arg, in_shape):
+    b, h, w, c = in_shape
+    da = torch.empty(in_shape, dtype=dpool.dtype, device=dpool.device)
+    check(lib().frhip_maxpool_bwd(dt_of(dpool), _p(dpool), _p(arg), _p(da), b, h, w, c, _s()), "frhip_maxpool_bwd")
+    return da
+
+
+# ------------------------------------------------------------------------------------------ packs
+def pack_wt(w_f32, dtype, out=None):
+    """w [K,R,S,C] fp32 (physical) -> [C,R,S,K] dtype"""
+    k, r, s, c = w_f32.shape
+    out = torch.empty((c, r, s, k), dtype=dtype, device=w_f32.device) if out is None else out
+    check(lib().frhip_pack_wt(_DT[dtype], _p(w_f32), _p(out), k, r * s, c, _s()), "frhip_pack_wt")
+    return out
+
+
+def transpose2d(x, out_dtype=None, out=None):
+    rows, cols = x.shape
+    out_dtype = x.dtype if out_dtype is None else out_dtype
+    out = torch.empty((cols, rows), dtype=out_dtype, device=x.device) if out is None else out
+    check(lib().frhip_transpose2d(dt_of(x), _DT[out_dtype], _p(x), _p(out), rows, cols, _s()), "frhip_transpose2d")
+    return out
+
+
+def pack_stem(w_f32_k27, dtype):
+    k = w_f32_k27.shape[0]
+    kp = 64 if dtype == torch.bfloat16 else 32
+    out = torch.empty((k, 1, 1, kp), dtype=dtype, device=w_f32_k27.device)
+    check(lib().frhip_pack_stem(_DT[dtype], _p(w_f32_k27), _p(out), k, 27, kp, _s()), "frhip_pack_stem")
+    return out
+
+
+def unpack_stem_grad(dwp, dw):
+    k, kp = dwp.shape[0], dwp.numel() // dwp.shape[0]
+    check(lib().frhip_unpack_stem_grad(_p(dwp), _p(dw), k, 27, kp, _s()), "frhip_unpack_stem_grad")
+
+
+def fc_permute(w_f32, c, hw, dtype):
+    nout = w_f32.shape[0]
+    out = torch.empty((nout, hw * c), dtype=dtype, device=w_f32.device)
+    check(lib().frhip_fc_permute(_DT[dtype], _p(w_f32), _p(out), nout, c, hw, _s()), "frhip_fc_permute")
+    return out
+
+
+def fc_unpermute_grad(dwp, dw, c, hw):
+    check(lib().frhip_fc_unpermute_grad(_p(dwp), _p(dw), dw.shape[0], c, hw, _s()), "frhip_fc_unpermute_grad")
+
+
+def gather_rows(src, index, out=None):
+    n, d = index.numel(), src.shape[1]
+    out = torch.empty((n, d), dtype=torch.float32, device=src.device) if out is None else out
+    check(lib().frhip_gather_rows(_p(src), _p(index), _p(out), n, d, _s()), "frhip_gather_rows")
+    return out
+
+
+def scatter_rows(src, index, dst):
+    check(lib().frhip_scatter_rows(_p(src), _p(index), _p(dst), index.numel(), src.shape[1], _s()), "frhip_scatter_rows")
+    return dst
+
+
+# ------------------------------------------------------------------------------------------ head
+def l2norm_rows(x, dtype, eps=1e-12):
+    rows, d = x.shape
+    xh = torch.empty((rows, d), dtype=dtype, device=x.device)
+    norms = torch.empty((rows,), dtype=torch.float32, device=x.device)
+    check(lib().frhip_l2norm_rows(_DT[dtype], _p(x), _p(xh), _p(norms), rows, d, eps, _s()), "frhip_l2norm_rows")
+    return xh, norms
+
+
+def l2norm_bwd(dxhat, xhat, norms, out_scale=1.0):
+    rows, d = dxhat.shape
+    dx = torch.empty((rows, d), dtype=torch.float32, device=dxhat.device)
+    check(lib().frhip_l2norm_bwd(dt_of(xhat), _p(dxhat), _p(xhat), _p(norms), _p(dx), rows, d, out_scale, _s()),
+          "frhip_l2norm_bwd")
+    return dx
+
+
+def head_fwd(ehat, what, labels_i32, s, m):
+    n, d = ehat.shape
+    classes = what.shape[0]
+    groups = lib().frhip_head_groups(classes)
+    dev = ehat.device
+    pm = torch.empty((groups, n), dtype=torch.float32, device=dev)
+    ps = torch.empty((groups, n), dtype=torch.float32, device=dev)
+    zt = torch.zeros((n,), dtype=torch.float32, device=dev)
+    rmax = torch.empty((n,), dtype=torch.float32, device=dev)
+    rsum = torch.empty((n,), dtype=torch.float32, device=dev)
+    check(lib().frhip_head_fwd(dt_of(ehat), _p(ehat), _p(what), _p(labels_i32), n, classes, d, s, m, _p(pm), _p(ps),
+                               _p(zt), _p(rmax), _p(rsum), _s()), "frhip_head_fwd")
+    return zt, rmax, rsum
+
+
+def head_rescale(rowsum, local_max, global_max):
+    check(lib().frhip_head_rescale(_p(rowsum), _p(local_max), _p(global_max), rowsum.numel(), _s()), "frhip_head_rescale")
+
+
+def head_target_prob(zt, labels_i32, rmax, rsum):
+    q = torch.empty_like(zt)
+    check(lib().frhip_head_target_prob(_p(zt), _p(labels_i32), _p(rmax), _p(rsum), _p(q), zt.numel(), _s()),
+          "frhip_head_target_prob")
+    return q
+
+
+def head_loss(q):
+    loss = torch.empty((1,), dtype=torch.float32, device=q.device)
+    check(lib().frhip_head_loss(_p(q), q.numel(), _p(loss), _s()), "frhip_head_loss")
+    return loss
+
+
+def head_bwd_dt(ehat, what, labels_i32, s, m, rmax, rsum, gscale):
+    n, d = ehat.shape
+    classes = what.shape[0]
+    e = epv(ehat.dtype)
+    ldt = (classes + e - 1) // e * e
+    dt = torch.empty((n, ldt), dtype=ehat.dtype, device=ehat.device)
+    check(lib().frhip_head_bwd_dt(dt_of(ehat), _p(ehat), _p(what), _p(labels_i32), n, classes, d, s, m, _p(rmax),
+                                  _p(rsum), gscale, _p(dt), ldt, _s()), "frhip_head_bwd_dt")
+    return dt

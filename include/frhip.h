@@ -1,0 +1,142 @@
+/* frhip.h -- C ABI of libfrhip.so: the MI355X (gfx950) kernels behind the face-embedding training path.
+ *
+ * The reference (aanna0701/face-recognition-pytorch) is pure Python over torch; it has no FFI of its own
+ * (SURVEY.md section 8b).  Each entry point below replaces the device work that one reference call site hands to
+ * cuDNN / cuBLAS / ATen, cited as /root/reference file:line.  INTEGRATION.md shows the ctypes stub a reference
+ * maintainer would add at that call site.
+ *
+ * Conventions
+ *   - plain pointers to DEVICE memory owned by the caller (PyTorch caching allocator), sizes as int / size_t;
+ *     no torch types; the library allocates nothing.
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*); no hidden synchronisation.
+ *   - returns 0 on success, a negative FRHIP_E* code otherwise; frhip_last_error() gives the message
+ *     (thread-local).  Nothing throws across the boundary.
+ *   - dtype: 0 = bf16 storage + bf16 MFMA (fp32 accumulate), 1 = fp32 storage + exact-fp32 MFMA (validation mode).
+ *   - activations are NHWC ("channels last"); conv weights are [K][R][S][C] which is the physical layout of a
+ *     torch channels_last [K,C,R,S] tensor.
+ */
+#ifndef FRHIP_H
+#define FRHIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#ifndef FRHIP_STREAM_T
+#define FRHIP_STREAM_T
+#ifdef __HIP_PLATFORM_AMD__
+#include <hip/hip_runtime_api.h>
+typedef hipStream_t frhip_stream_t;
+#else
+typedef void* frhip_stream_t;
+#endif
+#endif
+
+#define FRHIP_OK 0
+#define FRHIP_EINVAL (-1)
+#define FRHIP_ELAUNCH (-2)
+#define FRHIP_DT_BF16 0
+#define FRHIP_DT_F32 1
+
+const char* frhip_last_error(void);
+int frhip_abi_version(void);
+
+/* ---- convolution = MFMA implicit GEMM.  nn.Conv2d(bias=False): nets/resnet.py:23-46, used at :89-103, :232 ---- */
+/* y[n,ho,wo,k] = conv(x[n,h,w,c], w[k,r,s,c]); stats_partial (may be NULL) receives per-row-tile
+ * {sum, sum of squares} per output channel: [ceil(n*ho*wo / frhip_nt_block_m(k))][2][k] -- the BN batch statistics
+ * (nets/resnet.py:90-91) come out of the conv epilogue instead of a second pass. */
+int frhip_nt_block_m(int k);
+int frhip_conv_fwd(int dtype, const void* x, const void* w, void* y, float* stats_partial,
+                   int n, int h, int wd, int c, int k, int r, int s, int stride, int pad, frhip_stream_t stream);
+/* dx[n,h,w,c] = conv_transpose(dy[n,ho,wo,k], w) (+ residual[n,h,w,c] if not NULL); wt = frhip_pack_wt(w) = [c][r][s][k].
+ * autograd of nn.Conv2d w.r.t. input; the residual add is the gradient fan-in of `out += residual` (nets/resnet.py:101). */
+int frhip_conv_dgrad(int dtype, const void* dy, const void* wt, void* dx, const void* residual,
+                     int n, int h, int wd, int c, int k, int r, int s, int stride, int pad, frhip_stream_t stream);
+/* dw[k,r,s,c] (fp32, caller-zeroed) += sum over output pixels dy * x.  autograd of nn.Conv2d w.r.t. weight.
+ * splits <= 0: library picks the split-K factor. */
+int frhip_conv_wgrad(int dtype, const void* dy, const void* x, float* dw, int n, int h, int w, int c,
+                     int k, int r, int s, int stride, int pad, int splits, frhip_stream_t stream);
+/* out[m][n] = sum_k a[m][k]*b[n][k].  atomic_f32 = 0: out has `dtype`, overwritten (splits ignored);
+ * atomic_f32 = 1: out is fp32, caller-zeroed, K is split `splits` ways and added atomically.  nn.Linear: nets/resnet.py:244 */
+int frhip_gemm_nt(int dtype, const void* a, const void* b, void* out, int m, int n, int k, int splits,
+                  int atomic_f32, frhip_stream_t stream);
+/* out[kc][c] (fp32, caller-zeroed) += sum_m p[m][0..kc) * q[m][0..c);  p has row pitch ldp elements. */
+int frhip_gemm_tn(int dtype, const void* p, const void* q, float* out, int m, int kc, int ldp, int c,
+                  int splits, frhip_stream_t stream);
+
+/* ---- BatchNorm + element-wise glue.  nn.BatchNorm2d/1d: nets/resnet.py:81-86, :187, :196-199 ---- */
+int frhip_colreduce_blocks(int rows, int c, int dtype);   /* number of partial rows frhip_colstats / _bn_bwd_reduce write */
+int frhip_colstats(int dtype, const void* x, int rows, int c, float* partial, frhip_stream_t stream);
+/* partial[nparts][2][c] -> batch mean / invstd, affine scale/shift, running-stat update (running_* may be NULL).
+ * scratch: 64*2*c floats. */
+int frhip_bn_finalize(const float* partial, int nparts, float* scratch, int c, float count,
+                      const float* gamma, const float* beta, float* running_mean, float* running_var,
+                      float momentum, float eps, float* mean, float* invstd, float* scale, float* shift,
+                      frhip_stream_t stream);
+int frhip_bn_eval_affine(int c, const float* gamma, const float* beta, const float* running_mean,
+                         const float* running_var, float eps, float* scale, float* shift, frhip_stream_t stream);
+/* out = act(y*scale+shift [+ res | + res*res_scale+res_shift]);  BasicBlock tail: nets/resnet.py:92, :96-101 */
+int frhip_bn_apply(int dtype, const void* y, const float* scale, const float* shift, const void* res,
+                   const float* res_scale, const float* res_shift, int relu, void* out, int rows, int c,
+                   frhip_stream_t stream);
+/* backward of BN (optionally preceded by the ReLU mask recomputed from y*mask_scale+mask_shift > 0) */
+int frhip_bn_bwd_reduce(int dtype, const void* dout, const void* y, const float* mean, const float* invstd,
+                        const float* mask_scale, const float* mask_shift, int rows, int c, float* partial,
+                        frhip_stream_t stream);
+int frhip_bn_bwd_finalize(const float* partial, int nparts, float* scratch, int c, float count,
+                          const float* gamma, const float* mean, const float* invstd, float* dgamma,
+                          float* dbeta, float* ca, float* cb, float* cc, frhip_stream_t stream);
+int frhip_bn_bwd_apply(int dtype, const void* dout, const void* y, const float* ca, const float* cb,
+                       const float* cc, const float* mask_scale, const float* mask_shift, void* dy,
+                       int rows, int c, frhip_stream_t stream);
+int frhip_add_bias(float* x, const float* bias, int rows, int c, frhip_stream_t stream);
+int frhip_cast_from_f32(int dtype, const float* src, void* dst, size_t n, frhip_stream_t stream);
+int frhip_cast_to_f32(int dtype, const void* src, float* dst, size_t n, frhip_stream_t stream);
+
+/* ---- stem.  conv1 + bn1 + relu + maxpool: nets/resnet.py:186-189, :232-235 ---- */
+/* x NCHW fp32 [b,3,h,w] -> col [b*h*w][64 (bf16) | 32 (f32)], k = (r*3+s)*3+ci, zero beyond 27 */
+int frhip_stem_im2col(int dtype, const float* x, void* col, int b, int h, int w, frhip_stream_t stream);
+int frhip_bn_relu_maxpool_fwd(int dtype, const void* y, const float* scale, const float* shift, void* out,
+                              uint8_t* argmax, int b, int h, int w, int c, frhip_stream_t stream);
+int frhip_maxpool_bwd(int dtype, const void* dpool, const uint8_t* argmax, void* da, int b, int h, int w,
+                      int c, frhip_stream_t stream);
+
+/* ---- operand packs ---- */
+int frhip_pack_wt(int dtype, const float* w, void* wt, int k, int rs, int c, frhip_stream_t stream);
+int frhip_transpose2d(int dtype_in, int dtype_out, const void* in, void* out, int rows, int cols, frhip_stream_t stream);
+int frhip_pack_stem(int dtype, const float* w, void* wp, int k, int kin, int kp, frhip_stream_t stream);
+int frhip_unpack_stem_grad(const float* dwp, float* dw, int k, int kin, int kp, frhip_stream_t stream);
+/* fc weight columns: reference flattens NCHW (x.view(B,-1), nets/resnet.py:243); this backbone is NHWC */
+int frhip_fc_permute(int dtype, const float* w, void* wp, int nout, int c, int hw, frhip_stream_t stream);
+int frhip_fc_unpermute_grad(const float* dwp, float* dw, int nout, int c, int hw, frhip_stream_t stream);
+/* PartialFC sampled rows: weight[index] gather (nets/PartialFC.py:120-121) / write-back (:142-143) */
+int frhip_gather_rows(const float* src, const int64_t* index, float* dst, int n, int d, frhip_stream_t stream);
+int frhip_scatter_rows(const float* src, const int64_t* index, float* dst, int n, int d, frhip_stream_t stream);
+
+/* ---- margin-softmax head.  nets/PartialFC.py:198-207, nets/ArcFace.py:76-91, nets/PartialFC.py:441-484 ---- */
+/* F.normalize rows (also model/FR_PartialFC.py:171) */
+int frhip_l2norm_rows(int dtype, const float* x, void* xhat, float* norms, int rows, int d, float eps,
+                      frhip_stream_t stream);
+int frhip_l2norm_bwd(int dtype, const float* dxhat, const void* xhat, const float* norms, float* dx,
+                     int rows, int d, float out_scale, frhip_stream_t stream);
+int frhip_head_groups(int num_classes);     /* rows of part_max / part_sum */
+/* fused normalised-GEMM -> clamp -> ArcFace margin -> x s -> per-row max & sum-exp (this shard);
+ * labels: int32 shard-relative, -1 = another shard owns the class. */
+int frhip_head_fwd(int dtype, const void* ehat, const void* what, const int* labels, int n, int classes,
+                   int d, float s, float m, float* part_max, float* part_sum, float* ztarget,
+                   float* rowmax, float* rowsum, frhip_stream_t stream);
+int frhip_head_rescale(float* rowsum, const float* local_max, const float* global_max, int n, frhip_stream_t stream);
+int frhip_head_target_prob(const float* ztarget, const int* labels, const float* rowmax, const float* rowsum,
+                           float* q, int n, frhip_stream_t stream);
+int frhip_head_loss(const float* q, int n, float* loss, frhip_stream_t stream);
+/* dT[n][ldt] = d loss / d cos (after clamp/margin/scale chain rule), gscale = upstream / N_global */
+int frhip_head_bwd_dt(int dtype, const void* ehat, const void* what, const int* labels, int n, int classes,
+                      int d, float s, float m, const float* rowmax, const float* rowsum, float gscale,
+                      void* dt, int ldt, frhip_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,82 @@
+"""GPU parity of the fused margin-softmax head kernels against the oracle (oracle/head_ref.py)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import head_ref
+
+pytestmark = pytest.mark.gpu
+
+
+def _run_head(ops, dtype, emb, w_act, ll, s, m, upstream=1.0):
+    """ws = 1 composition of the head kernels; returns loss, d_emb, d_w_act (all fp32 CPU)."""
+    n = emb.shape[0]
+    eh, en = ops.l2norm_rows(emb.cuda(), dtype)
+    wh, wn = ops.l2norm_rows(w_act.cuda(), dtype)
+    lab = ll.to(torch.int32).cuda()
+    zt, rmax, rsum = ops.head_fwd(eh, wh, lab, s, m)
+    qv = ops.head_target_prob(zt, lab, rmax, rsum)
+    loss = ops.head_loss(qv)
+    dt = ops.head_bwd_dt(eh, wh, lab, s, m, rmax, rsum, upstream / n)
+    classes = w_act.shape[0]
+    d_wh = torch.zeros((classes, emb.shape[1]), dtype=torch.float32, device="cuda")
+    ops.gemm_tn(dt, eh, d_wh, kc=classes)
+    dtt = ops.transpose2d(dt)                       # [ldt][n]
+    d_eh = torch.zeros((n, emb.shape[1]), dtype=torch.float32, device="cuda")
+    ops.gemm_tn(dtt[:classes].contiguous(), wh, d_eh, kc=n)
+    d_e = ops.l2norm_bwd(d_eh, eh, en)
+    d_w = ops.l2norm_bwd(d_wh, wh, wn)
+    return loss.cpu().item(), d_e.cpu(), d_w.cpu()
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(24, 1003, 128), (130, 200, 512), (8, 16, 64)])
+def test_head_matches_oracle(dtype, shape):
+    from frhip import ops
+    n, classes, d = shape
+    g = torch.Generator().manual_seed(n + classes)
+    emb = torch.randn((n, d), generator=g)
+    w = torch.randn((classes, d), generator=g) * 0.05
+    lab = torch.randint(0, classes, (n,), generator=g)
+    lab[1] = lab[0]
+    ll = lab.clone()
+    ll[2] = -1                                        # a row whose class lives on another shard
+    # make one target cosine large (exercise the easy-margin branch both ways)
+    w[lab[3]] = emb[3] * 0.9 + 0.1 * torch.randn(d, generator=g)
+    w[lab[4]] = -emb[4]
+    s, m = 30.0, 0.35
+    # oracle (one shard; rows with -1 simply have no target here)
+    eh, en = head_ref.l2_normalize(emb)
+    wh, wn = head_ref.l2_normalize(w)
+    raw = eh @ wh.t()
+    z, slope = head_ref.arcface_logits(raw.clamp(-1, 1), ll, s, m)
+    loss_ref, grads = head_ref.dist_cross_entropy([z], [ll])
+    dcos = grads[0] * s * slope * ((raw >= -1) & (raw <= 1))
+    d_e_ref = head_ref.l2_normalize_bwd(dcos @ wh, eh, en)
+    d_w_ref = head_ref.l2_normalize_bwd(dcos.t() @ eh, wh, wn)
+    loss, d_e, d_w = _run_head(ops, dtype, emb, w, ll, s, m)
+    if dtype == torch.float32:
+        np.testing.assert_allclose(loss, loss_ref.item(), rtol=1e-3)      # north_star: 1e-3 relative
+        np.testing.assert_allclose(d_e.numpy(), d_e_ref.numpy(), rtol=1e-3, atol=1e-6 * d_e_ref.abs().max().item() * 1e3)
+        np.testing.assert_allclose(d_w.numpy(), d_w_ref.numpy(), rtol=1e-3, atol=1e-6 * d_w_ref.abs().max().item() * 1e3)
+    else:
+        np.testing.assert_allclose(loss, loss_ref.item(), rtol=3e-2)
+        np.testing.assert_allclose(d_e.numpy(), d_e_ref.numpy(), rtol=0.1, atol=0.05 * d_e_ref.abs().max().item())
+        np.testing.assert_allclose(d_w.numpy(), d_w_ref.numpy(), rtol=0.1, atol=0.05 * d_w_ref.abs().max().item())
+
+
+def test_head_matches_reference_fixture_ws1(golden):
+    """Same inputs as the reference-generated fixture head_ws1_rate10 (fp32 mode)."""
+    from frhip import ops
+    from oracle import recipe
+    g = golden("head_ws1_rate10")
+    C, B, D = int(g["C"]), int(g["B"]), int(g["D"])
+    emb = recipe.normal(100, (B, D))
+    lab = recipe.labels(200, B, C)
+    lab[0] = 3
+    lab[1] = 3
+    w = recipe.normal(500, (C, D), 0.05)
+    loss, d_e, d_w = _run_head(ops, torch.float32, emb, w, lab, float(g["s"]), float(g["m"]))
+    np.testing.assert_allclose(loss, g["r0_loss"], rtol=1e-4)
+    np.testing.assert_allclose(d_e.numpy(), g["r0_d_emb"], rtol=1e-3, atol=1e-6)
+    np.testing.assert_allclose(d_w.numpy(), g["r0_d_w_act"], rtol=1e-3, atol=1e-6)

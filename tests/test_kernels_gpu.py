@@ -1,0 +1,221 @@
+"""GPU parity of each HIP kernel (called through the C ABI) against a plain PyTorch fp32 CPU reference of the
+same op.  fp32 mode: exact-fp32 MFMA, tight tolerances.  bf16 mode: inputs are rounded to bf16 first and the
+reference is computed in fp32 from the rounded inputs, so the tolerance only covers bf16 output rounding
+(2^-8 relative) and accumulation order."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DTYPES = [torch.float32, torch.bfloat16]
+
+
+def _ops():
+    from frhip import ops
+    return ops
+
+
+def tol(dtype, scale=1.0):
+    return (dict(rtol=2e-4, atol=2e-5 * scale) if dtype == torch.float32 else dict(rtol=2e-2, atol=2e-2 * scale))
+
+
+def rnd(seed, shape, std=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(shape, generator=g) * std
+
+
+def q(t, dtype):
+    """round to the compute dtype and come back to fp32 (CPU)"""
+    return t.to(dtype).float()
+
+
+def nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+def nchw(t):
+    return t.permute(0, 3, 1, 2).contiguous()
+
+
+CONV_CASES = [
+    # n, h, w, c, k, r, stride, pad
+    (2, 8, 8, 64, 64, 3, 1, 1),
+    (3, 7, 7, 64, 128, 3, 1, 1),       # M = 147: ragged last row tile
+    (2, 10, 6, 128, 128, 3, 2, 1),     # strided, non-square
+    (2, 8, 8, 64, 128, 1, 2, 0),       # downsample 1x1 s2
+    (1, 5, 5, 256, 512, 3, 1, 1),
+    (5, 9, 9, 64, 64, 3, 2, 1),        # odd size with stride 2
+]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_fwd_and_stats(dtype, case):
+    ops = _ops()
+    n, h, w, c, k, r, stride, pad = case
+    x = q(rnd(1, (n, c, h, w)), dtype)
+    wt = q(rnd(2, (k, c, r, r), 0.05), dtype)
+    ref = F.conv2d(x, wt, None, stride, pad)
+    y, part = ops.conv_fwd(nhwc(x).to(dtype).cuda(), nhwc(wt).to(dtype).cuda(), stride, pad)
+    got = nchw(y.float().cpu())
+    np.testing.assert_allclose(got.numpy(), ref.numpy(), **tol(dtype, ref.abs().max().item()))
+    # epilogue statistics are those of the STORED tensor
+    s = part.sum(dim=0).cpu()
+    yy = y.float().cpu().reshape(-1, k)
+    np.testing.assert_allclose(s[0].numpy(), yy.sum(0).numpy(), rtol=1e-3, atol=1e-2)
+    np.testing.assert_allclose(s[1].numpy(), (yy * yy).sum(0).numpy(), rtol=1e-3, atol=1e-2)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_dgrad(dtype, case):
+    ops = _ops()
+    n, h, w, c, k, r, stride, pad = case
+    ho, wo = ops.conv_out_hw(h, w, r, r, stride, pad)
+    wt = q(rnd(2, (k, c, r, r), 0.05), dtype)
+    dy = q(rnd(3, (n, k, ho, wo)), dtype)
+    res = q(rnd(4, (n, c, h, w)), dtype)
+    ref = torch.nn.grad.conv2d_input((n, c, h, w), wt, dy, stride, pad) + res
+    wpack = ops.pack_wt(nhwc(wt).cuda(), dtype)
+    dx = ops.conv_dgrad(nhwc(dy).to(dtype).cuda(), wpack, (n, h, w, c), r, r, stride, pad,
+                        residual=nhwc(res).to(dtype).cuda())
+    np.testing.assert_allclose(nchw(dx.float().cpu()).numpy(), ref.numpy(), **tol(dtype, ref.abs().max().item()))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", CONV_CASES)
+@pytest.mark.parametrize("splits", [0, 1, 3])
+def test_conv_wgrad(dtype, case, splits):
+    ops = _ops()
+    n, h, w, c, k, r, stride, pad = case
+    ho, wo = ops.conv_out_hw(h, w, r, r, stride, pad)
+    x = q(rnd(1, (n, c, h, w)), dtype)
+    dy = q(rnd(3, (n, k, ho, wo)), dtype)
+    ref = torch.nn.grad.conv2d_weight(x, (k, c, r, r), dy, stride, pad)
+    dw = torch.zeros((k, r, r, c), dtype=torch.float32, device="cuda")
+    ops.conv_wgrad(nhwc(dy).to(dtype).cuda(), nhwc(x).to(dtype).cuda(), dw, r, r, stride, pad, splits)
+    got = dw.cpu().permute(0, 3, 1, 2)
+    np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=2e-3 if dtype == torch.bfloat16 else 2e-4,
+                               atol=1e-3 * ref.abs().max().item())
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("mnk", [(16, 512, 1024), (200, 64, 128), (512, 1003 // 8 * 8, 512)])
+def test_gemm_nt_store_and_splitk(dtype, mnk):
+    ops = _ops()
+    m, n, k = mnk
+    a, b = q(rnd(5, (m, k)), dtype), q(rnd(6, (n, k), 0.1), dtype)
+    ref = a @ b.t()
+    out = ops.gemm_nt(a.to(dtype).cuda(), b.to(dtype).cuda())
+    np.testing.assert_allclose(out.float().cpu().numpy(), ref.numpy(), **tol(dtype, ref.abs().max().item()))
+    out2 = ops.gemm_nt(a.to(dtype).cuda(), b.to(dtype).cuda(), splits=4, atomic_f32=True)
+    np.testing.assert_allclose(out2.cpu().numpy(), ref.numpy(), rtol=2e-4, atol=2e-4 * ref.abs().max().item())
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("shape", [(96, 200, 208, 64), (1000, 128, 128, 512), (70, 24, 24, 32)])
+def test_gemm_tn(dtype, shape):
+    ops = _ops()
+    m, kc, ldp, c = shape
+    p, qq = q(rnd(7, (m, ldp)), dtype), q(rnd(8, (m, c)), dtype)
+    ref = p[:, :kc].t() @ qq
+    out = torch.zeros((kc, c), dtype=torch.float32, device="cuda")
+    ops.gemm_tn(p.to(dtype).cuda(), qq.to(dtype).cuda(), out, kc=kc)
+    np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), rtol=2e-4, atol=2e-4 * ref.abs().max().item())
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("rc", [(300, 64), (4 * 7 * 7, 512), (2000, 128)])
+def test_batchnorm_forward_backward(dtype, rc):
+    ops = _ops()
+    rows, c = rc
+    y = q(rnd(9, (rows, c)) * 2 + 0.5, dtype)
+    res = q(rnd(10, (rows, c)), dtype)
+    dout = q(rnd(11, (rows, c)), dtype)
+    gamma, beta = 1 + 0.1 * rnd(12, (c,)), 0.1 * rnd(13, (c,))
+    rm, rv = 0.1 * rnd(14, (c,)), 1 + 0.1 * rnd(15, (c,)).abs()
+    for relu in (False, True):
+        yr = y.clone().requires_grad_(True)
+        g_, b_ = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+        rm_ref, rv_ref = rm.clone(), rv.clone()
+        o = F.batch_norm(yr, rm_ref, rv_ref, g_, b_, True, 0.1, 1e-5)
+        o = F.relu(o) if relu else o + res
+        o.backward(dout)
+        yd = y.to(dtype).cuda()
+        rm_d, rv_d = rm.clone().cuda(), rv.clone().cuda()
+        st = ops.bn_finalize(ops.colstats(yd), rows, gamma.cuda(), beta.cuda(), rm_d, rv_d)
+        out = ops.bn_apply(yd, st, relu=relu, res=None if relu else res.to(dtype).cuda())
+        np.testing.assert_allclose(out.float().cpu().numpy(), o.detach().numpy(), **tol(dtype, 4.0))
+        np.testing.assert_allclose(rm_d.cpu().numpy(), rm_ref.numpy(), rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(rv_d.cpu().numpy(), rv_ref.numpy(), rtol=1e-4, atol=1e-5)
+        dg, db = torch.zeros(c, device="cuda"), torch.zeros(c, device="cuda")
+        dy = ops.bn_backward(dout.to(dtype).cuda(), yd, st, gamma.cuda(), dg, db, relu_mask=relu)
+        np.testing.assert_allclose(dy.float().cpu().numpy(), yr.grad.numpy(), **tol(dtype, 1.0))
+        np.testing.assert_allclose(dg.cpu().numpy(), g_.grad.numpy(), rtol=2e-3, atol=2e-2 if dtype == torch.bfloat16 else 2e-3)
+        np.testing.assert_allclose(db.cpu().numpy(), b_.grad.numpy(), rtol=2e-3, atol=2e-2 if dtype == torch.bfloat16 else 2e-3)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_stem_im2col_conv_pool(dtype):
+    """conv1 -> bn1 -> relu -> maxpool of the reference stem (nets/resnet.py:232-235), fwd + bwd."""
+    ops = _ops()
+    b, h, w = 2, 12, 10
+    x = rnd(20, (b, 3, h, w)).clamp(-1, 1)
+    wt = rnd(21, (64, 3, 3, 3), 0.2)
+    gamma, beta = 1 + 0.1 * rnd(22, (64,)), 0.1 * rnd(23, (64,))
+    xq = q(x, dtype)
+    wq = q(wt, dtype)
+    # reference
+    w_ref = wq.clone().requires_grad_(True)
+    g_, b_ = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    y0 = F.conv2d(xq, w_ref, None, 1, 1)
+    y0.retain_grad()
+    a0 = F.relu(F.batch_norm(y0, None, None, g_, b_, True, 0.1, 1e-5))
+    p0 = F.max_pool2d(a0, 3, 2, 1)
+    dp = rnd(24, p0.shape)
+    p0.backward(q(dp, dtype))
+    # device
+    col = ops.stem_im2col(x.cuda(), dtype)
+    wp = ops.pack_stem(nhwc(wt).reshape(64, 27).contiguous().cuda(), dtype)
+    y, part = ops.conv_fwd(col.view(b * h * w, 1, 1, -1), wp, 1, 0)
+    y = y.view(b, h, w, 64)
+    np.testing.assert_allclose(nchw(y.float().cpu()).numpy(), y0.detach().numpy(), **tol(dtype, 2.0))
+    st = ops.bn_finalize(part, b * h * w, gamma.cuda(), beta.cuda(), None, None)
+    pooled, arg = ops.bn_relu_maxpool_fwd(y, st)
+    np.testing.assert_allclose(nchw(pooled.float().cpu()).numpy(), p0.detach().numpy(), **tol(dtype, 3.0))
+    if dtype == torch.float32:      # argmax ties make the bf16 scatter differ legitimately
+        da = ops.maxpool_bwd(nhwc(dp).cuda(), arg, (b, h, w, 64))
+        dg, db = torch.zeros(64, device="cuda"), torch.zeros(64, device="cuda")
+        dy0 = ops.bn_backward(da, y, st, gamma.cuda(), dg, db, relu_mask=True)
+        np.testing.assert_allclose(nchw(dy0.cpu()).numpy(), y0.grad.numpy(), rtol=2e-3, atol=2e-5)
+        dwp = torch.zeros((64, 1, 1, 32), dtype=torch.float32, device="cuda")
+        ops.conv_wgrad(dy0.view(b * h * w, 1, 1, 64), col.view(b * h * w, 1, 1, 32), dwp, 1, 1, 1, 0)
+        dw = torch.zeros((64, 27), device="cuda")
+        ops.unpack_stem_grad(dwp, dw)
+        ref_dw = nhwc(w_ref.grad).reshape(64, 27)
+        np.testing.assert_allclose(dw.cpu().numpy(), ref_dw.numpy(), rtol=2e-3, atol=2e-4)
+        np.testing.assert_allclose(dg.cpu().numpy(), g_.grad.numpy(), rtol=2e-3, atol=2e-4)
+
+
+def test_packs_roundtrip():
+    ops = _ops()
+    w = rnd(30, (48, 3, 3, 40))
+    wt = ops.pack_wt(w.cuda(), torch.float32).cpu()
+    assert torch.equal(wt, w.permute(3, 1, 2, 0).contiguous())
+    fc = rnd(31, (16, 128 * 9))
+    wp = ops.fc_permute(fc.cuda(), 128, 9, torch.float32).cpu()
+    assert torch.equal(wp, fc.view(16, 128, 9).permute(0, 2, 1).reshape(16, -1))
+    back = torch.zeros_like(fc).cuda()
+    ops.fc_unpermute_grad(wp.cuda(), back, 128, 9)
+    assert torch.equal(back.cpu(), fc)
+    t = ops.transpose2d(fc.cuda()).cpu()
+    assert torch.equal(t, fc.t().contiguous())
+    idx = torch.tensor([5, 0, 9, 3], dtype=torch.int64)
+    src = rnd(32, (12, 64))
+    got = ops.gather_rows(src.cuda(), idx.cuda()).cpu()
+    assert torch.equal(got, src[idx])
+    dst = torch.zeros((12, 64)).cuda()
+    ops.scatter_rows(got.cuda(), idx.cuda(), dst)
+    assert torch.equal(dst.cpu()[idx], src[idx])
