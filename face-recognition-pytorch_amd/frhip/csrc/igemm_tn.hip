@@ -120,7 +120,7 @@ __global__ __launch_bounds__(TN_THREADS, 2) void tn_kernel(TnGeom g, const void*
             // P row: dy[m][co0 + ce ...]
             uint32_t offp = OOB_OFFSET, offq = OOB_OFFSET;
             if (m < g.M) {
-                if (co0 + ce < g.Kc) offp = ((uint32_t)m * (uint32_t)g.ldp + (uint32_t)(co0 + ce)) * (uint32_t)sizeof(T);
+                if (co0 + ce < g.ldp) offp = ((uint32_t)m * (uint32_t)g.ldp + (uint32_t)(co0 + ce)) * (uint32_t)sizeof(T);
                 const uint32_t n = fdiv((uint32_t)m, g.d_howo);
                 const uint32_t rem = (uint32_t)m - n * (uint32_t)(g.Ho * g.Wo);
                 const uint32_t ho = fdiv(rem, g.d_wo), wo = rem - ho * (uint32_t)g.Wo;
@@ -215,8 +215,8 @@ static int tn_run(int dtype, const void* p, const void* q, float* out, int n, in
     const int es = dtype == FRHIP_DT_BF16 ? 2 : 4;
     if (dtype != FRHIP_DT_BF16 && dtype != FRHIP_DT_F32) { set_error("%s: bad dtype %d", who, dtype); return FRHIP_EINVAL; }
     const int epv = 16 / es;
-    if (n <= 0 || c <= 0 || kc <= 0 || (c % epv) || (ldp % epv) || (kc % epv) || ldp < kc) {
-        set_error("%s: unsupported shape c=%d kc=%d ldp=%d (must be multiples of %d)", who, c, kc, ldp, epv);
+    if (n <= 0 || c <= 0 || kc <= 0 || (c % epv) || (ldp % epv) || ldp < kc) {
+        set_error("%s: unsupported shape c=%d kc=%d ldp=%d (c and ldp must be multiples of %d, ldp >= kc)", who, c, kc, ldp, epv);
         return FRHIP_EINVAL;
     }
     TnGeom g;

@@ -43,7 +43,7 @@ __global__ void pack_wt_kernel(const float* __restrict__ w, T* __restrict__ wt, 
 
 // generic 2-D transpose in[rows][cols] -> out[cols][rows]
 template <typename TI, typename TO>
-__global__ void transpose2d_kernel(const TI* __restrict__ in, TO* __restrict__ out, int rows, int cols) {
+__global__ void transpose2d_kernel(const TI* __restrict__ in, TO* __restrict__ out, int rows, int cols, int ld_out) {
     __shared__ float tile[32][33];
     const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
     for (int j = threadIdx.y; j < 32; j += blockDim.y) {
@@ -53,7 +53,7 @@ __global__ void transpose2d_kernel(const TI* __restrict__ in, TO* __restrict__ o
     __syncthreads();
     for (int j = threadIdx.y; j < 32; j += blockDim.y) {
         const int c = c0 + j, r = r0 + threadIdx.x;
-        if (c < cols && r < rows) out[(size_t)c * rows + r] = from_f32<TO>(tile[threadIdx.x][j]);
+        if (c < cols && r < ld_out) out[(size_t)c * ld_out + r] = from_f32<TO>(tile[threadIdx.x][j]);   // r >= rows: zero pad
     }
 }
 
@@ -135,14 +135,16 @@ extern "C" int frhip_pack_wt(int dtype, const float* w, void* wt, int k, int rs,
     return check_launch("frhip_pack_wt");
 }
 
-extern "C" int frhip_transpose2d(int dtype_in, int dtype_out, const void* in, void* out, int rows, int cols, hipStream_t stream) {
-    dim3 grid((cols + 31) / 32, (rows + 31) / 32), block(32, 8);
+extern "C" int frhip_transpose2d(int dtype_in, int dtype_out, const void* in, void* out, int rows, int cols, int ld_out, hipStream_t stream) {
+    // out[cols][ld_out], ld_out >= rows; columns [rows, ld_out) are zero-filled
+    if (ld_out < rows) { set_error("frhip_transpose2d: ld_out %d < rows %d", ld_out, rows); return FRHIP_EINVAL; }
+    dim3 grid((cols + 31) / 32, (ld_out + 31) / 32), block(32, 8);
     const int key = dtype_in * 2 + dtype_out;
     switch (key) {
-        case 0: hipLaunchKernelGGL((transpose2d_kernel<bf16_t, bf16_t>), grid, block, 0, stream, (const bf16_t*)in, (bf16_t*)out, rows, cols); break;
-        case 1: hipLaunchKernelGGL((transpose2d_kernel<bf16_t, float>), grid, block, 0, stream, (const bf16_t*)in, (float*)out, rows, cols); break;
-        case 2: hipLaunchKernelGGL((transpose2d_kernel<float, bf16_t>), grid, block, 0, stream, (const float*)in, (bf16_t*)out, rows, cols); break;
-        case 3: hipLaunchKernelGGL((transpose2d_kernel<float, float>), grid, block, 0, stream, (const float*)in, (float*)out, rows, cols); break;
+        case 0: hipLaunchKernelGGL((transpose2d_kernel<bf16_t, bf16_t>), grid, block, 0, stream, (const bf16_t*)in, (bf16_t*)out, rows, cols, ld_out); break;
+        case 1: hipLaunchKernelGGL((transpose2d_kernel<bf16_t, float>), grid, block, 0, stream, (const bf16_t*)in, (float*)out, rows, cols, ld_out); break;
+        case 2: hipLaunchKernelGGL((transpose2d_kernel<float, bf16_t>), grid, block, 0, stream, (const float*)in, (bf16_t*)out, rows, cols, ld_out); break;
+        case 3: hipLaunchKernelGGL((transpose2d_kernel<float, float>), grid, block, 0, stream, (const float*)in, (float*)out, rows, cols, ld_out); break;
         default: set_error("frhip_transpose2d: bad dtypes"); return FRHIP_EINVAL;
     }
     return check_launch("frhip_transpose2d");

@@ -217,11 +217,14 @@ def pack_wt(w_f32, dtype, out=None):
     return out
 
 
-def transpose2d(x, out_dtype=None, out=None):
+def transpose2d(x, out_dtype=None, out=None, pad_to=1):
+    """x [rows][cols] -> [cols][ld] with ld = rows rounded up to pad_to (pad columns are zero)"""
     rows, cols = x.shape
     out_dtype = x.dtype if out_dtype is None else out_dtype
-    out = torch.empty((cols, rows), dtype=out_dtype, device=x.device) if out is None else out
-    check(lib().frhip_transpose2d(dt_of(x), _DT[out_dtype], _p(x), _p(out), rows, cols, _s()), "frhip_transpose2d")
+    ld = (rows + pad_to - 1) // pad_to * pad_to
+    out = torch.empty((cols, ld), dtype=out_dtype, device=x.device) if out is None else out
+    check(lib().frhip_transpose2d(dt_of(x), _DT[out_dtype], _p(x), _p(out), rows, cols, out.shape[1], _s()),
+          "frhip_transpose2d")
     return out
 
 

@@ -105,7 +105,9 @@ int frhip_maxpool_bwd(int dtype, const void* dpool, const uint8_t* argmax, void*
 
 /* ---- operand packs ---- */
 int frhip_pack_wt(int dtype, const float* w, void* wt, int k, int rs, int c, frhip_stream_t stream);
-int frhip_transpose2d(int dtype_in, int dtype_out, const void* in, void* out, int rows, int cols, frhip_stream_t stream);
+/* out[cols][ld_out] = in[rows][cols]^T, ld_out >= rows, pad columns zero-filled */
+int frhip_transpose2d(int dtype_in, int dtype_out, const void* in, void* out, int rows, int cols, int ld_out,
+                      frhip_stream_t stream);
 int frhip_pack_stem(int dtype, const float* w, void* wp, int k, int kin, int kp, frhip_stream_t stream);
 int frhip_unpack_stem_grad(const float* dwp, float* dw, int k, int kin, int kp, frhip_stream_t stream);
 /* fc weight columns: reference flattens NCHW (x.view(B,-1), nets/resnet.py:243); this backbone is NHWC */

@@ -21,9 +21,9 @@ def _run_head(ops, dtype, emb, w_act, ll, s, m, upstream=1.0):
     classes = w_act.shape[0]
     d_wh = torch.zeros((classes, emb.shape[1]), dtype=torch.float32, device="cuda")
     ops.gemm_tn(dt, eh, d_wh, kc=classes)
-    dtt = ops.transpose2d(dt)                       # [ldt][n]
+    dtt = ops.transpose2d(dt, pad_to=8)             # [ldt][n rounded up to 8]
     d_eh = torch.zeros((n, emb.shape[1]), dtype=torch.float32, device="cuda")
-    ops.gemm_tn(dtt[:classes].contiguous(), wh, d_eh, kc=n)
+    ops.gemm_tn(dtt[:classes], wh, d_eh, kc=n)
     d_e = ops.l2norm_bwd(d_eh, eh, en)
     d_w = ops.l2norm_bwd(d_wh, wh, wn)
     return loss.cpu().item(), d_e.cpu(), d_w.cpu()
