@@ -170,6 +170,15 @@ __global__ __launch_bounds__(EW_THREADS) void bn_bwd_apply_kernel(const T* __res
     }
 }
 
+// out[c] += sum_p partial[p][which][c]
+__global__ void sum_partials_kernel(const float* __restrict__ partial, int nparts, int C, int which, float* __restrict__ out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float acc = 0.f;
+    for (int p = 0; p < nparts; ++p) acc += partial[((size_t)p * 2 + which) * C + c];
+    out[c] += acc;
+}
+
 // x[rows][C] += bias[C]  (fp32 tail of the backbone: fc bias)
 __global__ void add_bias_kernel(float* __restrict__ x, const float* __restrict__ bias, size_t n, int C) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
@@ -308,6 +317,11 @@ extern "C" int frhip_bn_bwd_apply(int dtype, const void* dout, const void* y, co
         hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(blocks), dim3(EW_THREADS), 0, stream, (const float*)dout,
                            (const float*)y, ca, cb, cc, mask_scale, mask_shift, (float*)dy, nvec, c);
     return check_launch("frhip_bn_bwd_apply");
+}
+
+extern "C" int frhip_sum_partials(const float* partial, int nparts, int c, int which, float* out_accum, hipStream_t stream) {
+    hipLaunchKernelGGL(sum_partials_kernel, dim3((c + 63) / 64), dim3(64), 0, stream, partial, nparts, c, which, out_accum);
+    return check_launch("frhip_sum_partials");
 }
 
 extern "C" int frhip_add_bias(float* x, const float* bias, int rows, int c, hipStream_t stream) {

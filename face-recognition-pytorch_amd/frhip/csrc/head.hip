@@ -64,8 +64,8 @@ __global__ __launch_bounds__(NT_THREADS, 2) void head_kernel(NtGeom g, const voi
                                                              MarginConst mc, float* __restrict__ part_max,
                                                              float* __restrict__ part_sum, float* __restrict__ ztarget,
                                                              const float* __restrict__ rowmax, const float* __restrict__ rowsum,
-                                                             float gscale, void* __restrict__ dt, int ldt,
-                                                             int mtiles, int ntiles) {
+                                                             float gscale, const float* __restrict__ upstream,
+                                                             void* __restrict__ dt, int ldt, int mtiles, int ntiles) {
     typedef NtTile<T, 2, 2> Tile;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const uint32_t lin = xcd_remap(blockIdx.x, gridDim.x);
@@ -79,6 +79,7 @@ __global__ __launch_bounds__(NT_THREADS, 2) void head_kernel(NtGeom g, const voi
     const int fi = lane & 15, fg = lane >> 4;
     const int m0 = mtile * Tile::BM + wm * 64, n0 = ntile * Tile::BN + wn * 64;
     const int group = ntile * 2 + wn;                   // 64-class column group id
+    if (!FWD && upstream) gscale *= upstream[0];        // d(loss)/d(loss) stays on the device: no host sync
 
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
@@ -190,7 +191,7 @@ __global__ void head_loss_kernel(const float* __restrict__ q, int N, float* __re
 template <typename T, bool FWD>
 static int head_launch(const NtGeom& g, const void* ehat, const void* what, const int* labels, const MarginConst& mc,
                        float* pmax, float* psum, float* zt, const float* rmax, const float* rsum, float gscale,
-                       void* dt, int ldt, hipStream_t stream) {
+                       const float* upstream, void* dt, int ldt, hipStream_t stream) {
     typedef NtTile<T, 2, 2> Tile;
     const int mtiles = (g.M + Tile::BM - 1) / Tile::BM, ntiles = (g.Nout + Tile::BN - 1) / Tile::BN;
     const int lds = Tile::template lds_bytes<T>();
@@ -204,7 +205,7 @@ static int head_launch(const NtGeom& g, const void* ehat, const void* what, cons
         attr_done = true;
     }
     hipLaunchKernelGGL(kern, dim3(mtiles * ntiles), dim3(NT_THREADS), lds, stream, g, ehat, what, labels, mc, pmax, psum,
-                       zt, rmax, rsum, gscale, dt, ldt, mtiles, ntiles);
+                       zt, rmax, rsum, gscale, upstream, dt, ldt, mtiles, ntiles);
     return check_launch("head");
 }
 
@@ -259,8 +260,8 @@ extern "C" int frhip_head_fwd(int dtype, const void* ehat, const void* what, con
     int rc = head_geom(g, dtype, n, classes, d, "frhip_head_fwd");
     if (rc) return rc;
     const MarginConst mc = margin_const(s, m);
-    if (dtype == FRHIP_DT_BF16) rc = head_launch<bf16_t, true>(g, ehat, what, labels, mc, part_max, part_sum, ztarget, nullptr, nullptr, 0.f, nullptr, 0, stream);
-    else rc = head_launch<float, true>(g, ehat, what, labels, mc, part_max, part_sum, ztarget, nullptr, nullptr, 0.f, nullptr, 0, stream);
+    if (dtype == FRHIP_DT_BF16) rc = head_launch<bf16_t, true>(g, ehat, what, labels, mc, part_max, part_sum, ztarget, nullptr, nullptr, 0.f, nullptr, nullptr, 0, stream);
+    else rc = head_launch<float, true>(g, ehat, what, labels, mc, part_max, part_sum, ztarget, nullptr, nullptr, 0.f, nullptr, nullptr, 0, stream);
     if (rc) return rc;
     hipLaunchKernelGGL(head_rowreduce_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, part_max, part_sum,
                        frhip_head_groups(classes), n, rowmax, rowsum);
@@ -285,13 +286,13 @@ extern "C" int frhip_head_loss(const float* q, int n, float* loss, hipStream_t s
 
 extern "C" int frhip_head_bwd_dt(int dtype, const void* ehat, const void* what, const int* labels, int n, int classes,
                                  int d, float s, float m, const float* rowmax, const float* rowsum, float gscale,
-                                 void* dt, int ldt, hipStream_t stream) {
+                                 const float* upstream, void* dt, int ldt, hipStream_t stream) {
     NtGeom g;
     int rc = head_geom(g, dtype, n, classes, d, "frhip_head_bwd_dt");
     if (rc) return rc;
     const int epv = dtype == FRHIP_DT_BF16 ? 8 : 4;
     if (ldt < classes || (ldt % epv)) { set_error("frhip_head_bwd_dt: bad dT pitch %d", ldt); return FRHIP_EINVAL; }
     const MarginConst mc = margin_const(s, m);
-    if (dtype == FRHIP_DT_BF16) return head_launch<bf16_t, false>(g, ehat, what, labels, mc, nullptr, nullptr, nullptr, rowmax, rowsum, gscale, dt, ldt, stream);
-    return head_launch<float, false>(g, ehat, what, labels, mc, nullptr, nullptr, nullptr, rowmax, rowsum, gscale, dt, ldt, stream);
+    if (dtype == FRHIP_DT_BF16) return head_launch<bf16_t, false>(g, ehat, what, labels, mc, nullptr, nullptr, nullptr, rowmax, rowsum, gscale, upstream, dt, ldt, stream);
+    return head_launch<float, false>(g, ehat, what, labels, mc, nullptr, nullptr, nullptr, rowmax, rowsum, gscale, upstream, dt, ldt, stream);
 }

@@ -164,6 +164,13 @@ def bn_backward(dout, y, st, gamma, dgamma, dbeta, relu_mask=False, out=None, sc
     return dy
 
 
+def colsum_accumulate(x2d, out_accum):
+    """out_accum[c] += sum_rows x2d[:, c]"""
+    part = colstats(x2d)
+    check(lib().frhip_sum_partials(_p(part), part.shape[0], x2d.shape[1], 0, _p(out_accum), _s()), "frhip_sum_partials")
+    return out_accum
+
+
 def add_bias(x, bias):
     check(lib().frhip_add_bias(_p(x), _p(bias), x.shape[0], x.shape[1], _s()), "frhip_add_bias")
     return x
@@ -313,12 +320,12 @@ def head_loss(q):
     return loss
 
 
-def head_bwd_dt(ehat, what, labels_i32, s, m, rmax, rsum, gscale):
+def head_bwd_dt(ehat, what, labels_i32, s, m, rmax, rsum, gscale, upstream=None):
     n, d = ehat.shape
     classes = what.shape[0]
     e = epv(ehat.dtype)
     ldt = (classes + e - 1) // e * e
     dt = torch.empty((n, ldt), dtype=ehat.dtype, device=ehat.device)
     check(lib().frhip_head_bwd_dt(dt_of(ehat), _p(ehat), _p(what), _p(labels_i32), n, classes, d, s, m, _p(rmax),
-                                  _p(rsum), gscale, _p(dt), ldt, _s()), "frhip_head_bwd_dt")
+                                  _p(rsum), gscale, _p(upstream), _p(dt), ldt, _s()), "frhip_head_bwd_dt")
     return dt

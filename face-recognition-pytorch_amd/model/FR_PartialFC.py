@@ -1,0 +1,115 @@
+"""MI355X-native drop-in for the reference train-step orchestrator `model/FR_PartialFC.py`.
+
+Kept from /root/reference/model/FR_PartialFC.py: `Model(conf, logger, stage)` with `.encoder`, `.loss`, `.opt`,
+`.sch`, `.forward(x)` (:154-156), `.training_step(batch) -> {'loss': np.ndarray}` (:162-193),
+`.configure_optimizers()` (:434-474, ONE optimizer over param groups [encoder, head], head group last) and
+`.training_epoch_end`.  The step composition is the reference's:
+    opt.zero_grad -> encoder.train() -> feat = normalize(encoder(img)) -> loss = head(feat, id, opt)
+    -> loss.backward() -> clip_grad_norm_(encoder, 5) -> opt.step()
+but encoder, normalize and head are the libfrhip kernels (nets.resnet / nets.PartialFC of this package).
+`conf.mixed_precision` selects bf16 MFMA compute (the reference's fp16 autocast + GradScaler has no role with
+bf16: no loss scaling is needed, so the GradScaler branch collapses into the plain one).
+"""
+import importlib
+
+import numpy as np
+import torch
+from torch import nn
+from torch.nn.parallel import DistributedDataParallel as DDP
+
+
+class _NormalizeFn(torch.autograd.Function):
+    """F.normalize(x) rows (model/FR_PartialFC.py:171) on the HIP kernels."""
+
+    @staticmethod
+    def forward(ctx, x):
+        from frhip import ops
+        xh, nrm = ops.l2norm_rows(x.contiguous().float(), torch.float32)
+        ctx.save_for_backward(xh, nrm)
+        return xh
+
+    @staticmethod
+    def backward(ctx, g):
+        from frhip import ops
+        xh, nrm = ctx.saved_tensors
+        return ops.l2norm_bwd(g.contiguous().float(), xh, nrm)
+
+
+def normalize(x):
+    return _NormalizeFn.apply(x)
+
+
+class Model(nn.Module):
+    def __init__(self, conf, logger=None, stage="train"):
+        super().__init__()
+        self.conf = conf
+        self.logger_ = logger
+        self.epoch = 0
+        self.lr = conf.lr
+        self.sync_loss = True          # False: training_step returns the device tensor (no D2H sync per step)
+        if "ResNet" in conf.network:
+            self.encoder = importlib.import_module("nets.resnet").Encoder(conf=conf)
+        else:
+            raise NotImplementedError("frhip: backbone %r is not built yet (SURVEY.md section 8f)" % conf.network)
+        if self.encoder is None:
+            raise ValueError("unknown network %r" % conf.network)
+        self.encoder = self.encoder.to(conf.local_rank)
+        ckpt = getattr(conf, "ckpt_path", None)
+        if ckpt is not None:
+            pre = torch.load(ckpt, map_location="cpu")["model_state_dict"]
+            self.encoder.load_state_dict({k[7:]: v for k, v in pre.items()}, strict=True)   # strip 'module.'
+        if stage == "train":
+            if getattr(conf, "world_size", 1) > 1:
+                self.encoder = DDP(self.encoder, broadcast_buffers=False, device_ids=[conf.local_rank])
+            head_mod = importlib.import_module("nets.%s" % getattr(conf, "loss", "PartialFC"))
+            if conf.optimizer == "SGD":
+                self.loss = head_mod.PartialFC(conf=conf, num_classes=conf.n_classes)
+            elif conf.optimizer == "AdamW":
+                self.loss = head_mod.PartialFCAdamW(conf=conf, num_classes=conf.n_classes)
+            else:
+                raise ValueError(conf.optimizer)
+            self.loss.train().to(conf.local_rank)
+            self.opt, self.sch = self.configure_optimizers()
+
+    def forward(self, x):
+        return self.encoder(x)
+
+    def training_step(self, batch):
+        img, id_ = batch
+        img, id_ = img.to(self.conf.local_rank), id_.to(self.conf.local_rank)
+        self.opt.zero_grad()
+        self.encoder.train()
+        feat = normalize(self.forward(img))
+        self.loss.train()
+        loss = self.loss(feat, id_, self.opt)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(self.encoder.parameters(), 5)
+        self.opt.step()
+        if self.sync_loss:
+            return {"loss": loss.cpu().detach().numpy()}
+        return {"loss": loss.detach()}
+
+    def training_epoch_end(self, outputs, t=None):
+        self.sch.step() if self.sch is not None else None
+        self.epoch += 1
+        losses = [float(np.asarray(o["loss"].cpu() if torch.is_tensor(o["loss"]) else o["loss"])) for o in outputs]
+        return {"lr": self.opt.param_groups[0]["lr"], "train_loss": float(np.mean(losses)) if losses else None,
+                "val_acc": None}
+
+    def configure_optimizers(self):
+        c = self.conf
+        groups = [{"params": self.encoder.parameters()}, {"params": self.loss.parameters()}]
+        if c.optimizer == "AdamW":
+            opt = torch.optim.AdamW(groups, lr=self.lr, weight_decay=c.wd, eps=c.eps, betas=c.betas)
+        elif c.optimizer == "SGD":
+            opt = torch.optim.SGD(groups, lr=self.lr, momentum=c.mom, weight_decay=c.wd)
+        sch = None
+        name = getattr(c, "lr_scheduler", None)
+        if name == "CosineAnnealingWarmupRestarts":
+            sch = importlib.import_module("utils.scheduler").CosineAnnealingWarmupRestarts(
+                opt, first_cycle_steps=c.num_epoch, warmup_steps=c.warmup_steps, min_lr=c.min_lr, max_lr=self.lr)
+        elif name == "MultiStep":
+            sch = torch.optim.lr_scheduler.MultiStepLR(opt, milestones=c.lr_decay_epoch, gamma=c.lr_decay_ratio)
+        elif name == "StepLR":
+            sch = torch.optim.lr_scheduler.StepLR(opt, step_size=c.lr_decay_epoch_size, gamma=c.lr_decay_ratio)
+        return opt, sch

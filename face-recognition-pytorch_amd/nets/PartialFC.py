@@ -1,0 +1,321 @@
+"""MI355X-native drop-in for the reference class-sharded classifier `nets/PartialFC.py`.
+
+Interface kept from /root/reference/nets/PartialFC.py: `PartialFC(conf, num_classes, margin_loss=ArcFace)` (:30-90),
+`PartialFCAdamW` (:235-342), `.forward(local_embeddings, local_labels, optimizer) -> 0-dim loss` (:146-208),
+`.sample` (:92-131), `.update` (:133-143), `.state_dict() -> {"weight"}` / `.load_state_dict` (:210-232), attributes
+`rank, world_size, num_local, class_start, num_sample, weight, weight_activated, weight_index`.
+torch.distributed must be initialised first (:47-49).
+
+What runs where
+  * shard arithmetic, label re-basing and the choice of sampled rows are host-orchestrated integer ops on [N] /
+    [num_local] vectors; the uniform draws come from torch's CPU generator exactly like the reference (:110), so
+    `weight_index` is reproducible from the CPU seed alone;
+  * everything floating-point is libfrhip: row l2-normalise, ONE fused kernel for cos-theta GEMM -> clamp ->
+    ArcFace margin -> x s -> per-row max / sum-exp (logits never reach HBM), a recompute kernel that emits
+    d loss / d cos once, two MFMA TN GEMMs for dW and dE, normalise-backward, and row gather / scatter of the
+    sampled class centres;
+  * cross-rank traffic is torch.distributed (backend "nccl" = RCCL over xGMI): one all-gather of embeddings +
+    labels, all-reduce MAX / SUM of the per-row scalars, and a reduce-scatter of dE (the reference issues
+    world_size separate reduce() calls, :510-519).
+The floating-point steps sit behind `HipHeadKernels`; tests on CPU/gloo swap in an oracle-backed double to
+exercise the distributed host logic without a GPU.  There is no built-in CPU fallback.
+"""
+import collections
+from typing import Callable
+
+import torch
+from torch import distributed
+
+from .ArcFace import ArcFace
+
+
+# --------------------------------------------------------------------------------------------- kernels
+class HipHeadKernels:
+    """The floating-point steps of the head on the MI355X (through the C ABI)."""
+
+    def __init__(self, dtype):
+        from frhip import ops          # raises FrhipError when libfrhip.so is missing
+        self.ops, self.dtype = ops, dtype
+
+    def normalize(self, x):
+        return self.ops.l2norm_rows(x.contiguous(), self.dtype)          # (xhat, norms)
+
+    def forward_stats(self, ehat, what, labels_i32, s, m):
+        return self.ops.head_fwd(ehat, what, labels_i32, s, m)           # (ztarget, rowmax, rowsum) of this shard
+
+    def rescale(self, rowsum, local_max, global_max):
+        self.ops.head_rescale(rowsum, local_max, global_max)
+
+    def target_prob(self, zt, labels_i32, rmax, rsum):
+        return self.ops.head_target_prob(zt, labels_i32, rmax, rsum)
+
+    def loss(self, q):
+        return self.ops.head_loss(q)
+
+    def backward(self, ehat, enorm, what, wnorm, labels_i32, s, m, rmax, rsum, n_global, upstream):
+        ops = self.ops
+        n, d = ehat.shape
+        classes = what.shape[0]
+        dt = ops.head_bwd_dt(ehat, what, labels_i32, s, m, rmax, rsum, 1.0 / n_global, upstream)
+        d_wh = torch.zeros((classes, d), dtype=torch.float32, device=ehat.device)
+        ops.gemm_tn(dt, ehat, d_wh, kc=classes)
+        dtt = ops.transpose2d(dt, pad_to=8)
+        d_eh = torch.zeros((n, d), dtype=torch.float32, device=ehat.device)
+        ops.gemm_tn(dtt[:classes], what, d_eh, kc=n)
+        return ops.l2norm_bwd(d_eh, ehat, enorm), ops.l2norm_bwd(d_wh, what, wnorm)
+
+    def gather_rows(self, table, index):
+        return self.ops.gather_rows(table, index)
+
+    def scatter_rows(self, rows, index, table):
+        self.ops.scatter_rows(rows.contiguous(), index, table)
+
+
+def _default_kernels(conf):
+    from .resnet import compute_dtype
+    return HipHeadKernels(compute_dtype(conf))
+
+
+# --------------------------------------------------------------------------------------------- collectives
+def _backend_is_nccl():
+    return distributed.get_backend() == "nccl"
+
+
+class AllGatherFunc(torch.autograd.Function):
+    """all_gather with gradient: backward = reduce-scatter(SUM) of the per-chunk gradients, x world_size
+    (reference :495-525, which loops world_size reduce() calls)."""
+
+    @staticmethod
+    def forward(ctx, tensor, *gather_list):
+        gather_list = list(gather_list)
+        distributed.all_gather(gather_list, tensor.contiguous())
+        return tuple(gather_list)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        ws, rank = distributed.get_world_size(), distributed.get_rank()
+        stacked = torch.cat([g.contiguous() for g in grads])
+        if _backend_is_nccl():
+            out = torch.empty_like(grads[rank])
+            distributed.reduce_scatter_tensor(out, stacked, op=distributed.ReduceOp.SUM)
+        else:                                   # gloo has no reduce_scatter
+            distributed.all_reduce(stacked, op=distributed.ReduceOp.SUM)
+            b = grads[rank].shape[0]
+            out = stacked[rank * b:(rank + 1) * b].clone()
+        out *= ws
+        return (out, *[None for _ in grads])
+
+
+AllGather = AllGatherFunc.apply
+
+
+class _MarginSoftmaxFn(torch.autograd.Function):
+    """normalise -> cos -> margin -> distributed softmax-CE, as one autograd node over the fused kernels.
+    Arithmetic: SURVEY.md Appendix A steps 1-6 (nets/PartialFC.py:198-207, nets/ArcFace.py:76-91, :441-484)."""
+
+    @staticmethod
+    def forward(ctx, embeddings, weight_activated, labels_i32, kern, s, m, world_size):
+        ehat, enorm = kern.normalize(embeddings)
+        what, wnorm = kern.normalize(weight_activated)
+        zt, rmax, rsum = kern.forward_stats(ehat, what, labels_i32, s, m)
+        if world_size > 1:
+            gmax = rmax.clone()
+            distributed.all_reduce(gmax, distributed.ReduceOp.MAX)          # :448
+            kern.rescale(rsum, rmax, gmax)
+            distributed.all_reduce(rsum, distributed.ReduceOp.SUM)          # :453
+            rmax = gmax
+        q = kern.target_prob(zt, labels_i32, rmax, rsum)
+        if world_size > 1:
+            distributed.all_reduce(q, distributed.ReduceOp.SUM)             # :459
+        loss = kern.loss(q)
+        ctx.kern, ctx.s, ctx.m = kern, s, m
+        ctx.save_for_backward(ehat, enorm, what, wnorm, labels_i32, rmax, rsum)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, grad_loss):
+        ehat, enorm, what, wnorm, labels_i32, rmax, rsum = ctx.saved_tensors
+        up = grad_loss.reshape(1).float().contiguous()
+        d_e, d_w = ctx.kern.backward(ehat, enorm, what, wnorm, labels_i32, ctx.s, ctx.m, rmax, rsum,
+                                     ehat.shape[0], up)
+        return d_e, d_w, None, None, None, None, None
+
+
+class DistCrossEntropy(torch.nn.Module):
+    """Kept for interface parity (reference :487-492).  The fused head never materialises `logit_part`, so this
+    module is not on the hot path; calling it with explicit logits is not supported by the HIP build."""
+
+    def forward(self, logit_part, label_part):
+        raise NotImplementedError("frhip fuses the distributed softmax-CE into PartialFC.forward; "
+                                  "explicit logits are never materialised on the MI355X path")
+
+
+# --------------------------------------------------------------------------------------------- module
+class _PartialFCBase(torch.nn.Module):
+    _version = 1
+
+    def __init__(self, conf, num_classes, margin_loss: Callable = ArcFace, kernels=None):
+        super().__init__()
+        assert distributed.is_initialized(), "must initialize distributed before create this"
+        self.rank = distributed.get_rank()
+        self.world_size = distributed.get_world_size()
+        self.dist_cross_entropy = DistCrossEntropy()
+        self.embedding_size = conf.emd_size
+        self.sample_rate: float = conf.sample_rate
+        self.fp16 = conf.mixed_precision
+        self.num_local: int = num_classes // self.world_size + int(self.rank < num_classes % self.world_size)
+        self.class_start: int = num_classes // self.world_size * self.rank + min(self.rank, num_classes % self.world_size)
+        self.num_sample: int = int(self.sample_rate * self.num_local)
+        self.last_batch_size: int = 0
+        self.is_updated: bool = True
+        self.init_weight_update: bool = True
+        self._state_names = self._optimizer_state_names()
+        init = torch.normal(0, 0.01, (self.num_local, self.embedding_size))
+        if self.sample_rate < 1:
+            self.register_buffer("weight", tensor=init)
+            for nm in self._state_names:
+                self.register_buffer("weight_" + nm, tensor=torch.zeros_like(init))
+            self.register_parameter("weight_activated", param=torch.nn.Parameter(torch.empty(0, 0)))
+            for nm in self._state_names:
+                self.register_buffer("weight_activated_" + nm, tensor=torch.empty(0, 0))
+            self.register_buffer("weight_index", tensor=torch.empty(0, 0))
+        else:
+            self.weight_activated = torch.nn.Parameter(init)
+        if isinstance(margin_loss, Callable):
+            self.margin_softmax = margin_loss(conf.loss_s, conf.loss_m)
+        else:
+            raise
+        if getattr(self.margin_softmax, "kind", None) != "arcface":
+            raise NotImplementedError("the fused head kernel implements the ArcFace margin (the reference default)")
+        self._kernels = kernels
+        self._conf = conf
+        self.step = 0
+
+    # -- subclass hooks
+    def _optimizer_state_names(self):
+        raise NotImplementedError
+
+    def _install_optimizer_state(self, optimizer):
+        raise NotImplementedError
+
+    @property
+    def kernels(self):
+        if self._kernels is None:
+            self._kernels = _default_kernels(self._conf)
+        return self._kernels
+
+    @torch.no_grad()
+    def sample(self, labels, index_positive, optimizer):
+        """Choose the rows of this shard that take part in the step and re-express labels as positions in
+        that list (reference :92-131 / :309-327).  Mutates `labels` in place like the reference."""
+        self.step += 1
+        dev = labels.device
+        positive = torch.unique(labels[index_positive], sorted=True)
+        if self.num_sample - positive.size(0) >= 0:
+            perm = torch.rand(size=[self.num_local]).to(dev)     # CPU generator, then moved: same draws as the reference
+            perm[positive] = 2.0
+            index = torch.topk(perm, k=self.num_sample)[1]
+            index = index.sort()[0]
+        else:
+            index = positive
+        self.weight_index = index
+        labels[index_positive] = torch.searchsorted(index, labels[index_positive])
+        k = self.kernels
+        self.weight_activated = torch.nn.Parameter(k.gather_rows(self.weight, index))
+        for nm in self._state_names:
+            setattr(self, "weight_activated_" + nm, k.gather_rows(getattr(self, "weight_" + nm), index))
+        self._install_optimizer_state(optimizer)
+
+    @torch.no_grad()
+    def update(self):
+        """sampled rows -> full table (reference :133-143)"""
+        if self.init_weight_update:
+            self.init_weight_update = False
+            return
+        if self.sample_rate < 1:
+            k = self.kernels
+            k.scatter_rows(self.weight_activated.data, self.weight_index, self.weight)
+            for nm in self._state_names:
+                k.scatter_rows(getattr(self, "weight_activated_" + nm), self.weight_index, getattr(self, "weight_" + nm))
+
+    def forward(self, local_embeddings, local_labels, optimizer):
+        local_labels.squeeze_()
+        local_labels = local_labels.long()
+        self.update()
+        batch_size = local_embeddings.size(0)
+        if self.last_batch_size == 0:
+            self.last_batch_size = batch_size
+        assert self.last_batch_size == batch_size, (
+            "last batch size do not equal current batch size: {} vs {}".format(self.last_batch_size, batch_size))
+        dev = local_embeddings.device
+        if self.world_size > 1:
+            gathered = [torch.zeros((batch_size, self.embedding_size), device=dev) for _ in range(self.world_size)]
+            glabels = [torch.zeros(batch_size, dtype=torch.long, device=dev) for _ in range(self.world_size)]
+            embeddings = torch.cat(AllGather(local_embeddings, *gathered))
+            distributed.all_gather(glabels, local_labels)
+            labels = torch.cat(glabels)
+        else:
+            embeddings, labels = local_embeddings, local_labels.clone()
+        labels = labels.view(-1, 1)
+        index_positive = (self.class_start <= labels) & (labels < self.class_start + self.num_local)
+        labels[~index_positive] = -1
+        labels[index_positive] -= self.class_start
+        if self.sample_rate < 1:
+            self.sample(labels, index_positive, optimizer)
+        return _MarginSoftmaxFn.apply(embeddings, self.weight_activated, labels.view(-1).to(torch.int32).contiguous(),
+                                      self.kernels, float(self.margin_softmax.scale), float(self.margin_softmax.margin),
+                                      self.world_size)
+
+    def state_dict(self, destination=None, prefix="", keep_vars=False):
+        if destination is None:
+            destination = collections.OrderedDict()
+            destination._metadata = collections.OrderedDict()
+        for name, module in self._modules.items():
+            if module is not None:
+                module.state_dict(destination=destination, prefix=prefix + name + ".", keep_vars=keep_vars)
+        destination["weight"] = (self.weight if self.sample_rate < 1 else self.weight_activated.data).detach()
+        return destination
+
+    def load_state_dict(self, state_dict, strict: bool = True):
+        if self.sample_rate < 1:
+            self.weight = state_dict["weight"].to(self.weight.device)
+            for nm in self._state_names:
+                getattr(self, "weight_" + nm).zero_()
+                getattr(self, "weight_activated_" + nm).zero_()
+            self.weight_activated.data.zero_()
+            self.weight_index.zero_()
+        else:
+            self.weight_activated.data = state_dict["weight"].to(self.weight_activated.data.device)
+
+
+class PartialFC(_PartialFCBase):
+    """SGD flavour: the sampled rows carry their momentum rows (reference :10-232)."""
+
+    def _optimizer_state_names(self):
+        return ("mom",)
+
+    def _install_optimizer_state(self, optimizer):
+        if isinstance(optimizer, torch.optim.SGD):
+            # the params of partial fc must be last in the params list (reference :124)
+            optimizer.state.pop(optimizer.param_groups[-1]["params"][0], None)
+            optimizer.param_groups[-1]["params"][0] = self.weight_activated
+            optimizer.state[self.weight_activated]["momentum_buffer"] = self.weight_activated_mom
+        else:
+            raise
+
+
+class PartialFCAdamW(_PartialFCBase):
+    """Adam/AdamW flavour: exp_avg / exp_avg_sq rows travel with the sampled rows (reference :235-432)."""
+
+    def _optimizer_state_names(self):
+        return ("exp_avg", "exp_avg_sq")
+
+    def _install_optimizer_state(self, optimizer):
+        if isinstance(optimizer, (torch.optim.Adam, torch.optim.AdamW)):
+            optimizer.state.pop(optimizer.param_groups[-1]["params"][0], None)
+            optimizer.param_groups[-1]["params"][0] = self.weight_activated
+            optimizer.state[self.weight_activated]["exp_avg"] = self.weight_activated_exp_avg
+            optimizer.state[self.weight_activated]["exp_avg_sq"] = self.weight_activated_exp_avg_sq
+            optimizer.state[self.weight_activated]["step"] = self.step
+        else:
+            raise

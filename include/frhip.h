@@ -91,6 +91,8 @@ int frhip_bn_bwd_finalize(const float* partial, int nparts, float* scratch, int 
 int frhip_bn_bwd_apply(int dtype, const void* dout, const void* y, const float* ca, const float* cb,
                        const float* cc, const float* mask_scale, const float* mask_shift, void* dy,
                        int rows, int c, frhip_stream_t stream);
+/* out_accum[c] += sum over partial rows of partial[p][which][c]  (fc bias gradient = column sum) */
+int frhip_sum_partials(const float* partial, int nparts, int c, int which, float* out_accum, frhip_stream_t stream);
 int frhip_add_bias(float* x, const float* bias, int rows, int c, frhip_stream_t stream);
 int frhip_cast_from_f32(int dtype, const float* src, void* dst, size_t n, frhip_stream_t stream);
 int frhip_cast_to_f32(int dtype, const void* src, float* dst, size_t n, frhip_stream_t stream);
@@ -133,10 +135,11 @@ int frhip_head_rescale(float* rowsum, const float* local_max, const float* globa
 int frhip_head_target_prob(const float* ztarget, const int* labels, const float* rowmax, const float* rowsum,
                            float* q, int n, frhip_stream_t stream);
 int frhip_head_loss(const float* q, int n, float* loss, frhip_stream_t stream);
-/* dT[n][ldt] = d loss / d cos (after clamp/margin/scale chain rule), gscale = upstream / N_global */
+/* dT[n][ldt] = d loss / d cos (after clamp/margin/scale chain rule); gscale = 1 / N_global, times the device
+ * scalar *upstream when it is not NULL (the reference syncs the host here: loss_gradient.item(), nets/PartialFC.py:484) */
 int frhip_head_bwd_dt(int dtype, const void* ehat, const void* what, const int* labels, int n, int classes,
                       int d, float s, float m, const float* rowmax, const float* rowsum, float gscale,
-                      void* dt, int ldt, frhip_stream_t stream);
+                      const float* upstream, void* dt, int ldt, frhip_stream_t stream);
 
 #ifdef __cplusplus
 }

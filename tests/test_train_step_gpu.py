@@ -1,0 +1,83 @@
+"""Whole optimisation steps of the drop-in Model on the MI355X against the reference-generated fixtures
+(BASELINE cfg 1: ResNet-18 + ArcFace head, 256 ids, 3 SGD steps), fp32 validation mode."""
+import os
+import tempfile
+import types
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+
+from oracle import recipe, resnet_ref
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pg():
+    if not dist.is_initialized():
+        d = tempfile.mkdtemp()
+        dist.init_process_group("gloo", init_method="file://" + os.path.join(d, "pg"), rank=0, world_size=1)
+    yield
+    if dist.is_initialized():
+        dist.destroy_process_group()
+
+
+def _conf(rate, dtype):
+    return types.SimpleNamespace(network="ResNet18", emd_size=512, img_size=112, local_rank=0, world_size=1,
+                                 sample_rate=rate, mixed_precision=False, loss_s=30.0, loss_m=0.35, n_classes=256,
+                                 optimizer="SGD", lr=0.1, wd=5e-4, mom=0.9, loss="PartialFC", lr_scheduler=None,
+                                 frhip_dtype=dtype, ckpt_path=None)
+
+
+@pytest.mark.parametrize("tag", ["rate10", "rate03"])
+def test_three_sgd_steps_match_reference(golden, pg, tag):
+    from model.FR_PartialFC import Model
+    g = golden("train_step_resnet18_c256_" + tag)
+    rate, C, B = float(g["rate"]), int(g["C"]), int(g["B"])
+    torch.cuda.set_device(0)
+    model = Model(_conf(rate, "fp32"), None, "train")
+    spec = resnet_ref.resnet_spec(resnet_ref.BLOCKS["ResNet18"])
+    sd = recipe.fill_state(spec, 777)
+    for k, _, kind in spec:
+        if kind in ("bn_w", "bn_rv"):
+            sd[k].fill_(1.0)
+        elif kind in ("bn_b", "bn_rm"):
+            sd[k].zero_()
+    model.encoder.load_state_dict(sd, strict=True)
+    W = recipe.normal(778, (C, 512), 0.01).cuda()
+    with torch.no_grad():
+        (model.loss.weight if rate < 1 else model.loss.weight_activated.data).copy_(W)
+    img, ids = recipe.images(779, B), recipe.labels(780, B, C)
+    for st in range(int(g["steps"])):
+        torch.manual_seed(3000 + st)                 # the head draws its negatives from the CPU generator
+        out = model.training_step((img, ids.clone()))
+        # step 0 is a pure function of the inputs: 1e-3 (north_star tolerance).  Later steps see the previous
+        # update (lr 0.1 on a memorised 16-image batch: losses collapse to ~1e-5) and amplify fp32 summation-order
+        # noise, so they get a looser bound.
+        np.testing.assert_allclose(float(out["loss"]), g["losses"][st], rtol=1e-3 if st == 0 else 5e-2, atol=1e-6)
+        if rate < 1:
+            assert np.array_equal(model.loss.weight_index.cpu().numpy(), g["index_step%d" % st])   # bit-exact
+    if rate < 1:
+        model.loss.update()
+    for k in ("conv1.weight", "layer2.0.downsample.0.weight", "layer4.1.bn2.weight", "fc.weight",
+              "bn3.running_var", "bn1.running_mean"):
+        got = recipe.summary(model.encoder.state_dict()[k].float().cpu())
+        # three lr-0.1 steps on a memorised batch amplify summation-order noise: elements to 5e-4 abs,
+        # the tensor's l2 norm (entry 1 of the summary) to 1e-3 relative
+        # (entry 0, the plain sum over the tensor, accumulates those per-element differences and is skipped)
+        np.testing.assert_allclose(got[1:], g["after." + k][1:], rtol=5e-3, atol=5e-4, err_msg=k)
+        np.testing.assert_allclose(got[1], g["after." + k][1], rtol=1e-3, err_msg=k)
+    wfin = model.loss.weight if rate < 1 else model.loss.weight_activated.data
+    np.testing.assert_allclose(recipe.summary(wfin.cpu())[1:], g["after.head_weight"][1:], rtol=5e-3, atol=5e-4)
+
+
+def test_bf16_training_reduces_loss(pg):
+    from model.FR_PartialFC import Model
+    torch.cuda.set_device(0)
+    model = Model(_conf(1.0, "bf16"), None, "train")
+    img, ids = recipe.images(779, 16), recipe.labels(780, 16, 256)
+    losses = [float(model.training_step((img, ids.clone()))["loss"]) for _ in range(6)]
+    assert np.isfinite(losses).all()
+    assert losses[-1] < losses[0] * 0.7, losses
