@@ -1,0 +1,215 @@
+#!/usr/bin/env python3
+"""Headline benchmark: train imgs/sec of the IR-50-layout ResNet50 + ArcFace/PartialFC head on synthetic 112x112
+faces (BASELINE.json metric), one process per GPU.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W
+
+A step = Model.training_step (zero_grad, backbone fwd, normalise, margin-softmax head, backward, clip, SGD step)
+on a pre-staged synthetic batch.  Rank 0 prints ONE JSON line.  `roofline` is measured live: every launch of the
+dominant kernel (the bf16 MFMA implicit-GEMM conv, forward + data-gradient) inside the timed region is bracketed
+by HIP events on the stream it runs on; achieved = algorithmic FLOPs of those launches / their summed duration.
+`cpu_baseline` times the CPU restatement (oracle/) of the same step on the host cores (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+import types
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(ROOT, "face-recognition-pytorch_amd")
+for p in (ROOT, PKG):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+BF16_DENSE_PEAK_TFLOPS = 2516.6      # 256 CU x 4096 FLOP/clk x 2.4 GHz (MI355X_MICROARCH.md: ~2.5 PF dense)
+NUM_CLASSES = 122000                 # BASELINE.json cfg 2 ("MS1M-122K ids"); the reference config has 86 690
+BATCH = 512
+
+
+def make_conf(args, rank, world):
+    rate = 1.0 if world == 1 else 0.1            # cfg 2 (1 GPU, full head) / cfg 3 (PartialFC rate 0.1 over the node)
+    return types.SimpleNamespace(
+        network="ResNet50", emd_size=512, img_size=112, local_rank=rank % max(torch.cuda.device_count(), 1),
+        world_size=world, sample_rate=rate, mixed_precision=True, loss_s=30.0, loss_m=0.35, n_classes=args.classes,
+        optimizer="SGD", lr=0.1, wd=5e-4, mom=0.9, loss="PartialFC", lr_scheduler=None, frhip_dtype="bf16",
+        ckpt_path=None)
+
+
+class ConvMeter:
+    """Brackets every NT implicit-GEMM conv launch (forward and data-gradient) with HIP events."""
+
+    def __init__(self, ops):
+        self.ops, self.records, self.on = ops, [], False
+        self._fwd, self._dgrad = ops.conv_fwd, ops.conv_dgrad
+
+        def conv_fwd(x, w, stride, pad, want_stats=True):
+            if not self.on or x.dtype != torch.bfloat16:
+                return self._fwd(x, w, stride, pad, want_stats)
+            n, h, wd, c = x.shape
+            k, r, s, _ = w.shape
+            ho, wo = ops.conv_out_hw(h, wd, r, s, stride, pad)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = self._fwd(x, w, stride, pad, want_stats)
+            e1.record()
+            self.records.append((e0, e1, 2.0 * n * ho * wo * k * r * s * c))
+            return out
+
+        def conv_dgrad(dy, wt, x_shape, r, s, stride, pad, residual=None, out=None):
+            if not self.on or dy.dtype != torch.bfloat16:
+                return self._dgrad(dy, wt, x_shape, r, s, stride, pad, residual, out)
+            n, ho, wo, k = dy.shape
+            c = x_shape[3]
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            o = self._dgrad(dy, wt, x_shape, r, s, stride, pad, residual, out)
+            e1.record()
+            self.records.append((e0, e1, 2.0 * n * ho * wo * k * r * s * c))   # algorithmic: same MACs as forward
+            return o
+
+        ops.conv_fwd, ops.conv_dgrad = conv_fwd, conv_dgrad
+
+    def summary(self):
+        ms = sum(e0.elapsed_time(e1) for e0, e1, _ in self.records)
+        fl = sum(f for _, _, f in self.records)
+        n = len(self.records)
+        return n, ms, fl
+
+
+def cpu_baseline(classes, batch=16, steps=4):
+    """Oracle (CPU restatement, fp32, all host cores) on a bounded sample of the same workload."""
+    from oracle import recipe, resnet_ref, train_ref
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 32))
+    torch.set_num_threads(cores)
+    log("cpu_baseline: %d threads" % cores)
+    blocks = resnet_ref.BLOCKS["ResNet50"]
+    sd = recipe.fill_state(resnet_ref.resnet_spec(blocks), 1)
+    w = recipe.normal(2, (classes, 512), 0.01)
+    img, ids = recipe.images(3, batch), recipe.labels(4, batch, classes)
+    opt = train_ref.SGDState(0.1, 0.9, 5e-4)
+    train_ref.train_step(sd, w, img, ids, blocks, classes, opt)       # warm-up
+    log("cpu_baseline: warm-up step done")
+    t0 = time.time()
+    for i in range(steps):
+        train_ref.train_step(sd, w, img, ids, blocks, classes, opt)
+        log("cpu_baseline: step %d" % i)
+    dt = time.time() - t0
+    return {"value": round(batch * steps / dt, 2), "unit": "imgs/sec", "cores": cores, "kind": "port",
+            "sample": "oracle/ CPU restatement, ResNet50 + ArcFace head C=%d, B=%d fp32, 1 warm-up + %d timed SGD "
+                      "steps (%.1f s)" % (classes, batch, steps, dt)}
+
+
+def log(msg):
+    if int(os.environ.get("RANK", "0")) == 0:
+        print("[bench %7.1fs] %s" % (time.time() - T_START, msg), file=sys.stderr, flush=True)
+
+
+T_START = time.time()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=BATCH)
+    ap.add_argument("--classes", type=int, default=NUM_CLASSES)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    torch.cuda.set_device(local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    else:
+        dist.init_process_group("gloo", init_method="file://" + os.path.join(tempfile.mkdtemp(), "pg"),
+                                rank=0, world_size=1)
+
+    import __graft_entry__ as ge
+    if rank == 0:
+        ge.build()
+    if world > 1:
+        dist.barrier()
+    from frhip import ops
+    from model.FR_PartialFC import Model
+
+    log("library built/loaded")
+    conf = make_conf(args, local, world)
+    torch.manual_seed(1234 + rank)
+    model = Model(conf, None, "train")
+    model.sync_loss = False
+    gen = torch.Generator().manual_seed(1234 + rank)
+    img = torch.randn((args.batch, 3, 112, 112), generator=gen).clamp_(-1, 1).cuda()
+    ids = torch.randint(0, args.classes, (args.batch,), generator=gen).cuda()
+    meter = ConvMeter(ops)
+    log("model + synthetic batch ready (B=%d, classes=%d)" % (args.batch, args.classes))
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        model.training_step((img, ids.clone()))
+        torch.cuda.synchronize()
+        log("warm-up step %d done" % i)
+    sync()
+    meter.on = True
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = model.training_step((img, ids.clone()))
+    sync()
+    dt = time.perf_counter() - t0
+    meter.on = False
+    t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+    loss = float(out["loss"])
+    log("timed region: %.3f s for %d steps" % (dt, args.steps))
+
+    if rank == 0:
+        n, ms, fl = meter.summary()
+        achieved = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        line = {
+            "metric": "train imgs/sec IR-50-layout ResNet50 + ArcFace/PartialFC head, 112x112",
+            "value": round(args.batch * world * args.steps / dt, 1), "unit": "imgs/sec", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "BASELINE cfg %d: ResNet50([3,4,14,4] BasicBlock)+%s, %d ids, B=%d/GPU, SGD "
+                                   "mom 0.9 wd 5e-4, s=30 m=0.35" % (2 if world == 1 else 3,
+                                                                     "ArcFace (PartialFC rate 1.0)" if world == 1 else "PartialFC rate 0.1",
+                                                                     args.classes, args.batch),
+                       "global_batch": args.batch * world, "parallelism": "dp%d+class-shard%d" % (world, world)},
+            "final_loss": round(loss, 4),
+            "roofline": {"bound": "mfma", "achieved": round(achieved, 1), "peak": BF16_DENSE_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": round(achieved / BF16_DENSE_PEAK_TFLOPS, 4), "traffic": None,
+                         "kernel": "frhip::nt_kernel<bf16> (conv forward + data-gradient implicit GEMM)",
+                         "launches": n, "avg_launch_us": round(ms * 1e3 / max(n, 1), 2),
+                         "flop_per_launch": round(fl / max(n, 1))},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args.classes)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
