@@ -123,26 +123,40 @@ __global__ void bn_bwd_finalize_kernel(const float* __restrict__ parts, int npar
 }
 
 // out = act( y*scale + shift  [+ res  |  + res*rscale + rshift] )
+// Each thread owns one 16-byte channel group for its whole life, so the per-channel vectors are read once into
+// registers and the row loop is pure streaming.
 template <typename T>
 __global__ __launch_bounds__(EW_THREADS) void bn_apply_kernel(const T* __restrict__ y, const float* __restrict__ scale,
                                                               const float* __restrict__ shift, const T* __restrict__ res,
                                                               const float* __restrict__ rscale, const float* __restrict__ rshift,
-                                                              int relu, T* __restrict__ out, size_t nvec, int C) {
+                                                              int relu, T* __restrict__ out, int rows, int C) {
     constexpr int EPV = EW<T>::EPV;
     const int vpr = C / EPV;
-    for (size_t v = (size_t)blockIdx.x * EW_THREADS + threadIdx.x; v < nvec; v += (size_t)gridDim.x * EW_THREADS) {
-        const int c0 = (int)(v % vpr) * EPV;
-        Vec16<T> a = *reinterpret_cast<const Vec16<T>*>(y + v * EPV);
-        Vec16<T> r;
-        if (res) r = *reinterpret_cast<const Vec16<T>*>(res + v * EPV);
+    const int cg = threadIdx.x % vpr, rl = threadIdx.x / vpr, rlanes = EW_THREADS / vpr;
+    float sc[EPV], sh[EPV], rs[EPV], rb[EPV];
 #pragma unroll
-        for (int e = 0; e < EPV; ++e) {
-            float o = a.get(e) * scale[c0 + e] + shift[c0 + e];
-            if (res) o += rscale ? r.get(e) * rscale[c0 + e] + rshift[c0 + e] : r.get(e);
-            if (relu) o = o > 0.f ? o : 0.f;
-            a.set(e, o);
+    for (int e = 0; e < EPV; ++e) {
+        sc[e] = scale[cg * EPV + e]; sh[e] = shift[cg * EPV + e];
+        rs[e] = rscale ? rscale[cg * EPV + e] : 1.f; rb[e] = rscale ? rshift[cg * EPV + e] : 0.f;
+    }
+    for (int r = blockIdx.x * rlanes + rl; r < rows; r += gridDim.x * rlanes) {
+        const size_t idx = (size_t)r * C + cg * EPV;
+        Vec16<T> a = *reinterpret_cast<const Vec16<T>*>(y + idx);
+        if (res) {
+            const Vec16<T> rv = *reinterpret_cast<const Vec16<T>*>(res + idx);
+#pragma unroll
+            for (int e = 0; e < EPV; ++e) {
+                float o = a.get(e) * sc[e] + sh[e] + (rv.get(e) * rs[e] + rb[e]);
+                a.set(e, relu ? fmaxf(o, 0.f) : o);
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < EPV; ++e) {
+                float o = a.get(e) * sc[e] + sh[e];
+                a.set(e, relu ? fmaxf(o, 0.f) : o);
+            }
         }
-        *reinterpret_cast<Vec16<T>*>(out + v * EPV) = a;
+        *reinterpret_cast<Vec16<T>*>(out + idx) = a;
     }
 }
 
@@ -152,21 +166,27 @@ __global__ __launch_bounds__(EW_THREADS) void bn_bwd_apply_kernel(const T* __res
                                                                   const float* __restrict__ ca, const float* __restrict__ cb,
                                                                   const float* __restrict__ cc, const float* __restrict__ mscale,
                                                                   const float* __restrict__ mshift, T* __restrict__ dy,
-                                                                  size_t nvec, int C) {
+                                                                  int rows, int C) {
     constexpr int EPV = EW<T>::EPV;
     const int vpr = C / EPV;
-    for (size_t v = (size_t)blockIdx.x * EW_THREADS + threadIdx.x; v < nvec; v += (size_t)gridDim.x * EW_THREADS) {
-        const int c0 = (int)(v % vpr) * EPV;
-        const Vec16<T> d = *reinterpret_cast<const Vec16<T>*>(dout + v * EPV);
-        Vec16<T> b = *reinterpret_cast<const Vec16<T>*>(y + v * EPV);
+    const int cg = threadIdx.x % vpr, rl = threadIdx.x / vpr, rlanes = EW_THREADS / vpr;
+    float a_[EPV], b_[EPV], c_[EPV], ms[EPV], mb[EPV];
+#pragma unroll
+    for (int e = 0; e < EPV; ++e) {
+        a_[e] = ca[cg * EPV + e]; b_[e] = cb[cg * EPV + e]; c_[e] = cc[cg * EPV + e];
+        ms[e] = mscale ? mscale[cg * EPV + e] : 0.f; mb[e] = mscale ? mshift[cg * EPV + e] : 1.f;
+    }
+    for (int r = blockIdx.x * rlanes + rl; r < rows; r += gridDim.x * rlanes) {
+        const size_t idx = (size_t)r * C + cg * EPV;
+        const Vec16<T> d = *reinterpret_cast<const Vec16<T>*>(dout + idx);
+        Vec16<T> b = *reinterpret_cast<const Vec16<T>*>(y + idx);
 #pragma unroll
         for (int e = 0; e < EPV; ++e) {
             const float yy = b.get(e);
-            float de = d.get(e);
-            if (mscale && !(yy * mscale[c0 + e] + mshift[c0 + e] > 0.f)) de = 0.f;
-            b.set(e, ca[c0 + e] * de + cb[c0 + e] * yy + cc[c0 + e]);
+            const float de = (yy * ms[e] + mb[e] > 0.f) ? d.get(e) : 0.f;
+            b.set(e, a_[e] * de + b_[e] * yy + c_[e]);
         }
-        *reinterpret_cast<Vec16<T>*>(dy + v * EPV) = b;
+        *reinterpret_cast<Vec16<T>*>(dy + idx) = b;
     }
 }
 
@@ -201,6 +221,15 @@ static int grid_for(size_t work_items, int per_block) {
     if (b > 2048) b = 2048;            // 256 CUs x 8 blocks, grid-stride the rest
     if (b < 1) b = 1;
     return (int)b;
+}
+
+// blocks for the row-streaming element-wise kernels: 256 CUs x 8 resident blocks, each thread >= 1 row
+static int ew_row_blocks(int rows, int c, int dtype) {
+    const int epv = dtype == FRHIP_DT_BF16 ? 8 : 4;
+    const int rlanes = EW_THREADS / (c / epv);
+    int b = (rows + rlanes - 1) / rlanes;
+    if (b > 2048) b = 2048;
+    return b < 1 ? 1 : b;
 }
 
 static bool shape_ok(int dtype, int C, const char* who) {
@@ -291,15 +320,13 @@ extern "C" int frhip_bn_apply(int dtype, const void* y, const float* scale, cons
                               const float* res_scale, const float* res_shift, int relu, void* out, int rows, int c,
                               hipStream_t stream) {
     if (!shape_ok(dtype, c, "frhip_bn_apply")) return FRHIP_EINVAL;
-    const int epv = dtype == FRHIP_DT_BF16 ? 8 : 4;
-    const size_t nvec = (size_t)rows * c / epv;
-    const int blocks = grid_for(nvec, EW_THREADS);
+    const int blocks = ew_row_blocks(rows, c, dtype);
     if (dtype == FRHIP_DT_BF16)
         hipLaunchKernelGGL(bn_apply_kernel<bf16_t>, dim3(blocks), dim3(EW_THREADS), 0, stream, (const bf16_t*)y, scale,
-                           shift, (const bf16_t*)res, res_scale, res_shift, relu, (bf16_t*)out, nvec, c);
+                           shift, (const bf16_t*)res, res_scale, res_shift, relu, (bf16_t*)out, rows, c);
     else
         hipLaunchKernelGGL(bn_apply_kernel<float>, dim3(blocks), dim3(EW_THREADS), 0, stream, (const float*)y, scale,
-                           shift, (const float*)res, res_scale, res_shift, relu, (float*)out, nvec, c);
+                           shift, (const float*)res, res_scale, res_shift, relu, (float*)out, rows, c);
     return check_launch("frhip_bn_apply");
 }
 
@@ -307,15 +334,13 @@ extern "C" int frhip_bn_bwd_apply(int dtype, const void* dout, const void* y, co
                                   const float* cc, const float* mask_scale, const float* mask_shift, void* dy,
                                   int rows, int c, hipStream_t stream) {
     if (!shape_ok(dtype, c, "frhip_bn_bwd_apply")) return FRHIP_EINVAL;
-    const int epv = dtype == FRHIP_DT_BF16 ? 8 : 4;
-    const size_t nvec = (size_t)rows * c / epv;
-    const int blocks = grid_for(nvec, EW_THREADS);
+    const int blocks = ew_row_blocks(rows, c, dtype);
     if (dtype == FRHIP_DT_BF16)
         hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(blocks), dim3(EW_THREADS), 0, stream, (const bf16_t*)dout,
-                           (const bf16_t*)y, ca, cb, cc, mask_scale, mask_shift, (bf16_t*)dy, nvec, c);
+                           (const bf16_t*)y, ca, cb, cc, mask_scale, mask_shift, (bf16_t*)dy, rows, c);
     else
         hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(blocks), dim3(EW_THREADS), 0, stream, (const float*)dout,
-                           (const float*)y, ca, cb, cc, mask_scale, mask_shift, (float*)dy, nvec, c);
+                           (const float*)y, ca, cb, cc, mask_scale, mask_shift, (float*)dy, rows, c);
     return check_launch("frhip_bn_bwd_apply");
 }
 

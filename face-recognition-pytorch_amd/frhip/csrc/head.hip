@@ -151,15 +151,32 @@ __global__ __launch_bounds__(NT_THREADS, 2) void head_kernel(NtGeom g, const voi
 }
 
 // rowmax[m] = max_g part_max[g][m]; rowsum[m] = sum_g part_sum[g][m] * exp(part_max[g][m] - rowmax[m])
-__global__ void head_rowreduce_kernel(const float* __restrict__ part_max, const float* __restrict__ part_sum,
-                                      int ngroups, int N, float* __restrict__ rowmax, float* __restrict__ rowsum) {
-    const int m = blockIdx.x * blockDim.x + threadIdx.x;
-    if (m >= N) return;
-    float mx = -INFINITY;
-    for (int gq = 0; gq < ngroups; ++gq) mx = fmaxf(mx, part_max[(size_t)gq * N + m]);
-    float s = 0.f;
-    for (int gq = 0; gq < ngroups; ++gq) s += part_sum[(size_t)gq * N + m] * __expf(part_max[(size_t)gq * N + m] - mx);
-    rowmax[m] = mx; rowsum[m] = s;
+// block = 16 rows x 16 group-lanes; each lane folds its share of the column groups with an online max/sum merge,
+// the 16 partial (max, sum) pairs of a row are merged through LDS.
+__global__ __launch_bounds__(256) void head_rowreduce_kernel(const float* __restrict__ part_max, const float* __restrict__ part_sum,
+                                                             int ngroups, int N, float* __restrict__ rowmax, float* __restrict__ rowsum) {
+    __shared__ float smax[16][17], ssum[16][17];
+    const int ml = threadIdx.x & 15, gl = threadIdx.x >> 4;
+    const int m = blockIdx.x * 16 + ml;
+    float mx = -INFINITY, s = 0.f;
+    if (m < N) {
+        for (int gq = gl; gq < ngroups; gq += 16) {
+            const float pm = part_max[(size_t)gq * N + m], ps = part_sum[(size_t)gq * N + m];
+            if (pm > mx) { s = s * __expf(mx - pm) + ps; mx = pm; }
+            else if (pm > -INFINITY) s += ps * __expf(pm - mx);
+        }
+    }
+    smax[gl][ml] = mx; ssum[gl][ml] = s;
+    __syncthreads();
+    if (gl == 0 && m < N) {
+        float M = -INFINITY;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) M = fmaxf(M, smax[k][ml]);
+        float S = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) if (smax[k][ml] > -INFINITY) S += ssum[k][ml] * __expf(smax[k][ml] - M);
+        rowmax[m] = M; rowsum[m] = S;
+    }
 }
 
 // rowsum *= exp(local_max - global_max)      (before the cross-rank SUM)
@@ -263,7 +280,7 @@ extern "C" int frhip_head_fwd(int dtype, const void* ehat, const void* what, con
     if (dtype == FRHIP_DT_BF16) rc = head_launch<bf16_t, true>(g, ehat, what, labels, mc, part_max, part_sum, ztarget, nullptr, nullptr, 0.f, nullptr, nullptr, 0, stream);
     else rc = head_launch<float, true>(g, ehat, what, labels, mc, part_max, part_sum, ztarget, nullptr, nullptr, 0.f, nullptr, nullptr, 0, stream);
     if (rc) return rc;
-    hipLaunchKernelGGL(head_rowreduce_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, part_max, part_sum,
+    hipLaunchKernelGGL(head_rowreduce_kernel, dim3((n + 15) / 16), dim3(256), 0, stream, part_max, part_sum,
                        frhip_head_groups(classes), n, rowmax, rowsum);
     return check_launch("frhip_head_fwd/rowreduce");
 }

@@ -47,6 +47,7 @@ class Model(nn.Module):
         self.epoch = 0
         self.lr = conf.lr
         self.sync_loss = True          # False: training_step returns the device tensor (no D2H sync per step)
+        self._graph = None             # set by capture_training_step()
         if "ResNet" in conf.network:
             self.encoder = importlib.import_module("nets.resnet").Encoder(conf=conf)
         else:
@@ -74,9 +75,8 @@ class Model(nn.Module):
     def forward(self, x):
         return self.encoder(x)
 
-    def training_step(self, batch):
-        img, id_ = batch
-        img, id_ = img.to(self.conf.local_rank), id_.to(self.conf.local_rank)
+    def _step(self, img, id_):
+        """the reference's step body (model/FR_PartialFC.py:167-188, non-GradScaler branch)"""
         self.opt.zero_grad()
         self.encoder.train()
         feat = normalize(self.forward(img))
@@ -85,9 +85,44 @@ class Model(nn.Module):
         loss.backward()
         torch.nn.utils.clip_grad_norm_(self.encoder.parameters(), 5)
         self.opt.step()
+        return loss.detach()
+
+    def training_step(self, batch):
+        img, id_ = batch
+        img, id_ = img.to(self.conf.local_rank), id_.to(self.conf.local_rank)
+        if self._graph is not None:
+            self._g_img.copy_(img, non_blocking=True)
+            self._g_id.copy_(id_.view(self._g_id.shape), non_blocking=True)
+            self._graph.replay()
+            loss = self._g_loss
+        else:
+            loss = self._step(img, id_)
         if self.sync_loss:
             return {"loss": loss.cpu().detach().numpy()}
-        return {"loss": loss.detach()}
+        return {"loss": loss}
+
+    def capture_training_step(self, batch, warmup=3):
+        """Record one whole optimisation step (some 1.1 K kernel launches) into a HIP graph and replay it from then
+        on: the step becomes ONE host call, so the MI355X is never waiting for Python.  Valid while the batch shape
+        stays fixed and the head does no host-side sampling (sample_rate == 1; PartialFC's sampled variant draws
+        from the CPU generator every step, nets/PartialFC.py:110, which a graph cannot replay)."""
+        if getattr(self.conf, "sample_rate", 1.0) < 1 or getattr(self.conf, "world_size", 1) > 1:
+            raise RuntimeError("graph capture needs sample_rate == 1 and world_size == 1")
+        img, id_ = batch
+        self._g_img = img.to(self.conf.local_rank).clone()
+        self._g_id = id_.to(self.conf.local_rank).clone()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                self._step(self._g_img, self._g_id.clone())
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        self.opt.zero_grad(set_to_none=True)
+        with torch.cuda.graph(graph):
+            self._g_loss = self._step(self._g_img, self._g_id.clone())
+        self._graph = graph
 
     def training_epoch_end(self, outputs, t=None):
         self.sch.step() if self.sch is not None else None

@@ -258,8 +258,9 @@ class _PartialFCBase(torch.nn.Module):
             embeddings, labels = local_embeddings, local_labels.clone()
         labels = labels.view(-1, 1)
         index_positive = (self.class_start <= labels) & (labels < self.class_start + self.num_local)
-        labels[~index_positive] = -1
-        labels[index_positive] -= self.class_start
+        # shard-relative label, -1 when another rank owns the class (reference :188-193); written with where()
+        # so no boolean-mask indexing (= no host sync; the step stays capturable in a HIP graph)
+        labels = torch.where(index_positive, labels - self.class_start, torch.full_like(labels, -1))
         if self.sample_rate < 1:
             self.sample(labels, index_positive, optimizer)
         return _MarginSoftmaxFn.apply(embeddings, self.weight_activated, labels.view(-1).to(torch.int32).contiguous(),
