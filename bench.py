@@ -88,14 +88,26 @@ class ConvMeter:
         return len(self.calls), ms, fl
 
 
-def cpu_baseline(classes, batch=16, steps=4):
-    """Oracle (CPU restatement, fp32, all host cores) on a bounded sample of the same workload."""
-    from oracle import recipe, resnet_ref, train_ref
+def host_cores():
+    """cores this process may really use: affinity mask capped by the cgroup CPU quota (the GPU box shows 256
+    logical CPUs but grants a 16-CPU share; oversubscribing torch's pool makes the CPU leg crawl)."""
     try:
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count() or 1
-    cores = max(1, min(cores, 32))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            cores = min(cores, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, cores)
+
+
+def cpu_baseline(classes, batch=16, steps=12):
+    """Oracle (CPU restatement, fp32, all host cores) on a bounded sample of the same workload."""
+    from oracle import recipe, resnet_ref, train_ref
+    cores = host_cores()
     torch.set_num_threads(cores)
     log("cpu_baseline: %d threads" % cores)
     blocks = resnet_ref.BLOCKS["ResNet50"]

@@ -25,9 +25,9 @@ class CosineAnnealingWarmupRestarts:
         self.warmup_steps, self.gamma = warmup_steps, gamma
         self.last_epoch = last_epoch
         self.cycle, self.step_in_cycle, self.cur_cycle_steps = 0, last_epoch, first_cycle_steps
-        for group in optimizer.param_groups:          # the reference starts every group at min_lr
-            group["lr"] = min_lr
-        self.step()                                   # torch's _LRScheduler.__init__ performs one step()
+        self.step()                                   # torch's _LRScheduler.__init__ performs one step() ...
+        for group in optimizer.param_groups:          # ... and the reference then resets every group to min_lr
+            group["lr"] = min_lr                      # (init_lr(), :42-46): epoch 0 always trains at min_lr
 
     def lr_at(self, epoch):
         cyc, pos, length = _cycle_position(epoch, self.first_cycle_steps, self.warmup_steps, self.cycle_mult)

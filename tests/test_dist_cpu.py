@@ -1,0 +1,92 @@
+"""world_size-2 (and 8) runs of the drop-in PartialFC host logic on gloo/CPU, real processes, against the
+fixtures produced by the real reference under the same world sizes.  The floating-point kernels are replaced by
+an oracle-backed double (tests/head_double.py); everything else -- collectives, sharding, sampling, optimizer
+patching -- is the product code."""
+import os
+import sys
+import tempfile
+import types
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, ws, path, name, ret):
+    for p in (ROOT, os.path.join(ROOT, "face-recognition-pytorch_amd"), os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from head_double import OracleHeadKernels
+    from oracle import recipe
+    import nets.PartialFC as P
+    torch.set_num_threads(1)
+    g = dict(np.load(os.path.join(ROOT, "tests", "golden", name + ".npz")))
+    dist.init_process_group("gloo", init_method="file://" + path, rank=rank, world_size=ws)
+    C, B, D, rate = int(g["C"]), int(g["B"]), int(g["D"]), float(g["rate"])
+    conf = types.SimpleNamespace(emd_size=D, sample_rate=rate, mixed_precision=False, loss_s=float(g["s"]),
+                                 loss_m=float(g["m"]))
+    pfc = P.PartialFC(conf, C, kernels=OracleHeadKernels())
+    W = recipe.normal(500 + rank, (pfc.num_local, D), 0.05)
+    with torch.no_grad():
+        (pfc.weight if rate < 1 else pfc.weight_activated.data).copy_(W)
+    dummy = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.SGD([{"params": [dummy]}, {"params": pfc.parameters()}], lr=0.1, momentum=0.9)
+    emb = recipe.normal(100 + rank, (B, D)).requires_grad_(True)
+    lab = recipe.labels(200 + rank, B, C)
+    if int(g["dup"]):
+        lab[0] = 3
+        lab[1] = 3
+    torch.manual_seed(1000 + rank)
+    loss = pfc(emb, lab.clone(), opt)
+    loss.backward()
+    idx = pfc.weight_index if rate < 1 else torch.arange(pfc.num_local)
+    ok_opt = opt.param_groups[-1]["params"][0] is pfc.weight_activated
+    if rate < 1:
+        ok_opt = ok_opt and opt.state[pfc.weight_activated]["momentum_buffer"] is pfc.weight_activated_mom
+    ret[rank] = dict(loss=float(loss), d_emb=emb.grad.numpy(), d_w=pfc.weight_activated.grad.numpy(),
+                     index=idx.numpy(), class_start=pfc.class_start, num_local=pfc.num_local,
+                     num_sample=pfc.num_sample, ok_opt=bool(ok_opt))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name", ["head_ws2_rate10", "head_ws2_rate03", "head_ws8_rate01"])
+def test_partial_fc_host_logic_multi_rank(golden, name):
+    g = golden(name)
+    ws = int(g["ws"])
+    with tempfile.TemporaryDirectory() as td:
+        mgr = mp.Manager()
+        ret = mgr.dict()
+        mp.spawn(_worker, args=(ws, os.path.join(td, "pg"), name, ret), nprocs=ws, join=True)
+        for r in range(ws):
+            out = ret[r]
+            assert out["class_start"] == int(g["r%d_class_start" % r])
+            assert out["num_local"] == int(g["r%d_num_local" % r])
+            assert out["num_sample"] == int(g["r%d_num_sample" % r])
+            assert out["ok_opt"]
+            np.testing.assert_allclose(out["loss"], g["r%d_loss" % r], rtol=2e-6)
+            assert np.array_equal(out["index"], g["r%d_index" % r])                 # bit-exact sampled rows
+            np.testing.assert_allclose(out["d_emb"], g["r%d_d_emb" % r], rtol=2e-4, atol=2e-7)
+            np.testing.assert_allclose(out["d_w"], g["r%d_d_w_act" % r], rtol=2e-4, atol=2e-7)
+
+
+def test_scheduler_restatement_matches_reference(golden):
+    """utils.scheduler.CosineAnnealingWarmupRestarts against per-epoch lrs logged from the reference class."""
+    from utils.scheduler import CosineAnnealingWarmupRestarts
+    g = golden("scheduler_lrs")
+    cases = {"c10_w2": dict(first_cycle_steps=10, warmup_steps=2, min_lr=0.001, max_lr=0.1),
+             "c15_w0": dict(first_cycle_steps=15, warmup_steps=0, min_lr=1e-5, max_lr=0.05),
+             "c6_w1_m2_g05": dict(first_cycle_steps=6, warmup_steps=1, min_lr=0.001, max_lr=0.1, cycle_mult=2.0,
+                                  gamma=0.5)}
+    for tag, kw in cases.items():
+        p = torch.nn.Parameter(torch.zeros(1))
+        opt = torch.optim.SGD([p], lr=0.1)
+        sch = CosineAnnealingWarmupRestarts(opt, **kw)
+        got = []
+        for _ in range(40):
+            got.append(opt.param_groups[0]["lr"])
+            sch.step()
+        np.testing.assert_allclose(got, g[tag], rtol=1e-9, atol=1e-12, err_msg=tag)

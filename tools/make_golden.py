@@ -259,7 +259,28 @@ def gen_train_steps():
             dist.destroy_process_group()
 
 
+# ----------------------------------------------------------------------------- lr schedule
+def gen_scheduler():
+    _ref()
+    import utils.scheduler as S
+    p = torch.nn.Parameter(torch.zeros(1))
+    out = {}
+    for tag, kw in {"c10_w2": dict(first_cycle_steps=10, warmup_steps=2, min_lr=0.001, max_lr=0.1),
+                    "c15_w0": dict(first_cycle_steps=15, warmup_steps=0, min_lr=1e-5, max_lr=0.05),
+                    "c6_w1_m2_g05": dict(first_cycle_steps=6, warmup_steps=1, min_lr=0.001, max_lr=0.1,
+                                         cycle_mult=2.0, gamma=0.5)}.items():
+        opt = torch.optim.SGD([p], lr=0.1)
+        sch = S.CosineAnnealingWarmupRestarts(opt, **kw)
+        lrs = []
+        for _ in range(40):
+            lrs.append(opt.param_groups[0]["lr"])
+            sch.step()
+        out[tag] = np.asarray(lrs, dtype=np.float64)
+    save("scheduler_lrs", **out)
+
+
 GENS = {
+    "scheduler": gen_scheduler,
     "arcface": gen_arcface_edge,
     "distce": gen_distce,
     "head_ws1_rate10": lambda: gen_head(1, 1.0),
