@@ -144,6 +144,8 @@ def main():
     ap.add_argument("--classes", type=int, default=NUM_CLASSES)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of one HIP graph per step")
+    ap.add_argument("--dist-path", action="store_true",
+                    help="rehearse the N>1 code path (RCCL group, DDP wrap, PartialFC rate 0.1) in a 1-rank group")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -151,7 +153,12 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
     torch.cuda.set_device(local)
-    if world > 1:
+    if world > 1 or args.dist_path:
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     else:
         dist.init_process_group("gloo", init_method="file://" + os.path.join(tempfile.mkdtemp(), "pg"),
@@ -167,6 +174,8 @@ def main():
 
     log("library built/loaded")
     conf = make_conf(args, local, world)
+    if args.dist_path:
+        conf.sample_rate, conf.force_ddp = 0.1, True
     torch.manual_seed(1234 + rank)
     model = Model(conf, None, "train")
     model.sync_loss = False
@@ -181,7 +190,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    use_graph = world == 1 and not args.no_graph
+    use_graph = world == 1 and not args.no_graph and not args.dist_path
     meter.collect = True
     model.training_step((img, ids.clone()))          # eager; also records the conv launch list for the probe
     meter.collect = False

@@ -60,7 +60,7 @@ class Model(nn.Module):
             pre = torch.load(ckpt, map_location="cpu")["model_state_dict"]
             self.encoder.load_state_dict({k[7:]: v for k, v in pre.items()}, strict=True)   # strip 'module.'
         if stage == "train":
-            if getattr(conf, "world_size", 1) > 1:
+            if getattr(conf, "world_size", 1) > 1 or getattr(conf, "force_ddp", False):
                 self.encoder = DDP(self.encoder, broadcast_buffers=False, device_ids=[conf.local_rank])
             head_mod = importlib.import_module("nets.%s" % getattr(conf, "loss", "PartialFC"))
             if conf.optimizer == "SGD":

@@ -29,6 +29,13 @@ from torch import distributed
 from .ArcFace import ArcFace
 
 
+import os
+
+# test hook: take the multi-rank branch (all-gather, all-reduces, reduce-scatter) even in a 1-rank group, so the
+# RCCL call sequence can be exercised on a single-GPU box
+_FORCE_COLLECTIVES = os.environ.get("FRHIP_FORCE_COLLECTIVES", "0") == "1"
+
+
 # --------------------------------------------------------------------------------------------- kernels
 class HipHeadKernels:
     """The floating-point steps of the head on the MI355X (through the C ABI)."""
@@ -248,7 +255,7 @@ class _PartialFCBase(torch.nn.Module):
         assert self.last_batch_size == batch_size, (
             "last batch size do not equal current batch size: {} vs {}".format(self.last_batch_size, batch_size))
         dev = local_embeddings.device
-        if self.world_size > 1:
+        if self.world_size > 1 or _FORCE_COLLECTIVES:
             gathered = [torch.zeros((batch_size, self.embedding_size), device=dev) for _ in range(self.world_size)]
             glabels = [torch.zeros(batch_size, dtype=torch.long, device=dev) for _ in range(self.world_size)]
             embeddings = torch.cat(AllGather(local_embeddings, *gathered))
@@ -265,7 +272,7 @@ class _PartialFCBase(torch.nn.Module):
             self.sample(labels, index_positive, optimizer)
         return _MarginSoftmaxFn.apply(embeddings, self.weight_activated, labels.view(-1).to(torch.int32).contiguous(),
                                       self.kernels, float(self.margin_softmax.scale), float(self.margin_softmax.margin),
-                                      self.world_size)
+                                      2 if (_FORCE_COLLECTIVES and self.world_size == 1) else self.world_size)
 
     def state_dict(self, destination=None, prefix="", keep_vars=False):
         if destination is None:
