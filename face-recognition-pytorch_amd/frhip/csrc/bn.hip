@@ -9,7 +9,7 @@
 namespace frhip {
 
 constexpr int EW_THREADS = 256;
-constexpr int RED_GROUPS = 64;      // second-level partial count
+constexpr int RED_GROUPS = 16;      // second-level partial count
 
 template <typename T> struct EW {
     static constexpr int EPV = 16 / (int)sizeof(T);
@@ -64,25 +64,43 @@ __global__ __launch_bounds__(EW_THREADS) void colreduce_kernel(const T* __restri
     }
 }
 
-// partial[nparts][2][C] -> out[RED_GROUPS][2][C]
-__global__ void reduce_partials_kernel(const float* __restrict__ in, float* __restrict__ out, int nparts, int C) {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;     // over 2*C
-    if (t >= 2 * C) return;
+// partial[nparts][2][C] -> out[RED_GROUPS][2][C]   (block = 64 columns x 4 partial-lanes, 4 independent loads in flight)
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ in, float* __restrict__ out, int nparts, int C) {
+    __shared__ float red[4][64];
+    const int tl = threadIdx.x & 63, pl = threadIdx.x >> 6;
+    const int t = blockIdx.x * 64 + tl;                        // over 2*C
     float acc = 0.f;
-    for (int p = blockIdx.y; p < nparts; p += gridDim.y) acc += in[(size_t)p * 2 * C + t];
-    out[(size_t)blockIdx.y * 2 * C + t] = acc;
+    if (t < 2 * C)
+        for (int p = blockIdx.y * 4 + pl; p < nparts; p += gridDim.y * 4) acc += in[(size_t)p * 2 * C + t];
+    red[pl][tl] = acc;
+    __syncthreads();
+    if (pl == 0 && t < 2 * C) out[(size_t)blockIdx.y * 2 * C + t] = red[0][tl] + red[1][tl] + red[2][tl] + red[3][tl];
+}
+
+// sum of partial[p][st][c] over p, by 4 lanes per channel (block = 64 channels x 4 lanes); result valid on lane 0
+__device__ __forceinline__ void sum_parts_4(const float* __restrict__ parts, int nparts, int C, int c, int pl,
+                                            float (*red)[2][64], float& s1, float& s2) {
+    float a1 = 0.f, a2 = 0.f;
+    if (c < C)
+        for (int p = pl; p < nparts; p += 4) { a1 += parts[(size_t)p * 2 * C + c]; a2 += parts[(size_t)p * 2 * C + C + c]; }
+    red[pl][0][threadIdx.x & 63] = a1; red[pl][1][threadIdx.x & 63] = a2;
+    __syncthreads();
+    const int cl = threadIdx.x & 63;
+    s1 = red[0][0][cl] + red[1][0][cl] + red[2][0][cl] + red[3][0][cl];
+    s2 = red[0][1][cl] + red[1][1][cl] + red[2][1][cl] + red[3][1][cl];
 }
 
 // Finalise forward batch statistics.
-__global__ void bn_finalize_kernel(const float* __restrict__ parts, int nparts, int C, float count,
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ parts, int nparts, int C, float count,
                                    const float* __restrict__ gamma, const float* __restrict__ beta,
                                    float* __restrict__ running_mean, float* __restrict__ running_var,
                                    float momentum, float eps, float* __restrict__ mean_out,
                                    float* __restrict__ invstd_out, float* __restrict__ scale, float* __restrict__ shift) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    float s1 = 0.f, s2 = 0.f;
-    for (int p = 0; p < nparts; ++p) { s1 += parts[(size_t)p * 2 * C + c]; s2 += parts[(size_t)p * 2 * C + C + c]; }
+    __shared__ float red[4][2][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), pl = threadIdx.x >> 6;
+    float s1, s2;
+    sum_parts_4(parts, nparts, C, c, pl, red, s1, s2);
+    if (pl != 0 || c >= C) return;
     const float mu = s1 / count;
     float var = s2 / count - mu * mu;
     var = var < 0.f ? 0.f : var;
@@ -108,15 +126,16 @@ __global__ void bn_eval_kernel(int C, const float* __restrict__ gamma, const flo
 }
 
 // Finalise backward sums: dgamma, dbeta and the per-channel affine of  dy = ca*d_eff + cb*y + cc.
-__global__ void bn_bwd_finalize_kernel(const float* __restrict__ parts, int nparts, int C, float count,
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ parts, int nparts, int C, float count,
                                        const float* __restrict__ gamma, const float* __restrict__ mean,
                                        const float* __restrict__ invstd, float* __restrict__ dgamma,
                                        float* __restrict__ dbeta, float* __restrict__ ca, float* __restrict__ cb,
                                        float* __restrict__ cc) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    float s1 = 0.f, s2 = 0.f;
-    for (int p = 0; p < nparts; ++p) { s1 += parts[(size_t)p * 2 * C + c]; s2 += parts[(size_t)p * 2 * C + C + c]; }
+    __shared__ float red[4][2][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), pl = threadIdx.x >> 6;
+    float s1, s2;
+    sum_parts_4(parts, nparts, C, c, pl, red, s1, s2);
+    if (pl != 0 || c >= C) return;
     dgamma[c] += s2; dbeta[c] += s1;                 // accumulate into (caller-zeroed) .grad
     const float gi = gamma[c] * invstd[c], m2 = s2 / count, m1 = s1 / count;
     ca[c] = gi; cb[c] = -gi * invstd[c] * m2; cc[c] = gi * (mean[c] * invstd[c] * m2 - m1);
@@ -283,7 +302,7 @@ extern "C" int frhip_bn_bwd_reduce(int dtype, const void* dout, const void* y, c
 
 static const float* fold_partials(const float* partial, int& nparts, int c, float* scratch, hipStream_t stream) {
     if (nparts <= RED_GROUPS) return partial;
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((2 * c + 255) / 256, RED_GROUPS), dim3(256), 0, stream,
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((2 * c + 63) / 64, RED_GROUPS), dim3(256), 0, stream,
                        partial, scratch, nparts, c);
     nparts = RED_GROUPS;
     return scratch;
@@ -295,7 +314,7 @@ extern "C" int frhip_bn_finalize(const float* partial, int nparts, float* scratc
                                  hipStream_t stream) {
     // scratch: RED_GROUPS*2*c floats
     const float* p = fold_partials(partial, nparts, c, scratch, stream);
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((c + 63) / 64), dim3(64), 0, stream, p, nparts, c, count, gamma, beta,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((c + 63) / 64), dim3(256), 0, stream, p, nparts, c, count, gamma, beta,
                        running_mean, running_var, momentum, eps, mean, invstd, scale, shift);
     return check_launch("frhip_bn_finalize");
 }
@@ -311,7 +330,7 @@ extern "C" int frhip_bn_bwd_finalize(const float* partial, int nparts, float* sc
                                      const float* gamma, const float* mean, const float* invstd, float* dgamma,
                                      float* dbeta, float* ca, float* cb, float* cc, hipStream_t stream) {
     const float* p = fold_partials(partial, nparts, c, scratch, stream);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((c + 63) / 64), dim3(64), 0, stream, p, nparts, c, count, gamma,
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((c + 63) / 64), dim3(256), 0, stream, p, nparts, c, count, gamma,
                        mean, invstd, dgamma, dbeta, ca, cb, cc);
     return check_launch("frhip_bn_bwd_finalize");
 }
