@@ -59,7 +59,7 @@ __global__ __launch_bounds__(256) void l2norm_bwd_kernel(const float* __restrict
 // FWD = true : partial row max / sum-exp per 64-class column group, target logit.
 // FWD = false: dT tile (compute dtype) from the recomputed cosines and the global row max / sum.
 template <typename T, bool FWD>
-__global__ __launch_bounds__(NT_THREADS, 2) void head_kernel(NtGeom g, const void* __restrict__ ehat,
+__global__ __launch_bounds__(256, 2) void head_kernel(NtGeom g, const void* __restrict__ ehat,
                                                              const void* __restrict__ what, const int* __restrict__ labels,
                                                              MarginConst mc, float* __restrict__ part_max,
                                                              float* __restrict__ part_sum, float* __restrict__ ztarget,
@@ -221,7 +221,7 @@ static int head_launch(const NtGeom& g, const void* ehat, const void* what, cons
         }
         attr_done = true;
     }
-    hipLaunchKernelGGL(kern, dim3(mtiles * ntiles), dim3(NT_THREADS), lds, stream, g, ehat, what, labels, mc, pmax, psum,
+    hipLaunchKernelGGL(kern, dim3(mtiles * ntiles), dim3(256), lds, stream, g, ehat, what, labels, mc, pmax, psum,
                        zt, rmax, rsum, gscale, upstream, dt, ldt, mtiles, ntiles);
     return check_launch("head");
 }

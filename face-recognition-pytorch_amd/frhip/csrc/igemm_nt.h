@@ -29,17 +29,20 @@ struct NtGeom {
 };
 
 constexpr int NT_ROWB = 128;                 // bytes per LDS row = one K step
-constexpr int NT_THREADS = 256;
 
-template <typename T, int WM, int WN>
+// WM x WN waves; each wave owns (MT*16) pixel rows x 64 channels (4 MFMA tiles wide).
+template <typename T, int WM, int WN, int MT = 4>
 struct NtTile {
-    static constexpr int BM = WM * 64, BN = WN * 64;
-    static constexpr int BKE = NT_ROWB / (int)sizeof(T);       // K elements per step
+    static constexpr int WAVES = WM * WN, THREADS = 64 * WAVES;
+    static constexpr int WROWS = MT * 16;                         // pixel rows per wave
+    static constexpr int BM = WM * WROWS, BN = WN * 64;
+    static constexpr int BKE = NT_ROWB / (int)sizeof(T);          // K elements per step
     static constexpr int STAGE_BYTES = (BM + BN) * NT_ROWB;
-    static constexpr int A_PIECES = BM / 32, B_PIECES = BN / 32;   // 1-KiB DMA pieces per thread... per wave: /4 waves *8 rows
+    static constexpr int A_PIECES = BM / 8 / WAVES, B_PIECES = BN / 8 / WAVES;   // 1-KiB (8-row) DMA pieces per wave
+    static_assert(A_PIECES * 8 * WAVES == BM && B_PIECES * 8 * WAVES == BN, "tile rows must split evenly over the waves");
     template <typename TS> static constexpr int stage_pitch() { return 64 * (int)sizeof(TS) + 16; }
     template <typename TS> static constexpr int lds_bytes() {
-        return (2 * STAGE_BYTES > 4 * 64 * stage_pitch<TS>()) ? 2 * STAGE_BYTES : 4 * 64 * stage_pitch<TS>();
+        return (2 * STAGE_BYTES > WAVES * WROWS * stage_pitch<TS>()) ? 2 * STAGE_BYTES : WAVES * WROWS * stage_pitch<TS>();
     }
 };
 
@@ -50,14 +53,14 @@ struct RowSet {
     int hb[NPIECE], wb[NPIECE];
 };
 
-template <typename T, int WM, int WN>
+template <typename T, int WM, int WN, int MT = 4>
 struct NtMainloop {
-    typedef NtTile<T, WM, WN> Tile;
+    typedef NtTile<T, WM, WN, MT> Tile;
     typedef typename Mma<T>::Frag Frag;
     static constexpr int BM = Tile::BM, BN = Tile::BN, BKE = Tile::BKE;
 
     // acc[nt][mt]: D rows = channels (nt*16 + 4*(lane>>4) + reg), D col = pixel (mt*16 + (lane&15))
-    f32x4_t acc[4][4];
+    f32x4_t acc[4][MT];
 
     __device__ __forceinline__ void run(const NtGeom& g, const void* __restrict__ a_ptr,
                                         const void* __restrict__ b_ptr, char* smem,
@@ -68,7 +71,7 @@ struct NtMainloop {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < MT; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
         if (ks_begin >= ks_end) return;
 
         const __amdgpu_buffer_rsrc_t ra = make_rsrc(a_ptr, g.a_bytes);
@@ -140,7 +143,7 @@ struct NtMainloop {
 
         // fragment read addresses (bytes inside a stage): row = base + i, chunk (g + 4s) ^ (row & 7)
         const int fi = lane & 15, fg = lane >> 4;
-        const int xoff = ((wm * 64 + fi) * NT_ROWB);                 // pixel rows (MFMA "B" operand)
+        const int xoff = ((wm * Tile::WROWS + fi) * NT_ROWB);        // pixel rows (MFMA "B" operand)
         const int woff = BM * NT_ROWB + ((wn * 64 + fi) * NT_ROWB);  // weight rows (MFMA "A" operand)
         const int sw = fi & 7;   // (row & 7) == (fi & 7) because tile bases are multiples of 16
 
@@ -149,16 +152,15 @@ struct NtMainloop {
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 const int ch = ((fg + 4 * s) ^ sw) * 16;
-                Frag xf[4], wf[4];
+                Frag xf[MT], wf[4];
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    xf[t] = *reinterpret_cast<const Frag*>(base + xoff + t * 16 * NT_ROWB + ch);
-                    wf[t] = *reinterpret_cast<const Frag*>(base + woff + t * 16 * NT_ROWB + ch);
-                }
+                for (int t = 0; t < 4; ++t) wf[t] = *reinterpret_cast<const Frag*>(base + woff + t * 16 * NT_ROWB + ch);
 #pragma unroll
-                for (int nt = 0; nt < 4; ++nt)
+                for (int t = 0; t < MT; ++t) xf[t] = *reinterpret_cast<const Frag*>(base + xoff + t * 16 * NT_ROWB + ch);
 #pragma unroll
-                    for (int mt = 0; mt < 4; ++mt) Mma<T>::run(wf[nt], xf[mt], acc[nt][mt]);
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) Mma<T>::run(wf[nt], xf[mt], acc[nt][mt]);
             }
         };
 
@@ -176,18 +178,18 @@ struct NtMainloop {
         compute(cur);
     }
 
-    // Write this wave's 64x64 tile to its private LDS staging area as TS (row = pixel, 64 channels).
+    // Write this wave's (MT*16)x64 tile to its private LDS staging area as TS (row = pixel, 64 channels).
     template <typename TS>
     __device__ __forceinline__ char* stage_out(char* smem) {
         constexpr int P = Tile::template stage_pitch<TS>();
         const int lane = lane_id();
         const int fi = lane & 15, fg = lane >> 4;
-        char* mine = smem + wave_id() * 64 * P;
+        char* mine = smem + wave_id() * Tile::WROWS * P;
         __syncthreads();        // every wave is done reading the operand stages
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) {
+            for (int mt = 0; mt < MT; ++mt) {
                 char* p = mine + (mt * 16 + fi) * P + (nt * 16 + 4 * fg) * (int)sizeof(TS);
                 if constexpr (sizeof(TS) == 4) {
                     *reinterpret_cast<f32x4_t*>(p) = acc[nt][mt];

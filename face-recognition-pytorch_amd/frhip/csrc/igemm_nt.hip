@@ -8,24 +8,25 @@ namespace frhip {
 
 enum { EPI_STORE = 0, EPI_ATOMIC = 1 };
 
-template <typename T, int WM, int WN, int EPI>
-__global__ __launch_bounds__(NT_THREADS, 2) void nt_kernel(NtGeom g, const void* __restrict__ a,
+template <typename T, int WM, int WN, int MT, int EPI>
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void nt_kernel(NtGeom g, const void* __restrict__ a,
                                                            const void* __restrict__ b, void* __restrict__ out,
                                                            const void* __restrict__ res, float* __restrict__ stats,
                                                            int mtiles, int ntiles) {
-    typedef NtTile<T, WM, WN> Tile;
+    typedef NtTile<T, WM, WN, MT> Tile;
+    constexpr int WROWS = Tile::WROWS, THREADS = Tile::THREADS;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const uint32_t lin = xcd_remap(blockIdx.x, gridDim.x);
     const int ntile = (int)(lin % (uint32_t)ntiles), mtile = (int)(lin / (uint32_t)ntiles);
     const int ks_begin = blockIdx.y * g.ksteps_per_split;
     const int ks_end = min(g.ksteps, ks_begin + g.ksteps_per_split);
 
-    NtMainloop<T, WM, WN> ml;
+    NtMainloop<T, WM, WN, MT> ml;
     ml.run(g, a, b, smem, mtile, ntile, ks_begin, ks_end);
 
     const int lane = lane_id(), wave = wave_id();
     const int wm = wave / WN, wn = wave % WN;
-    const int m0 = mtile * Tile::BM + wm * 64, n0 = ntile * Tile::BN + wn * 64;
+    const int m0 = mtile * Tile::BM + wm * WROWS, n0 = ntile * Tile::BN + wn * 64;
 
     if constexpr (EPI == EPI_STORE) {
         constexpr int P = Tile::template stage_pitch<T>();
@@ -41,7 +42,7 @@ __global__ __launch_bounds__(NT_THREADS, 2) void nt_kernel(NtGeom g, const void*
         T* o = reinterpret_cast<T*>(out);
         const T* r = reinterpret_cast<const T*>(res);
 #pragma unroll 4
-        for (int it = 0; it < 64 / RPI; ++it) {
+        for (int it = 0; it < WROWS / RPI; ++it) {
             const int row = it * RPI + rsub;
             const int m = m0 + row;
             Vec16<T> v = *reinterpret_cast<const Vec16<T>*>(mine + row * P + chunk * 16);
@@ -78,7 +79,7 @@ __global__ __launch_bounds__(NT_THREADS, 2) void nt_kernel(NtGeom g, const void*
             }
             __syncthreads();
             // one thread per (wn, stat, channel): sum over the WM waves that share wn
-            for (int t = threadIdx.x; t < WN * 2 * 64; t += NT_THREADS) {
+            for (int t = threadIdx.x; t < WN * 2 * 64; t += THREADS) {
                 const int c = t & 63, st = (t >> 6) & 1, w_n = t >> 7;
                 float acc = 0.f;
 #pragma unroll
@@ -92,7 +93,7 @@ __global__ __launch_bounds__(NT_THREADS, 2) void nt_kernel(NtGeom g, const void*
         const char* mine = ml.template stage_out<float>(smem);
         float* o = reinterpret_cast<float*>(out);
         const int n = n0 + lane;
-        for (int row = 0; row < 64; ++row) {
+        for (int row = 0; row < WROWS; ++row) {
             const int m = m0 + row;
             if (m < g.M && n < g.Nout)
                 atomicAdd(o + (size_t)m * g.Nout + n, *reinterpret_cast<const float*>(mine + row * P + lane * 4));
@@ -100,13 +101,13 @@ __global__ __launch_bounds__(NT_THREADS, 2) void nt_kernel(NtGeom g, const void*
     }
 }
 
-template <typename T, int WM, int WN, int EPI>
+template <typename T, int WM, int WN, int MT, int EPI>
 static int nt_launch_cfg(const NtGeom& g, const void* a, const void* b, void* out, const void* res,
                          float* stats, int splits, hipStream_t stream) {
-    typedef NtTile<T, WM, WN> Tile;
+    typedef NtTile<T, WM, WN, MT> Tile;
     const int mtiles = (g.M + Tile::BM - 1) / Tile::BM, ntiles = (g.Nout + Tile::BN - 1) / Tile::BN;
     const int lds = (EPI == EPI_STORE) ? Tile::template lds_bytes<T>() : Tile::template lds_bytes<float>();
-    auto kern = nt_kernel<T, WM, WN, EPI>;
+    auto kern = nt_kernel<T, WM, WN, MT, EPI>;
     static bool attr_done = false;
     if (!attr_done) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
@@ -116,23 +117,44 @@ static int nt_launch_cfg(const NtGeom& g, const void* a, const void* b, void* ou
         attr_done = true;
     }
     dim3 grid(mtiles * ntiles, splits);
-    hipLaunchKernelGGL(kern, grid, dim3(NT_THREADS), lds, stream, g, a, b, out, res, stats, mtiles, ntiles);
+    hipLaunchKernelGGL(kern, grid, dim3(Tile::THREADS), lds, stream, g, a, b, out, res, stats, mtiles, ntiles);
     return check_launch("igemm_nt");
+}
+
+// Tile choice.  0 = automatic; tests / micro-benchmarks can force one with frhip_set_nt_tile().
+//   1: 128x128 (4 waves 2x2)   2: 256x64 (4 waves 4x1)   3: 256x128 (8 waves 4x2)   4: 256x256 (8 waves 2x4, bf16 only)
+static int g_nt_tile = 0;
+
+static int nt_pick_tile(int dtype, const NtGeom& g) {
+    if (g_nt_tile) return (g_nt_tile == 4 && dtype != FRHIP_DT_BF16) ? 3 : g_nt_tile;
+    if ((g.Nout % 128) != 0 && g.Nout <= 256) return 2;
+    // measured on MI355X (tools/bench_kernels.py, B=512): 256x256 beats 128x128 by 15-25 % once Cout % 256 == 0
+    if (dtype == FRHIP_DT_BF16 && (g.Nout % 256) == 0 && g.M >= 256 * 64) return 4;
+    return 1;
 }
 
 static int nt_dispatch(int dtype, const NtGeom& g, const void* a, const void* b, void* out, const void* res,
                        float* stats, int splits, bool atomic, hipStream_t stream) {
-    const bool wide = (g.Nout % 128) == 0 || g.Nout > 256;     // 128x128 tile, else 256x64
-#define NT_CASE(T)                                                                                         \
-    do {                                                                                                   \
-        if (atomic) return wide ? nt_launch_cfg<T, 2, 2, EPI_ATOMIC>(g, a, b, out, res, stats, splits, stream)  \
-                                : nt_launch_cfg<T, 4, 1, EPI_ATOMIC>(g, a, b, out, res, stats, splits, stream); \
-        return wide ? nt_launch_cfg<T, 2, 2, EPI_STORE>(g, a, b, out, res, stats, splits, stream)           \
-                    : nt_launch_cfg<T, 4, 1, EPI_STORE>(g, a, b, out, res, stats, splits, stream);          \
-    } while (0)
-    if (dtype == FRHIP_DT_BF16) NT_CASE(bf16_t);
-    if (dtype == FRHIP_DT_F32) NT_CASE(float);
-#undef NT_CASE
+    const int tile = nt_pick_tile(dtype, g);
+#define NT_GO(T, WM, WN, MT)                                                                              \
+    return atomic ? nt_launch_cfg<T, WM, WN, MT, EPI_ATOMIC>(g, a, b, out, res, stats, splits, stream)     \
+                  : nt_launch_cfg<T, WM, WN, MT, EPI_STORE>(g, a, b, out, res, stats, splits, stream)
+    if (dtype == FRHIP_DT_BF16) {
+        switch (tile) {
+            case 2: NT_GO(bf16_t, 4, 1, 4);
+            case 3: NT_GO(bf16_t, 4, 2, 4);
+            case 4: if (!atomic) return nt_launch_cfg<bf16_t, 2, 4, 8, EPI_STORE>(g, a, b, out, res, stats, splits, stream);
+                    NT_GO(bf16_t, 4, 2, 4);
+            default: NT_GO(bf16_t, 2, 2, 4);
+        }
+    }
+    if (dtype == FRHIP_DT_F32) {
+        switch (tile) {
+            case 2: NT_GO(float, 4, 1, 4);
+            default: NT_GO(float, 2, 2, 4);
+        }
+    }
+#undef NT_GO
     set_error("igemm_nt: bad dtype %d", dtype);
     return FRHIP_EINVAL;
 }
@@ -163,7 +185,18 @@ static int fill_geom(NtGeom& g, int dtype, int n, int h, int w, int c, int ho, i
 
 using namespace frhip;
 
-extern "C" int frhip_nt_block_m(int nout) { return ((nout % 128) == 0 || nout > 256) ? 128 : 256; }
+extern "C" int frhip_nt_block_m(int nout) {
+    // smallest BM any tile choice uses for this width: callers size the BN-partial buffer with it
+    return ((nout % 128) == 0 || nout > 256) ? 128 : 256;
+}
+extern "C" int frhip_conv_stat_rows(int dtype, int m, int k) {
+    // rows of the stats_partial buffer frhip_conv_fwd writes for an output of m pixels x k channels
+    NtGeom g; g.M = m; g.Nout = k;
+    static const int bm_of[5] = {128, 128, 256, 256, 256};
+    const int bm = bm_of[nt_pick_tile(dtype, g)];
+    return (m + bm - 1) / bm;
+}
+extern "C" int frhip_set_nt_tile(int tile) { const int old = g_nt_tile; g_nt_tile = tile; return old; }
 
 extern "C" int frhip_conv_fwd(int dtype, const void* x, const void* w, void* y, float* stats_partial,
                               int n, int h, int wd, int c, int k, int r, int s, int stride, int pad,

@@ -45,9 +45,13 @@ int frhip_abi_version(void);
 
 /* ---- convolution = MFMA implicit GEMM.  nn.Conv2d(bias=False): nets/resnet.py:23-46, used at :89-103, :232 ---- */
 /* y[n,ho,wo,k] = conv(x[n,h,w,c], w[k,r,s,c]); stats_partial (may be NULL) receives per-row-tile
- * {sum, sum of squares} per output channel: [ceil(n*ho*wo / frhip_nt_block_m(k))][2][k] -- the BN batch statistics
+ * {sum, sum of squares} per output channel: [frhip_conv_stat_rows(dtype, n*ho*wo, k)][2][k] -- the BN batch statistics
  * (nets/resnet.py:90-91) come out of the conv epilogue instead of a second pass. */
 int frhip_nt_block_m(int k);
+/* number of partial rows frhip_conv_fwd writes into stats_partial for m = n*ho*wo output pixels and k channels */
+int frhip_conv_stat_rows(int dtype, int m, int k);
+/* test / micro-benchmark hook: force the NT tile (0 auto, 1 128x128, 2 256x64, 3 256x128, 4 256x256); returns the old value */
+int frhip_set_nt_tile(int tile);
 int frhip_conv_fwd(int dtype, const void* x, const void* w, void* y, float* stats_partial,
                    int n, int h, int wd, int c, int k, int r, int s, int stride, int pad, frhip_stream_t stream);
 /* dx[n,h,w,c] = conv_transpose(dy[n,ho,wo,k], w) (+ residual[n,h,w,c] if not NULL); wt = frhip_pack_wt(w) = [c][r][s][k].

@@ -1,0 +1,58 @@
+"""Micro-benchmark of the conv kernels on the ResNet50 body shapes (B=512) per NT tile choice.  GPU box only."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "face-recognition-pytorch_amd")]
+import torch
+from frhip import ops
+from frhip._abi import lib
+
+B = int(os.environ.get("B", "512"))
+SHAPES = [  # (h, c, k, r, stride)
+    (56, 64, 64, 3, 1), (56, 64, 128, 3, 2), (28, 128, 128, 3, 1), (28, 128, 256, 3, 2),
+    (14, 256, 256, 3, 1), (14, 256, 512, 3, 2), (7, 512, 512, 3, 1), (56, 64, 128, 1, 2),
+]
+
+
+def timeit(fn, n=10):
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n * 1e3   # us
+
+
+what = sys.argv[1] if len(sys.argv) > 1 else "fwd"
+for (h, c, k, r, stride) in SHAPES:
+    pad = (r - 1) // 2
+    x = torch.randn(B, h, h, c, device="cuda").bfloat16()
+    w = (torch.randn(k, r, r, c, device="cuda") * 0.05).bfloat16()
+    ho = (h + 2 * pad - r) // stride + 1
+    flops = 2.0 * B * ho * ho * k * r * r * c
+    line = "h=%3d c=%3d k=%3d r=%d s=%d  GF=%6.1f |" % (h, c, k, r, stride, flops / 1e9)
+    if what == "fwd":
+        ref = None
+        for tile in (1, 2, 3, 4):
+            if tile == 4 and k % 256:
+                line += "    --    |"
+                continue
+            lib().frhip_set_nt_tile(tile)
+            y, _ = ops.conv_fwd(x, w, stride, pad)
+            if ref is None:
+                ref = y.float()
+            err = (y.float() - ref).abs().max().item()
+            us = timeit(lambda: ops.conv_fwd(x, w, stride, pad))
+            line += " t%d %6.1fus %5.0fTF e=%.0e |" % (tile, us, flops / us / 1e6, err)
+        lib().frhip_set_nt_tile(0)
+    elif what == "wgrad":
+        dy = torch.randn(B, ho, ho, k, device="cuda").bfloat16()
+        dw = torch.zeros(k, r, r, c, device="cuda")
+        for splits in (0,):
+            us = timeit(lambda: ops.conv_wgrad(dy, x, dw, r, r, stride, pad, splits))
+            line += " wgrad %6.1fus %5.0fTF |" % (us, flops / us / 1e6)
+    print(line, flush=True)
