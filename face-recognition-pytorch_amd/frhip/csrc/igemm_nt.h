@@ -205,4 +205,71 @@ struct NtMainloop {
     }
 };
 
+// Shared store epilogue: the wave's (WROWS x 64) tile sits in its LDS staging area `mine` as T (row = pixel).
+// Rows are written back as whole 128/256-byte lines (+ optional residual); the same read-back accumulates the
+// per-channel sum / sum of squares of the STORED values -> BN batch-statistic partials [mtile][2][Nout].
+template <typename T, int WM, int WN, int WROWS, int THREADS, int BN>
+__device__ __forceinline__ void nt_epilogue_store(const char* mine, int P, char* smem, int M, int Nout,
+                                                  void* __restrict__ out, const void* __restrict__ res,
+                                                  float* __restrict__ stats, int mtile, int ntile, int m0, int n0) {
+    constexpr int EPV = 16 / (int)sizeof(T);          // elements per 16-byte vector
+    constexpr int LPR = 64 / EPV;                     // lanes per 64-channel row
+    constexpr int RPI = 64 / LPR;                     // rows per wave instruction
+    const int lane = lane_id(), wave = wave_id();
+    const int chunk = lane % LPR, rsub = lane / LPR;
+    const int n = n0 + chunk * EPV;
+    float s1[EPV], s2[EPV];
+#pragma unroll
+    for (int e = 0; e < EPV; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
+    T* o = reinterpret_cast<T*>(out);
+    const T* r = reinterpret_cast<const T*>(res);
+#pragma unroll 4
+    for (int it = 0; it < WROWS / RPI; ++it) {
+        const int row = it * RPI + rsub;
+        const int m = m0 + row;
+        Vec16<T> v = *reinterpret_cast<const Vec16<T>*>(mine + row * P + chunk * 16);
+        if (m < M && n < Nout) {
+            const size_t idx = (size_t)m * Nout + n;
+            if (r) {
+                const Vec16<T> rv = *reinterpret_cast<const Vec16<T>*>(r + idx);
+#pragma unroll
+                for (int e = 0; e < EPV; ++e) v.set(e, v.get(e) + rv.get(e));
+            }
+            *reinterpret_cast<Vec16<T>*>(o + idx) = v;
+        }
+#pragma unroll
+        for (int e = 0; e < EPV; ++e) { const float x = v.get(e); s1[e] += x; s2[e] += x * x; }
+    }
+    if (stats) {
+        // rows beyond M were gathered as zeros -> contribute 0.  Reduce over the lanes that share `chunk`.
+#pragma unroll
+        for (int e = 0; e < EPV; ++e) {
+#pragma unroll
+            for (int d = LPR; d < 64; d <<= 1) {
+                s1[e] += __shfl_xor(s1[e], d);
+                s2[e] += __shfl_xor(s2[e], d);
+            }
+        }
+        __syncthreads();                                // staging area is free again
+        float* red = reinterpret_cast<float*>(smem);   // [wave][2][64]
+        if (lane < LPR) {
+#pragma unroll
+            for (int e = 0; e < EPV; ++e) {
+                red[(wave * 2 + 0) * 64 + chunk * EPV + e] = s1[e];
+                red[(wave * 2 + 1) * 64 + chunk * EPV + e] = s2[e];
+            }
+        }
+        __syncthreads();
+        // one thread per (wn, stat, channel): sum over the WM waves that share wn
+        for (int t = threadIdx.x; t < WN * 2 * 64; t += THREADS) {
+            const int c = t & 63, st = (t >> 6) & 1, w_n = t >> 7;
+            float a = 0.f;
+#pragma unroll
+            for (int w_m = 0; w_m < WM; ++w_m) a += red[((w_m * WN + w_n) * 2 + st) * 64 + c];
+            const int nn = ntile * BN + w_n * 64 + c;
+            if (nn < Nout) stats[((size_t)mtile * 2 + st) * Nout + nn] = a;
+        }
+    }
+}
+
 }  // namespace frhip

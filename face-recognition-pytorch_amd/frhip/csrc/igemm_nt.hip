@@ -6,6 +6,11 @@
 
 namespace frhip {
 
+bool halo_applicable(int dtype, int h, int w, int c, int k, int r, int s, int stride, int pad);
+int halo_block_m();
+int halo_run(int dtype, const void* a, const void* b, void* out, const void* res, float* stats, int n, int h, int w,
+             int c, int k, int sign, hipStream_t stream);
+
 enum { EPI_STORE = 0, EPI_ATOMIC = 1 };
 
 template <typename T, int WM, int WN, int MT, int EPI>
@@ -29,65 +34,9 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void nt_kernel(NtGeom 
     const int m0 = mtile * Tile::BM + wm * WROWS, n0 = ntile * Tile::BN + wn * 64;
 
     if constexpr (EPI == EPI_STORE) {
-        constexpr int P = Tile::template stage_pitch<T>();
-        constexpr int EPV = 16 / (int)sizeof(T);          // elements per 16-byte vector
-        constexpr int LPR = 64 / EPV;                     // lanes per 64-channel row
-        constexpr int RPI = 64 / LPR;                     // rows per wave instruction
         const char* mine = ml.template stage_out<T>(smem);
-        const int chunk = lane % LPR, rsub = lane / LPR;
-        const int n = n0 + chunk * EPV;
-        float s1[EPV], s2[EPV];
-#pragma unroll
-        for (int e = 0; e < EPV; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
-        T* o = reinterpret_cast<T*>(out);
-        const T* r = reinterpret_cast<const T*>(res);
-#pragma unroll 4
-        for (int it = 0; it < WROWS / RPI; ++it) {
-            const int row = it * RPI + rsub;
-            const int m = m0 + row;
-            Vec16<T> v = *reinterpret_cast<const Vec16<T>*>(mine + row * P + chunk * 16);
-            if (m < g.M && n < g.Nout) {
-                const size_t idx = (size_t)m * g.Nout + n;
-                if (r) {
-                    const Vec16<T> rv = *reinterpret_cast<const Vec16<T>*>(r + idx);
-#pragma unroll
-                    for (int e = 0; e < EPV; ++e) v.set(e, v.get(e) + rv.get(e));
-                }
-                *reinterpret_cast<Vec16<T>*>(o + idx) = v;
-            }
-#pragma unroll
-            for (int e = 0; e < EPV; ++e) { const float x = v.get(e); s1[e] += x; s2[e] += x * x; }
-        }
-        if (stats) {
-            // rows beyond M were gathered as zeros -> contribute 0.  Reduce over the lanes that share `chunk`.
-#pragma unroll
-            for (int e = 0; e < EPV; ++e) {
-#pragma unroll
-                for (int d = LPR; d < 64; d <<= 1) {
-                    s1[e] += __shfl_xor(s1[e], d);
-                    s2[e] += __shfl_xor(s2[e], d);
-                }
-            }
-            __syncthreads();                                // staging area is free again
-            float* red = reinterpret_cast<float*>(smem);   // [wave][2][64]
-            if (lane < LPR) {
-#pragma unroll
-                for (int e = 0; e < EPV; ++e) {
-                    red[(wave * 2 + 0) * 64 + chunk * EPV + e] = s1[e];
-                    red[(wave * 2 + 1) * 64 + chunk * EPV + e] = s2[e];
-                }
-            }
-            __syncthreads();
-            // one thread per (wn, stat, channel): sum over the WM waves that share wn
-            for (int t = threadIdx.x; t < WN * 2 * 64; t += THREADS) {
-                const int c = t & 63, st = (t >> 6) & 1, w_n = t >> 7;
-                float acc = 0.f;
-#pragma unroll
-                for (int w_m = 0; w_m < WM; ++w_m) acc += red[((w_m * WN + w_n) * 2 + st) * 64 + c];
-                const int nn = ntile * Tile::BN + w_n * 64 + c;
-                if (nn < g.Nout) stats[((size_t)mtile * 2 + st) * g.Nout + nn] = acc;
-            }
-        }
+        nt_epilogue_store<T, WM, WN, WROWS, THREADS, Tile::BN>(mine, Tile::template stage_pitch<T>(), smem, g.M, g.Nout, out, res,
+                                                               stats, mtile, ntile, m0, n0);
     } else {
         constexpr int P = Tile::template stage_pitch<float>();
         const char* mine = ml.template stage_out<float>(smem);
@@ -189,8 +138,9 @@ extern "C" int frhip_nt_block_m(int nout) {
     // smallest BM any tile choice uses for this width: callers size the BN-partial buffer with it
     return ((nout % 128) == 0 || nout > 256) ? 128 : 256;
 }
-extern "C" int frhip_conv_stat_rows(int dtype, int m, int k) {
+extern "C" int frhip_conv_stat_rows(int dtype, int m, int k, int h, int w, int c, int r, int s, int stride, int pad) {
     // rows of the stats_partial buffer frhip_conv_fwd writes for an output of m pixels x k channels
+    if (halo_applicable(dtype, h, w, c, k, r, s, stride, pad)) return (m + halo_block_m() - 1) / halo_block_m();
     NtGeom g; g.M = m; g.Nout = k;
     static const int bm_of[5] = {128, 128, 256, 256, 256};
     const int bm = bm_of[nt_pick_tile(dtype, g)];
@@ -205,6 +155,8 @@ extern "C" int frhip_conv_fwd(int dtype, const void* x, const void* w, void* y, 
     const int ho = (h + 2 * pad - r) / stride + 1, wo = (wd + 2 * pad - s) / stride + 1;
     int rc = fill_geom(g, dtype, n, h, wd, c, ho, wo, k, r, s, stride, pad, 0, "frhip_conv_fwd");
     if (rc) return rc;
+    if (halo_applicable(dtype, h, wd, c, k, r, s, stride, pad))
+        return halo_run(dtype, x, w, y, nullptr, stats_partial, n, h, wd, c, k, +1, stream);
     return nt_dispatch(dtype, g, x, w, y, nullptr, stats_partial, 1, false, stream);
 }
 
@@ -216,6 +168,8 @@ extern "C" int frhip_conv_dgrad(int dtype, const void* dy, const void* wt, void*
     const int ho = (h + 2 * pad - r) / stride + 1, wo = (wd + 2 * pad - s) / stride + 1;
     int rc = fill_geom(g, dtype, n, ho, wo, k, h, wd, c, r, s, stride, pad, 1, "frhip_conv_dgrad");
     if (rc) return rc;
+    if (halo_applicable(dtype, h, wd, k, c, r, s, stride, pad))       // gathered tensor = dy [n,h,w,k] -> dx [n,h,w,c]
+        return halo_run(dtype, dy, wt, dx, residual, nullptr, n, h, wd, k, c, -1, stream);
     return nt_dispatch(dtype, g, dy, wt, dx, residual, nullptr, 1, false, stream);
 }
 

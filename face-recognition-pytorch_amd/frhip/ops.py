@@ -45,7 +45,7 @@ def conv_fwd(x, w, stride, pad, want_stats=True):
     y = torch.empty((n, ho, wo, k), dtype=x.dtype, device=x.device)
     part = None
     if want_stats:
-        rows = lib().frhip_conv_stat_rows(dt_of(x), n * ho * wo, k)
+        rows = lib().frhip_conv_stat_rows(dt_of(x), n * ho * wo, k, h, wd, c, r, s, stride, pad)
         part = torch.empty((rows, 2, k), dtype=torch.float32, device=x.device)
     check(lib().frhip_conv_fwd(dt_of(x), _p(x), _p(w), _p(y), _p(part), n, h, wd, c, k, r, s, stride, pad, _s()),
           "frhip_conv_fwd")

@@ -45,11 +45,13 @@ int frhip_abi_version(void);
 
 /* ---- convolution = MFMA implicit GEMM.  nn.Conv2d(bias=False): nets/resnet.py:23-46, used at :89-103, :232 ---- */
 /* y[n,ho,wo,k] = conv(x[n,h,w,c], w[k,r,s,c]); stats_partial (may be NULL) receives per-row-tile
- * {sum, sum of squares} per output channel: [frhip_conv_stat_rows(dtype, n*ho*wo, k)][2][k] -- the BN batch statistics
+ * {sum, sum of squares} per output channel: [frhip_conv_stat_rows(...)][2][k] -- the BN batch statistics
  * (nets/resnet.py:90-91) come out of the conv epilogue instead of a second pass. */
 int frhip_nt_block_m(int k);
-/* number of partial rows frhip_conv_fwd writes into stats_partial for m = n*ho*wo output pixels and k channels */
-int frhip_conv_stat_rows(int dtype, int m, int k);
+/* number of partial rows frhip_conv_fwd writes into stats_partial for this convolution (m = n*ho*wo output pixels) */
+int frhip_conv_stat_rows(int dtype, int m, int k, int h, int w, int c, int r, int s, int stride, int pad);
+/* test hook: 0 disables the LDS-halo 3x3/s1 kernel (generic NT kernel is used instead); returns the old value */
+int frhip_set_conv_halo(int enabled);
 /* test / micro-benchmark hook: force the NT tile (0 auto, 1 128x128, 2 256x64, 3 256x128, 4 256x256); returns the old value */
 int frhip_set_nt_tile(int tile);
 int frhip_conv_fwd(int dtype, const void* x, const void* w, void* y, float* stats_partial,

@@ -47,6 +47,12 @@ CONV_CASES = [
     (2, 8, 8, 64, 128, 1, 2, 0),       # downsample 1x1 s2
     (1, 5, 5, 256, 512, 3, 1, 1),
     (5, 9, 9, 64, 64, 3, 2, 1),        # odd size with stride 2
+    (2, 56, 56, 64, 64, 3, 1, 1),      # halo kernel, widest map, one 64-channel chunk
+    (3, 28, 28, 128, 128, 3, 1, 1),    # halo kernel, two chunks, tiles cross image boundaries
+    (5, 14, 14, 256, 256, 3, 1, 1),
+    (9, 7, 7, 512, 512, 3, 1, 1),      # 441 pixels: ragged last tile, 5+ images per tile
+    (3, 7, 7, 128, 64, 3, 1, 1),       # narrow output, multi-chunk
+    (2, 12, 12, 64, 128, 3, 1, 1),     # wide output, single chunk
 ]
 
 
@@ -99,6 +105,29 @@ def test_conv_wgrad(dtype, case, splits):
     got = dw.cpu().permute(0, 3, 1, 2)
     np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=2e-3 if dtype == torch.bfloat16 else 2e-4,
                                atol=1e-3 * ref.abs().max().item())
+
+
+def test_halo_kernel_equals_generic_kernel():
+    """The LDS-halo 3x3/s1 kernel and the generic tap-by-tap kernel are two schedules of the same sums."""
+    ops = _ops()
+    from frhip._abi import lib
+    for (n, h, c, k) in [(4, 56, 64, 64), (6, 28, 128, 128), (7, 14, 256, 256), (11, 7, 512, 512)]:
+        x = rnd(40, (n, h, h, c)).bfloat16().cuda()
+        w = (rnd(41, (k, 3, 3, c)) * 0.05).bfloat16().cuda()
+        res = rnd(42, (n, h, h, c)).bfloat16().cuda()
+        wt = ops.pack_wt(w.float(), torch.bfloat16)
+        dy = rnd(43, (n, h, h, k)).bfloat16().cuda()
+        outs = []
+        for halo in (1, 0):
+            old = lib().frhip_set_conv_halo(halo)
+            y, part = ops.conv_fwd(x, w, 1, 1)
+            dx = ops.conv_dgrad(dy, wt, (n, h, h, c), 3, 3, 1, 1, residual=res)
+            lib().frhip_set_conv_halo(old)
+            outs.append((y.float().cpu(), part.sum(0).cpu(), dx.float().cpu()))
+        scale = outs[1][0].abs().max().item()
+        np.testing.assert_allclose(outs[0][0].numpy(), outs[1][0].numpy(), rtol=0, atol=scale * 2 ** -7)   # one bf16 ulp of the largest value
+        np.testing.assert_allclose(outs[0][1].numpy(), outs[1][1].numpy(), rtol=2e-3, atol=0.5)
+        np.testing.assert_allclose(outs[0][2].numpy(), outs[1][2].numpy(), rtol=0, atol=outs[1][2].abs().max().item() * 2 ** -7)
 
 
 @pytest.mark.parametrize("dtype", DTYPES)

@@ -37,6 +37,7 @@ for (h, c, k, r, stride) in SHAPES:
     line = "h=%3d c=%3d k=%3d r=%d s=%d  GF=%6.1f |" % (h, c, k, r, stride, flops / 1e9)
     if what == "fwd":
         ref = None
+        lib().frhip_set_conv_halo(0)
         for tile in (1, 2, 3, 4):
             if tile == 4 and k % 256:
                 line += "    --    |"
@@ -49,6 +50,11 @@ for (h, c, k, r, stride) in SHAPES:
             us = timeit(lambda: ops.conv_fwd(x, w, stride, pad))
             line += " t%d %6.1fus %5.0fTF e=%.0e |" % (tile, us, flops / us / 1e6, err)
         lib().frhip_set_nt_tile(0)
+        lib().frhip_set_conv_halo(1)
+        y, _ = ops.conv_fwd(x, w, stride, pad)
+        err = (y.float() - ref).abs().max().item()
+        us = timeit(lambda: ops.conv_fwd(x, w, stride, pad))
+        line += " halo %6.1fus %5.0fTF e=%.0e |" % (us, flops / us / 1e6, err)
     elif what == "wgrad":
         dy = torch.randn(B, ho, ho, k, device="cuda").bfloat16()
         dw = torch.zeros(k, r, r, c, device="cuda")
