@@ -19,6 +19,7 @@ struct TnGeom {
     int M, Kc, ldp;          // GEMM-K rows, valid P columns (= output rows), P row pitch (elements)
     int ksteps, ksteps_per_split;
     FastDiv d_howo, d_wo;
+    int adv_wo, adv_ho, adv_n;   // 64 pixels = adv_n images + adv_ho rows + adv_wo columns (mixed-radix step per K step)
     uint32_t p_bytes, q_bytes;
 };
 
@@ -107,29 +108,47 @@ __global__ __launch_bounds__(TN_THREADS, 2) void tn_kernel(TnGeom g, const void*
     const int sub = lane / Tile::CHUNKS, phys = lane % Tile::CHUNKS;
     const int co0 = co_tile * Tile::BC, ci0 = ci_tile * Tile::BC;
 
+    // Row bookkeeping: the pixel (image base, ho, wo) of every row this thread stages, decoded ONCE at the first
+    // K step and then advanced by 64 pixels per step with a mixed-radix add (two compares) instead of two
+    // divisions per row per step.
+    int row_of[Tile::PIECES], pixbase[Tile::PIECES], rho[Tile::PIECES], rwo[Tile::PIECES];
+    uint32_t chunk_el[Tile::PIECES];
+    const int HWin = g.H * g.W;
+#pragma unroll
+    for (int j = 0; j < Tile::PIECES; ++j) {
+        const int piece = wave * Tile::PIECES + j;
+        const int row = piece * Tile::ROWS_PER_PIECE + sub;
+        row_of[j] = row;
+        chunk_el[j] = (uint32_t)((phys ^ tn_swz<RB>(row)) * (16 / (int)sizeof(T)));   // first channel of this lane's chunk
+        const uint32_t m = (uint32_t)(ks_begin * TN_KP + row);
+        const uint32_t n = fdiv(m, g.d_howo);
+        const uint32_t rem = m - n * (uint32_t)(g.Ho * g.Wo);
+        const uint32_t ho = fdiv(rem, g.d_wo);
+        pixbase[j] = (int)n * HWin; rho[j] = (int)ho; rwo[j] = (int)(rem - ho * (uint32_t)g.Wo);
+    }
+
     auto stage = [&](int buf, int ks) {
         char* sp = smem + buf * Tile::STAGE_BYTES;
         char* sq = sp + Tile::TILE_BYTES;
 #pragma unroll
         for (int j = 0; j < Tile::PIECES; ++j) {
             const int piece = wave * Tile::PIECES + j;
-            const int row = piece * Tile::ROWS_PER_PIECE + sub;
-            const int chunk = phys ^ tn_swz<RB>(row);
-            const int m = ks * TN_KP + row;
-            const int ce = chunk * (16 / (int)sizeof(T));      // first channel (element) of this chunk inside the tile
-            // P row: dy[m][co0 + ce ...]
+            const int m = ks * TN_KP + row_of[j];
+            const int ce = (int)chunk_el[j];
             uint32_t offp = OOB_OFFSET, offq = OOB_OFFSET;
             if (m < g.M) {
                 if (co0 + ce < g.ldp) offp = ((uint32_t)m * (uint32_t)g.ldp + (uint32_t)(co0 + ce)) * (uint32_t)sizeof(T);
-                const uint32_t n = fdiv((uint32_t)m, g.d_howo);
-                const uint32_t rem = (uint32_t)m - n * (uint32_t)(g.Ho * g.Wo);
-                const uint32_t ho = fdiv(rem, g.d_wo), wo = rem - ho * (uint32_t)g.Wo;
-                const int hi = (int)ho * g.stride - g.pad + fr, wi = (int)wo * g.stride - g.pad + fs;
+                const int hi = rho[j] * g.stride - g.pad + fr, wi = rwo[j] * g.stride - g.pad + fs;
                 if ((unsigned)hi < (unsigned)g.H && (unsigned)wi < (unsigned)g.W && ci0 + ce < g.C)
-                    offq = ((uint32_t)(((int)n * g.H + hi) * g.W + wi) * (uint32_t)g.C + (uint32_t)(ci0 + ce)) * (uint32_t)sizeof(T);
+                    offq = ((uint32_t)(pixbase[j] + hi * g.W + wi) * (uint32_t)g.C + (uint32_t)(ci0 + ce)) * (uint32_t)sizeof(T);
             }
             glds16(rp, sp + piece * 1024, offp);
             glds16(rq, sq + piece * 1024, offq);
+            // advance this row by one K step (64 pixels)
+            int wo = rwo[j] + g.adv_wo, ho = rho[j] + g.adv_ho, nb = g.adv_n;
+            if (wo >= g.Wo) { wo -= g.Wo; ++ho; }
+            if (ho >= g.Ho) { ho -= g.Ho; ++nb; }
+            rwo[j] = wo; rho[j] = ho; pixbase[j] += nb * HWin;
         }
     };
 
@@ -228,16 +247,32 @@ static int tn_run(int dtype, const void* p, const void* q, float* out, int n, in
     g.M = (int)M; g.Kc = kc; g.ldp = ldp;
     g.p_bytes = (uint32_t)pb; g.q_bytes = (uint32_t)qb;
     g.d_howo = make_fastdiv((uint32_t)(g.Ho * g.Wo)); g.d_wo = make_fastdiv((uint32_t)g.Wo);
+    g.adv_n = TN_KP / (g.Ho * g.Wo);
+    g.adv_ho = (TN_KP % (g.Ho * g.Wo)) / g.Wo;
+    g.adv_wo = TN_KP % g.Wo;
     g.ksteps = (g.M + TN_KP - 1) / TN_KP;
     const int taps = r * s;
     const bool big = (c * es >= 256) && (kc * es >= 256);
-    if (splits <= 0) {   // heuristic: aim for >= ~1024 workgroups
+    if (splits <= 0) {
+        // Split-K heuristic: the grid should fill whole "rounds" of the chip (256 CUs x resident workgroups) with as
+        // few splits as possible -- every extra split adds a full fp32 atomic pass over the output tile and a
+        // partially filled last round wastes up to a third of the launch.
         const int bc = (big ? 256 : 128) / es;
         const long long tiles = 1LL * ((kc + bc - 1) / bc) * ((c + bc - 1) / bc) * taps;
-        splits = (int)((1024 + tiles - 1) / tiles);
-        const int max_splits = (g.ksteps + 3) / 4;       // at least 4 K steps per workgroup
-        if (splits > max_splits) splits = max_splits;
-        if (splits < 1) splits = 1;
+        const int slots = 256 * (big ? 2 : 4);                 // LDS-limited residency: 2 (64 KB) / 4 (32 KB) per CU
+        const int max_splits = (g.ksteps + 7) / 8 > 0 ? (g.ksteps + 7) / 8 : 1;     // >= 8 K steps per workgroup
+        int best = 1; double best_score = -1.0;
+        for (int sp = 1; sp <= max_splits && sp <= 512; ++sp) {
+            const long long wgs = tiles * sp;
+            const long long rounds = (wgs + slots - 1) / slots;
+            const double fill = (double)wgs / (double)(rounds * slots);
+            // time ~ rounds * (ksteps/sp + epilogue cost in K-step units)
+            const double t = (double)rounds * ((double)g.ksteps / sp + 6.0);
+            const double score = 1.0 / t;
+            if (score > best_score * 1.02 || best_score < 0) { best_score = score; best = sp; }
+            (void)fill;
+        }
+        splits = best;
     }
     if (splits > g.ksteps) splits = g.ksteps;
     g.ksteps_per_split = (g.ksteps + splits - 1) / splits;
