@@ -158,6 +158,7 @@ __global__ __launch_bounds__(EW_THREADS) void bn_apply_kernel(const T* __restric
         sc[e] = scale[cg * EPV + e]; sh[e] = shift[cg * EPV + e];
         rs[e] = rscale ? rscale[cg * EPV + e] : 1.f; rb[e] = rscale ? rshift[cg * EPV + e] : 0.f;
     }
+#pragma unroll 2
     for (int r = blockIdx.x * rlanes + rl; r < rows; r += gridDim.x * rlanes) {
         const size_t idx = (size_t)r * C + cg * EPV;
         Vec16<T> a = *reinterpret_cast<const Vec16<T>*>(y + idx);
@@ -195,6 +196,7 @@ __global__ __launch_bounds__(EW_THREADS) void bn_bwd_apply_kernel(const T* __res
         a_[e] = ca[cg * EPV + e]; b_[e] = cb[cg * EPV + e]; c_[e] = cc[cg * EPV + e];
         ms[e] = mscale ? mscale[cg * EPV + e] : 0.f; mb[e] = mscale ? mshift[cg * EPV + e] : 1.f;
     }
+#pragma unroll 2
     for (int r = blockIdx.x * rlanes + rl; r < rows; r += gridDim.x * rlanes) {
         const size_t idx = (size_t)r * C + cg * EPV;
         const Vec16<T> d = *reinterpret_cast<const Vec16<T>*>(dout + idx);
@@ -246,7 +248,8 @@ static int grid_for(size_t work_items, int per_block) {
 static int ew_row_blocks(int rows, int c, int dtype) {
     const int epv = dtype == FRHIP_DT_BF16 ? 8 : 4;
     const int rlanes = EW_THREADS / (c / epv);
-    int b = (rows + rlanes - 1) / rlanes;
+    // >= 8 rows per thread so the per-channel vectors (up to 40 floats per thread) are amortised
+    int b = (rows + rlanes * 8 - 1) / (rlanes * 8);
     if (b > 2048) b = 2048;
     return b < 1 ? 1 : b;
 }

@@ -22,6 +22,7 @@ import torch.nn as nn
 
 from frhip import ops
 
+_OVERLAP_WGRAD = os.environ.get("FRHIP_OVERLAP_WGRAD", "1") == "1"
 _BLOCKS = {18: (2, 2, 2, 2), 34: (3, 4, 6, 4), 50: (3, 4, 14, 4), 100: (3, 13, 30, 4), 200: (3, 43, 50, 4)}
 _DTYPES = {"bf16": torch.bfloat16, "bfloat16": torch.bfloat16, "fp32": torch.float32, "float32": torch.float32}
 
@@ -234,9 +235,35 @@ def _flat_grads(params, device):
     return views
 
 
+_SIDE_STREAMS = {}
+
+
+def _side_stream(device):
+    """one long-lived side stream per device for the weight-gradient GEMMs"""
+    key = torch.device(device).index
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
+    return _SIDE_STREAMS[key]
+
+
 def _backward_impl(net, sv, d_emb, params):
     dt = net.dtype
     grads = _flat_grads(params, d_emb.device)
+    # Weight gradients do not feed the rest of the backward chain, so they run on a side HIP stream and fill the
+    # gaps (partially filled last rounds, HBM-bound BN passes) of the data-gradient chain on the main stream.
+    # Every tensor a side-stream kernel reads is kept referenced in `keep` until the streams are joined again.
+    main = torch.cuda.current_stream()
+    side = _side_stream(d_emb.device) if _OVERLAP_WGRAD else None
+    keep = []
+
+    def wgrad(dy, x, gview, r, s, stride, pad):
+        if side is None:
+            ops.conv_wgrad(dy, x, gview, r, s, stride, pad)
+            return
+        keep.append((dy, x, gview))
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            ops.conv_wgrad(dy, x, gview, r, s, stride, pad)
 
     def G(p):
         return grads[p]
@@ -262,14 +289,14 @@ def _backward_impl(net, sv, d_emb, params):
             dyd = ops.bn_backward(dout, s.yd, s.std, dbn.weight.data, G(dbn.weight), G(dbn.bias))
             wdt = ops.pack_wt(dconv.physical(), dt)
             shortcut = ops.conv_dgrad(dyd, wdt, s.x.shape, 1, 1, dconv.stride, 0)
-            ops.conv_wgrad(dyd, s.x, _phys_grad(dconv, G(dconv.weight)), 1, 1, dconv.stride, 0)
+            wgrad(dyd, s.x, _phys_grad(dconv, G(dconv.weight)), 1, 1, dconv.stride, 0)
         w2t = ops.pack_wt(blk.conv2.physical(), dt)
         da1 = ops.conv_dgrad(dy2, w2t, s.a1.shape, 3, 3, blk.stride, 1)
-        ops.conv_wgrad(dy2, s.a1, _phys_grad(blk.conv2, G(blk.conv2.weight)), 3, 3, blk.stride, 1)
+        wgrad(dy2, s.a1, _phys_grad(blk.conv2, G(blk.conv2.weight)), 3, 3, blk.stride, 1)
         dy1 = ops.bn_backward(da1, s.y1, s.st1, blk.bn1.weight.data, G(blk.bn1.weight), G(blk.bn1.bias), relu_mask=True)
         w1t = ops.pack_wt(blk.conv1.physical(), dt)
         dout = ops.conv_dgrad(dy1, w1t, s.x.shape, 3, 3, 1, 1, residual=shortcut)
-        ops.conv_wgrad(dy1, s.x, _phys_grad(blk.conv1, G(blk.conv1.weight)), 3, 3, 1, 1)
+        wgrad(dy1, s.x, _phys_grad(blk.conv1, G(blk.conv1.weight)), 3, 3, 1, 1)
     # ---- stem
     da0 = ops.maxpool_bwd(dout, sv.arg0, sv.y0.shape)
     dy0 = ops.bn_backward(da0, sv.y0, sv.st0, net.bn1.weight.data, G(net.bn1.weight), G(net.bn1.bias), relu_mask=True)
@@ -278,6 +305,9 @@ def _backward_impl(net, sv, d_emb, params):
     dwp0 = torch.zeros((64, 1, 1, kp), dtype=torch.float32, device=d_emb.device)
     ops.conv_wgrad(dy0.view(m, 1, 1, 64), sv.col.view(m, 1, 1, kp), dwp0, 1, 1, 1, 0)
     ops.unpack_stem_grad(dwp0, _phys_grad(net.conv1, G(net.conv1.weight)).view(64, 27))
+    if side is not None:
+        main.wait_stream(side)
+    del keep
     return grads
 
 

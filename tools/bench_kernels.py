@@ -28,6 +28,29 @@ def timeit(fn, n=10):
 
 
 what = sys.argv[1] if len(sys.argv) > 1 else "fwd"
+if what == "ew":
+    for (h, c) in [(56, 64), (28, 128), (14, 256), (7, 512)]:
+        rows = B * h * h
+        y = torch.randn(rows, c, device="cuda").bfloat16()
+        d = torch.randn(rows, c, device="cuda").bfloat16()
+        gamma, beta = torch.ones(c, device="cuda"), torch.zeros(c, device="cuda")
+        st = ops.bn_finalize(ops.colstats(y), rows, gamma, beta, None, None)
+        T = rows * c * 2 / 1e6   # MB per tensor
+        out = torch.empty_like(y)
+        dg, db = torch.zeros(c, device="cuda"), torch.zeros(c, device="cuda")
+        nb = lib().frhip_colreduce_blocks(rows, c, 0)
+        part = torch.empty((nb, 2, c), device="cuda")
+        coef = torch.rand((3, c), device="cuda")
+        P = ops._p
+        S = ops._s
+        t_apply = timeit(lambda: ops.bn_apply(y, st, relu=True, out=out))
+        t_apply_res = timeit(lambda: ops.bn_apply(y, st, res=d, out=out))
+        t_stats = timeit(lambda: lib().frhip_colstats(0, P(y), rows, c, P(part), S()))
+        t_bred = timeit(lambda: lib().frhip_bn_bwd_reduce(0, P(d), P(y), P(st.mean), P(st.invstd), P(st.scale), P(st.shift), rows, c, P(part), S()))
+        t_bapp = timeit(lambda: lib().frhip_bn_bwd_apply(0, P(d), P(y), P(coef[0]), P(coef[1]), P(coef[2]), P(st.scale), P(st.shift), P(out), rows, c, S()))
+        print("h=%2d c=%3d T=%6.1fMB | apply %6.1fus %4.2fTB/s | apply+res %6.1fus %4.2fTB/s | colstats %6.1fus %4.2fTB/s | bwd_reduce %6.1fus %4.2fTB/s | bwd_apply %6.1fus %4.2fTB/s" % (
+            h, c, T, t_apply, 2 * T / t_apply, t_apply_res, 3 * T / t_apply_res, t_stats, T / t_stats, t_bred, 2 * T / t_bred, t_bapp, 3 * T / t_bapp), flush=True)
+    sys.exit(0)
 for (h, c, k, r, stride) in SHAPES:
     pad = (r - 1) // 2
     x = torch.randn(B, h, h, c, device="cuda").bfloat16()
