@@ -78,6 +78,38 @@ template <int RB> struct TnFrag<float, RB> {
     }
 };
 
+template <typename T, int RB, int NT>
+__device__ __forceinline__ void tn_epilogue(f32x4_t (&acc)[NT][NT], char* smem, float* __restrict__ out,
+                                            const TnGeom& g, int co0, int ci0, int tap, int taps) {
+    typedef TnTile<T, RB> Tile;
+    static_assert(NT == Tile::NT, "accumulator shape");
+    const int lane = lane_id(), wave = wave_id();
+    const int wco = wave >> 1, wci = wave & 1;
+    // ---- epilogue: D[row = co (4g+reg)][col = ci (lane&15)] -> LDS [co][ci] fp32 -> row-wise atomic adds
+    __syncthreads();
+    constexpr int P = Tile::OUT_PITCH;
+    char* mine = smem + wave * Tile::WC * P;
+    const int fi = lane & 15, fg = lane >> 4;
+#pragma unroll
+    for (int a = 0; a < NT; ++a)
+#pragma unroll
+        for (int b = 0; b < NT; ++b)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                *reinterpret_cast<float*>(mine + (a * 16 + 4 * fg + e) * P + (b * 16 + fi) * 4) = acc[a][b][e];
+    __syncthreads();
+    constexpr int LPR = Tile::WC;            // lanes per row (64, 32 or 16)
+    constexpr int RPI = 64 / LPR;
+    const int col = lane % LPR, rsub = lane / LPR;
+    const int ci = ci0 + wci * Tile::WC + col;
+    for (int it = 0; it < Tile::WC / RPI; ++it) {
+        const int row = it * RPI + rsub;
+        const int co = co0 + wco * Tile::WC + row;
+        if (co < g.Kc && ci < g.C)
+            atomicAdd(out + ((size_t)co * taps + tap) * g.C + ci, *reinterpret_cast<const float*>(mine + row * P + col * 4));
+    }
+}
+
 template <typename T, int RB>
 __global__ __launch_bounds__(TN_THREADS, 2) void tn_kernel(TnGeom g, const void* __restrict__ p_ptr,
                                                            const void* __restrict__ q_ptr, float* __restrict__ out,
@@ -186,29 +218,368 @@ __global__ __launch_bounds__(TN_THREADS, 2) void tn_kernel(TnGeom g, const void*
         compute(cur);
     }
 
-    // ---- epilogue: D[row = co (4g+reg)][col = ci (lane&15)] -> LDS [co][ci] fp32 -> row-wise atomic adds
-    __syncthreads();
-    constexpr int P = Tile::OUT_PITCH;
-    char* mine = smem + wave * Tile::WC * P;
-    const int fi = lane & 15, fg = lane >> 4;
+    tn_epilogue<T, RB, NT>(acc, smem, out, g, co0, ci0, tap, taps);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// "Linear-shift" variant for stride-1 / same-size convolutions (3x3 p1, 1x1 p0) and plain TN GEMMs, bf16.
+// With stride 1 the input pixel of output pixel m at tap (r,s) is simply m + (r-pad)*W + (s-pad) in the linear
+// N*H*W index, so BOTH operand tiles are contiguous 64-row windows: the loader needs two adds per DMA piece and
+// no pixel decode at all.  Pixels whose neighbour falls outside the image are handled on the consumer side: the
+// transposing LDS read takes a per-lane row address, and lanes whose row is padding point at a zero block instead.
+// Each lane only tracks the (ho, wo) of the four pixel rows it addresses, advanced by 64 pixels per K step.
+template <int RB>
+__global__ __launch_bounds__(TN_THREADS, 2) void tn_lin_kernel(TnGeom g, const void* __restrict__ p_ptr,
+                                                               const void* __restrict__ q_ptr, float* __restrict__ out,
+                                                               int co_tiles, int ci_tiles, int taps) {
+    typedef bf16_t T;
+    typedef TnTile<T, RB> Tile;
+    constexpr int NT = Tile::NT;
+    constexpr int ZERO_OFF = 2 * Tile::STAGE_BYTES;          // 16 zero bytes behind the two stages
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = lane_id(), wave = wave_id();
+    uint32_t lin = xcd_remap(blockIdx.x, gridDim.x);
+    const int tap = (int)(lin % (uint32_t)taps); lin /= (uint32_t)taps;
+    const int ci_tile = (int)(lin % (uint32_t)ci_tiles), co_tile = (int)(lin / (uint32_t)ci_tiles);
+    const int dy = tap / g.S - g.pad, dx = tap % g.S - g.pad;
+    const int shift = dy * g.W + dx;
+    const int ks_begin = blockIdx.y * g.ksteps_per_split;
+    const int ks_end = min(g.ksteps, ks_begin + g.ksteps_per_split);
+    const int wco = wave >> 1, wci = wave & 1;
+
+    f32x4_t acc[NT][NT];
 #pragma unroll
     for (int a = 0; a < NT; ++a)
 #pragma unroll
-        for (int b = 0; b < NT; ++b)
+        for (int b = 0; b < NT; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    if (threadIdx.x == 0) *reinterpret_cast<f32x4_t*>(smem + ZERO_OFF) = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    const __amdgpu_buffer_rsrc_t rp = make_rsrc(p_ptr, g.p_bytes);
+    const __amdgpu_buffer_rsrc_t rq = make_rsrc(q_ptr, g.q_bytes);
+    const int sub = lane / Tile::CHUNKS, phys = lane % Tile::CHUNKS;
+    const int co0 = co_tile * Tile::BC, ci0 = ci_tile * Tile::BC;
+
+    // ---- loader state: one running byte offset per DMA piece and operand (out-of-range = hardware zero fill)
+    uint32_t offp[Tile::PIECES], offq[Tile::PIECES];
+    const uint32_t incp = (uint32_t)(TN_KP * g.ldp) * 2u, incq = (uint32_t)(TN_KP * g.C) * 2u;
+    bool okp[Tile::PIECES], okq[Tile::PIECES];
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-                *reinterpret_cast<float*>(mine + (a * 16 + 4 * fg + e) * P + (b * 16 + fi) * 4) = acc[a][b][e];
-    __syncthreads();
-    constexpr int LPR = Tile::WC;            // lanes per row (64, 32 or 16)
-    constexpr int RPI = 64 / LPR;
-    const int col = lane % LPR, rsub = lane / LPR;
-    const int ci = ci0 + wci * Tile::WC + col;
-    for (int it = 0; it < Tile::WC / RPI; ++it) {
-        const int row = it * RPI + rsub;
-        const int co = co0 + wco * Tile::WC + row;
-        if (co < g.Kc && ci < g.C)
-            atomicAdd(out + ((size_t)co * taps + tap) * g.C + ci, *reinterpret_cast<const float*>(mine + row * P + col * 4));
+    for (int j = 0; j < Tile::PIECES; ++j) {
+        const int row = (wave * Tile::PIECES + j) * Tile::ROWS_PER_PIECE + sub;
+        const int ce = (phys ^ tn_swz<RB>(row)) * 8;
+        const int m = ks_begin * TN_KP + row;
+        okp[j] = co0 + ce < g.ldp;
+        okq[j] = ci0 + ce < g.C;
+        offp[j] = (uint32_t)((m * g.ldp + co0 + ce) * 2);
+        offq[j] = (uint32_t)(((m + shift) * g.C + ci0 + ce) * 2);     // negative pixel index wraps above 2^31 = out of range
     }
+    auto stage = [&](int buf) {
+        char* sp = smem + buf * Tile::STAGE_BYTES;
+        char* sq = sp + Tile::TILE_BYTES;
+#pragma unroll
+        for (int j = 0; j < Tile::PIECES; ++j) {
+            const int piece = wave * Tile::PIECES + j;
+            glds16(rp, sp + piece * 1024, okp[j] ? offp[j] : OOB_OFFSET);
+            glds16(rq, sq + piece * 1024, okq[j] ? offq[j] : OOB_OFFSET);
+            offp[j] += incp; offq[j] += incq;
+        }
+    };
+
+    // ---- consumer state: the four pixel rows (of the 64-row K step) this lane supplies addresses for
+    const int fg = lane >> 4, fj = lane & 15, fq = fj >> 2, fp = fj & 3;
+    int prow[4], pho[4], pwo[4], pm[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        prow[i] = (i >> 1) * 32 + 8 * fg + fq + 4 * (i & 1);          // i = 2*kk + half
+        const uint32_t m = (uint32_t)(ks_begin * TN_KP + prow[i]);
+        const uint32_t n = fdiv(m, g.d_howo);
+        const uint32_t rem = m - n * (uint32_t)(g.Ho * g.Wo);
+        const uint32_t ho = fdiv(rem, g.d_wo);
+        pm[i] = (int)m; pho[i] = (int)ho; pwo[i] = (int)(rem - ho * (uint32_t)g.Wo);
+    }
+    // byte offsets inside a tile of this lane's 8-byte transposed-read slot, per row and channel tile
+    int pa[4][NT], qa[4][NT];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int cp = ((wco * Tile::WC + t * 16) >> 3) + (fp >> 1), cq = ((wci * Tile::WC + t * 16) >> 3) + (fp >> 1);
+            pa[i][t] = prow[i] * RB + ((cp ^ tn_swz<RB>(prow[i])) << 4) + 8 * (fp & 1);
+            qa[i][t] = Tile::TILE_BYTES + prow[i] * RB + ((cq ^ tn_swz<RB>(prow[i])) << 4) + 8 * (fp & 1);
+        }
+
+    typedef __attribute__((ext_vector_type(8))) short i16x8_t;
+    auto tr8 = [&](const char* lo_p, const char* hi_p) {
+        i16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4_t*)LDS_ADDR(lo_p));
+        i16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4_t*)LDS_ADDR(hi_p));
+        return __builtin_bit_cast(bf16x8_t, (i16x8_t)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+    };
+
+    auto compute = [&](int buf) {
+        const char* base = smem + buf * Tile::STAGE_BYTES;
+        bool v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            v[i] = pm[i] < g.M && (unsigned)(pho[i] + dy) < (unsigned)g.H && (unsigned)(pwo[i] + dx) < (unsigned)g.W;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8_t pf[NT], qf[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                pf[t] = tr8(base + pa[2 * kk][t], base + pa[2 * kk + 1][t]);
+                qf[t] = tr8(v[2 * kk] ? base + qa[2 * kk][t] : smem + ZERO_OFF,
+                            v[2 * kk + 1] ? base + qa[2 * kk + 1][t] : smem + ZERO_OFF);
+            }
+#pragma unroll
+            for (int a = 0; a < NT; ++a)
+#pragma unroll
+                for (int b = 0; b < NT; ++b) Mma<T>::run(pf[a], qf[b], acc[a][b]);
+        }
+        // advance the four tracked pixels by one K step
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int wo = pwo[i] + g.adv_wo, ho = pho[i] + g.adv_ho;
+            if (wo >= g.Wo) { wo -= g.Wo; ++ho; }
+            if (ho >= g.Ho) ho -= g.Ho;
+            pwo[i] = wo; pho[i] = ho; pm[i] += TN_KP;
+        }
+    };
+
+    if (ks_begin < ks_end) {
+        stage(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        int cur = 0;
+        for (int ks = ks_begin; ks < ks_end - 1; ++ks) {
+            stage(cur ^ 1);
+            compute(cur);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            cur ^= 1;
+        }
+        compute(cur);
+    }
+    tn_epilogue<T, RB, NT>(acc, smem, out, g, co0, ci0, tap, taps);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// "All nine taps" weight-gradient for 3x3 / stride-1 / pad-1 convolutions, bf16.
+// One workgroup owns a (64 co x 64 ci) tile for ALL nine taps.  Per K step (64 output pixels) it stages the dy rows
+// once and ONE input window of 64 + 2W + 2 pixel rows (stride 1: the nine taps read the same rows at offsets
+// dy*W + dx), instead of nine (dy tile + x tile) pairs spread over nine workgroups: ~6x fewer LDS-DMA bytes, and the
+// dy fragments are transposed-read once and reused by all taps.  Padding is resolved at the transposed read (lanes
+// whose row is padding point at a zero block).  Every LDS address is computed once before the K loop.
+// Accumulators: 9 taps x (32x32 per wave) = 144 VGPRs.
+constexpr int TH_RB = 128;                                  // 64 channels of bf16 per row
+constexpr int TH_MAXW = 56;
+constexpr int TH_QROWS = ((TN_KP + 2 * TH_MAXW + 2 + 7) / 8) * 8;        // 184
+constexpr int TH_P_BYTES = TN_KP * TH_RB;                    // 8 KB
+constexpr int TH_STAGE = TH_P_BYTES + TH_QROWS * TH_RB;      // 31.5 KB
+constexpr int TH_ZERO = 2 * TH_STAGE;
+constexpr int TH_LDS = TH_ZERO + 16 > 4 * 32 * (32 * 4 + 16) ? TH_ZERO + 16 : 4 * 32 * (32 * 4 + 16);
+
+__global__ __launch_bounds__(TN_THREADS, 1) void tn_taps9_kernel(TnGeom g, const void* __restrict__ p_ptr,
+                                                                 const void* __restrict__ q_ptr, float* __restrict__ out,
+                                                                 int co_tiles, int ci_tiles) {
+    typedef bf16_t T;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = lane_id(), wave = wave_id();
+    const uint32_t lin = xcd_remap(blockIdx.x, gridDim.x);
+    const int ci_tile = (int)(lin % (uint32_t)ci_tiles), co_tile = (int)(lin / (uint32_t)ci_tiles);
+    const int ks_begin = blockIdx.y * g.ksteps_per_split;
+    const int ks_end = min(g.ksteps, ks_begin + g.ksteps_per_split);
+    const int wco = wave >> 1, wci = wave & 1;
+    const int co0 = co_tile * 64, ci0 = ci_tile * 64;
+    const int qrows = TN_KP + 2 * g.W + 2, qpieces = (qrows + 7) >> 3;
+
+    f32x4_t acc[9][2][2];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) acc[t][a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    if (threadIdx.x == 0) *reinterpret_cast<f32x4_t*>(smem + TH_ZERO) = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    const __amdgpu_buffer_rsrc_t rp = make_rsrc(p_ptr, g.p_bytes);
+    const __amdgpu_buffer_rsrc_t rq = make_rsrc(q_ptr, g.q_bytes);
+
+    // ---- loader: pieces of 8 rows x 128 B.  P: 8 pieces (2 per wave); Q window: up to 23 pieces (6 per wave).
+    const int sub = lane >> 3, phys = lane & 7;
+    uint32_t offp[2], offq[6];
+    bool okq[6];
+    const uint32_t incp = (uint32_t)(TN_KP * g.ldp) * 2u, incq = (uint32_t)(TN_KP * g.C) * 2u;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int row = (wave * 2 + j) * 8 + sub;
+        const int ce = (phys ^ tn_swz<TH_RB>(row)) * 8;
+        offp[j] = (co0 + ce < g.ldp) ? (uint32_t)(((ks_begin * TN_KP + row) * g.ldp + co0 + ce) * 2) : OOB_OFFSET;
+    }
+    const bool p_col_ok0 = offp[0] != OOB_OFFSET, p_col_ok1 = offp[1] != OOB_OFFSET;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        const int piece = wave + 4 * j;
+        const int row = piece * 8 + sub;
+        const int ce = (phys ^ tn_swz<TH_RB>(row)) * 8;
+        okq[j] = piece < qpieces && ci0 + ce < g.C;
+        offq[j] = (uint32_t)(((ks_begin * TN_KP - g.W - 1 + row) * g.C + ci0 + ce) * 2);   // negative pixel -> out of range
+    }
+    auto stage = [&](int buf) {
+        char* sp = smem + buf * TH_STAGE;
+        char* sq = sp + TH_P_BYTES;
+        glds16(rp, sp + (wave * 2 + 0) * 1024, p_col_ok0 ? offp[0] : OOB_OFFSET);
+        glds16(rp, sp + (wave * 2 + 1) * 1024, p_col_ok1 ? offp[1] : OOB_OFFSET);
+        offp[0] += incp; offp[1] += incp;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            if (wave + 4 * j < qpieces) glds16(rq, sq + (wave + 4 * j) * 1024, okq[j] ? offq[j] : OOB_OFFSET);
+            offq[j] += incq;
+        }
+    };
+
+    // ---- consumer: the four pixel rows (of the 64) this lane addresses in the transposed reads
+    const int fg = lane >> 4, fj = lane & 15, fq = fj >> 2, fp = fj & 3;
+    int pho[4], pwo[4], pm[4];
+    int pa[4];             // P slot of row i, channel tile 0 (tile 1 = ^32)
+    int qa[9][4];          // Q slot of row i at tap t, channel tile 0 (tile 1 = ^32)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int prow = (i >> 1) * 32 + 8 * fg + fq + 4 * (i & 1);          // i = 2*kk + half
+        const uint32_t m = (uint32_t)(ks_begin * TN_KP + prow);
+        const uint32_t n = fdiv(m, g.d_howo);
+        const uint32_t rem = m - n * (uint32_t)(g.Ho * g.Wo);
+        const uint32_t ho = fdiv(rem, g.d_wo);
+        pm[i] = (int)m; pho[i] = (int)ho; pwo[i] = (int)(rem - ho * (uint32_t)g.Wo);
+        const int cp = ((wco * 32) >> 3) + (fp >> 1), cq = ((wci * 32) >> 3) + (fp >> 1);
+        pa[i] = prow * TH_RB + ((cp ^ tn_swz<TH_RB>(prow)) << 4) + 8 * (fp & 1);
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int qrow = prow + g.W + 1 + (t / 3 - 1) * g.W + (t % 3 - 1);
+            qa[t][i] = TH_P_BYTES + qrow * TH_RB + ((cq ^ tn_swz<TH_RB>(qrow)) << 4) + 8 * (fp & 1);
+        }
+    }
+    typedef __attribute__((ext_vector_type(8))) short i16x8_t;
+    auto tr8 = [&](const char* lo_p, const char* hi_p) {
+        i16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4_t*)LDS_ADDR(lo_p));
+        i16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4_t*)LDS_ADDR(hi_p));
+        return __builtin_bit_cast(bf16x8_t, (i16x8_t)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+    };
+
+    auto compute = [&](int buf) {
+        const char* base = smem + buf * TH_STAGE;
+        const char* zero = smem + TH_ZERO;
+        bool up[4], dn[4], lf[4], rt[4], live[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            live[i] = pm[i] < g.M;
+            up[i] = pho[i] > 0; dn[i] = pho[i] < g.H - 1; lf[i] = pwo[i] > 0; rt[i] = pwo[i] < g.W - 1;
+        }
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int i0 = 2 * kk, i1 = 2 * kk + 1;
+            bf16x8_t pf[2];
+            pf[0] = tr8(base + pa[i0], base + pa[i1]);
+            pf[1] = tr8(base + (pa[i0] ^ 32), base + (pa[i1] ^ 32));
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int dy = t / 3 - 1, dx = t % 3 - 1;
+                const bool v0 = live[i0] && (dy < 0 ? up[i0] : (dy > 0 ? dn[i0] : true)) && (dx < 0 ? lf[i0] : (dx > 0 ? rt[i0] : true));
+                const bool v1 = live[i1] && (dy < 0 ? up[i1] : (dy > 0 ? dn[i1] : true)) && (dx < 0 ? lf[i1] : (dx > 0 ? rt[i1] : true));
+                const char* a0 = v0 ? base + qa[t][i0] : zero;
+                const char* a1 = v1 ? base + qa[t][i1] : zero;
+                const bf16x8_t q0 = tr8(a0, a1);
+                const bf16x8_t q1 = tr8(v0 ? base + (qa[t][i0] ^ 32) : zero, v1 ? base + (qa[t][i1] ^ 32) : zero);
+                Mma<T>::run(pf[0], q0, acc[t][0][0]);
+                Mma<T>::run(pf[0], q1, acc[t][0][1]);
+                Mma<T>::run(pf[1], q0, acc[t][1][0]);
+                Mma<T>::run(pf[1], q1, acc[t][1][1]);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int wo = pwo[i] + g.adv_wo, ho = pho[i] + g.adv_ho;
+            if (wo >= g.Wo) { wo -= g.Wo; ++ho; }
+            if (ho >= g.Ho) ho -= g.Ho;
+            pwo[i] = wo; pho[i] = ho; pm[i] += TN_KP;
+        }
+    };
+
+    if (ks_begin < ks_end) {
+        stage(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        int cur = 0;
+        for (int ks = ks_begin; ks < ks_end - 1; ++ks) {
+            stage(cur ^ 1);
+            compute(cur);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            cur ^= 1;
+        }
+        compute(cur);
+    }
+    // ---- epilogue, tap by tap: 32x32 per wave -> LDS -> row-wise fp32 atomic adds into dw[co][tap][ci]
+    constexpr int P = 32 * 4 + 16;
+    char* mine = smem + wave * 32 * P;
+    const int fi = lane & 15;
+    const int col = lane & 31, rsub = lane >> 5;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        __syncthreads();
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    *reinterpret_cast<float*>(mine + (a * 16 + 4 * fg + e) * P + (b * 16 + fi) * 4) = acc[t][a][b][e];
+        __syncthreads();
+        const int ci = ci0 + wci * 32 + col;
+        for (int it = 0; it < 16; ++it) {
+            const int row = it * 2 + rsub;
+            const int co = co0 + wco * 32 + row;
+            if (co < g.Kc && ci < g.C)
+                atomicAdd(out + ((size_t)co * 9 + t) * g.C + ci, *reinterpret_cast<const float*>(mine + row * P + col * 4));
+        }
+    }
+}
+
+static int g_tn_taps9 = 1;
+
+static int tn_taps9_launch(const TnGeom& g, const void* p, const void* q, float* out, int splits, hipStream_t stream) {
+    const int co_tiles = (g.Kc + 63) / 64, ci_tiles = (g.C + 63) / 64;
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(tn_taps9_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, TH_LDS) != hipSuccess) {
+            set_error("igemm_tn(taps9): cannot raise dynamic LDS to %d bytes", TH_LDS);
+            return FRHIP_ELAUNCH;
+        }
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(tn_taps9_kernel, dim3(co_tiles * ci_tiles, splits), dim3(TN_THREADS), TH_LDS, stream, g, p, q, out,
+                       co_tiles, ci_tiles);
+    return check_launch("igemm_tn(taps9)");
+}
+
+static int g_tn_linear = 0;    // measured: no gain over the gather kernel (the TN main loop is not VALU-bound); kept for tests
+
+template <int RB>
+static int tn_lin_launch(const TnGeom& g, const void* p, const void* q, float* out, int taps, int splits, hipStream_t stream) {
+    typedef TnTile<bf16_t, RB> Tile;
+    const int co_tiles = (g.Kc + Tile::BC - 1) / Tile::BC, ci_tiles = (g.C + Tile::BC - 1) / Tile::BC;
+    const int lds = Tile::LDS_BYTES + 16;
+    auto kern = tn_lin_kernel<RB>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
+            set_error("igemm_tn(lin): cannot raise dynamic LDS to %d bytes", lds);
+            return FRHIP_ELAUNCH;
+        }
+        attr_done = true;
+    }
+    dim3 grid(co_tiles * ci_tiles * taps, splits);
+    hipLaunchKernelGGL(kern, grid, dim3(TN_THREADS), lds, stream, g, p, q, out, co_tiles, ci_tiles, taps);
+    return check_launch("igemm_tn(lin)");
 }
 
 template <typename T, int RB>
@@ -252,6 +623,27 @@ static int tn_run(int dtype, const void* p, const void* q, float* out, int n, in
     g.adv_wo = TN_KP % g.Wo;
     g.ksteps = (g.M + TN_KP - 1) / TN_KP;
     const int taps = r * s;
+    // measured (tools/bench_kernels.py wgrad, B=512): the nine-tap kernel wins where the per-tap tile is DMA-starved
+    // (64 channels: 293 vs 455 us) and loses to the 128x128-per-tap kernel from 128 channels up (LDS-read latency
+    // of its 32x32 wave tiles); g_tn_taps9 == 2 forces it everywhere (tests).
+    if (g_tn_taps9 && (g_tn_taps9 == 2 || (c <= 64 && kc <= 64)) && dtype == FRHIP_DT_BF16 && r == 3 && s == 3 &&
+        stride == 1 && pad == 1 && w <= TH_MAXW &&
+        1LL * (M + 64 + 2LL * w + 2) * (ldp > c ? ldp : c) * es < 0x7fffffffLL) {
+        const long long tiles = 1LL * ((kc + 63) / 64) * ((c + 63) / 64);
+        const int slots = 256 * 2;
+        int best = 1; double best_t = 1e30;
+        const int max_splits = g.ksteps / 8 > 0 ? g.ksteps / 8 : 1;
+        for (int sp = 1; sp <= max_splits && sp <= 1024; ++sp) {
+            const long long rounds = (tiles * sp + slots - 1) / slots;
+            const double t = (double)rounds * ((double)g.ksteps / sp + 12.0);       // epilogue ~ 12 K steps (nine atomic passes)
+            if (t < best_t * 0.98) { best_t = t; best = sp; }
+        }
+        if (splits <= 0) splits = best;
+        if (splits > g.ksteps) splits = g.ksteps;
+        g.ksteps_per_split = (g.ksteps + splits - 1) / splits;
+        splits = (g.ksteps + g.ksteps_per_split - 1) / g.ksteps_per_split;
+        return tn_taps9_launch(g, p, q, out, splits, stream);
+    }
     const bool big = (c * es >= 256) && (kc * es >= 256);
     if (splits <= 0) {
         // Split-K heuristic: the grid should fill whole "rounds" of the chip (256 CUs x resident workgroups) with as
@@ -277,6 +669,10 @@ static int tn_run(int dtype, const void* p, const void* q, float* out, int n, in
     if (splits > g.ksteps) splits = g.ksteps;
     g.ksteps_per_split = (g.ksteps + splits - 1) / splits;
     splits = (g.ksteps + g.ksteps_per_split - 1) / g.ksteps_per_split;
+    const bool linear = g_tn_linear && dtype == FRHIP_DT_BF16 && stride == 1 && g.Ho == h && g.Wo == w && r == s &&
+                        1LL * (M + 64 + 2LL * w + 2) * (ldp > c ? ldp : c) * es < 0x7fffffffLL;
+    if (linear) return big ? tn_lin_launch<256>(g, p, q, out, taps, splits, stream)
+                           : tn_lin_launch<128>(g, p, q, out, taps, splits, stream);
     if (dtype == FRHIP_DT_BF16) return big ? tn_launch<bf16_t, 256>(g, p, q, out, taps, splits, stream)
                                            : tn_launch<bf16_t, 128>(g, p, q, out, taps, splits, stream);
     return big ? tn_launch<float, 256>(g, p, q, out, taps, splits, stream)
@@ -286,6 +682,13 @@ static int tn_run(int dtype, const void* p, const void* q, float* out, int n, in
 }  // namespace frhip
 
 using namespace frhip;
+
+extern "C" int frhip_set_tn_linear(int enabled) {
+    // bit 0: linear-shift kernel; bits 1-2: all-nine-taps 3x3 kernel (0 off, 1 auto = narrow layers only, 2 always)
+    const int old = g_tn_linear | (g_tn_taps9 << 1);
+    g_tn_linear = enabled & 1; g_tn_taps9 = (enabled >> 1) & 3;
+    return old;
+}
 
 extern "C" int frhip_conv_wgrad(int dtype, const void* dy, const void* x, float* dw, int n, int h, int w, int c,
                                 int k, int r, int s, int stride, int pad, int splits, hipStream_t stream) {

@@ -50,6 +50,9 @@ int frhip_abi_version(void);
 int frhip_nt_block_m(int k);
 /* number of partial rows frhip_conv_fwd writes into stats_partial for this convolution (m = n*ho*wo output pixels) */
 int frhip_conv_stat_rows(int dtype, int m, int k, int h, int w, int c, int r, int s, int stride, int pad);
+/* test hook: bit 0 enables the linear-shift (stride-1) weight-gradient kernel; bits 1-2 select the all-nine-taps 3x3
+ * kernel (0 off, 1 = automatic: 64-channel layers only, 2 = always).  Default 2 (= auto, linear off).  Returns the old value */
+int frhip_set_tn_linear(int enabled);
 /* test hook: 0 disables the LDS-halo 3x3/s1 kernel (generic NT kernel is used instead); returns the old value */
 int frhip_set_conv_halo(int enabled);
 /* test / micro-benchmark hook: force the NT tile (0 auto, 1 128x128, 2 256x64, 3 256x128, 4 256x256); returns the old value */

@@ -130,6 +130,26 @@ def test_halo_kernel_equals_generic_kernel():
         np.testing.assert_allclose(outs[0][2].numpy(), outs[1][2].numpy(), rtol=0, atol=outs[1][2].abs().max().item() * 2 ** -7)
 
 
+def test_linear_shift_wgrad_equals_generic_wgrad():
+    """stride-1 weight gradient: contiguous-window kernel (padding resolved at the LDS read) vs the gather kernel"""
+    ops = _ops()
+    from frhip._abi import lib
+    for (n, h, c, k, r) in [(3, 56, 64, 64, 3), (5, 28, 128, 128, 3), (7, 14, 256, 256, 3), (11, 7, 512, 512, 3),
+                            (4, 9, 64, 128, 1)]:
+        pad = (r - 1) // 2
+        x = rnd(50, (n, h, h, c)).bfloat16().cuda()
+        dy = rnd(51, (n, h, h, k)).bfloat16().cuda()
+        outs = []
+        for lin in (4, 1, 0):          # nine-tap kernel forced / linear-shift kernel / plain gather kernel
+            old = lib().frhip_set_tn_linear(lin)
+            dw = torch.zeros((k, r, r, c), dtype=torch.float32, device="cuda")
+            ops.conv_wgrad(dy, x, dw, r, r, 1, pad)
+            lib().frhip_set_tn_linear(old)
+            outs.append(dw.cpu())
+        for o in outs[:2]:
+            np.testing.assert_allclose(o.numpy(), outs[2].numpy(), rtol=1e-4, atol=1e-4 * outs[2].abs().max().item())
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("mnk", [(16, 512, 1024), (200, 64, 128), (512, 1003 // 8 * 8, 512)])
 def test_gemm_nt_store_and_splitk(dtype, mnk):
