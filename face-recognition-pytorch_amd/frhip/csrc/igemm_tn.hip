@@ -19,6 +19,7 @@ struct TnGeom {
     int M, Kc, ldp;          // GEMM-K rows, valid P columns (= output rows), P row pitch (elements)
     int ksteps, ksteps_per_split;
     FastDiv d_howo, d_wo;
+    int slab_stride;             // 0: add into `out` with fp32 atomics; > 0: each K split stores its tiles into out + split*slab_stride
     int adv_wo, adv_ho, adv_n;   // 64 pixels = adv_n images + adv_ho rows + adv_wo columns (mixed-radix step per K step)
     uint32_t p_bytes, q_bytes;
 };
@@ -105,8 +106,12 @@ __device__ __forceinline__ void tn_epilogue(f32x4_t (&acc)[NT][NT], char* smem, 
     for (int it = 0; it < Tile::WC / RPI; ++it) {
         const int row = it * RPI + rsub;
         const int co = co0 + wco * Tile::WC + row;
-        if (co < g.Kc && ci < g.C)
-            atomicAdd(out + ((size_t)co * taps + tap) * g.C + ci, *reinterpret_cast<const float*>(mine + row * P + col * 4));
+        if (co < g.Kc && ci < g.C) {
+            const float v = *reinterpret_cast<const float*>(mine + row * P + col * 4);
+            const size_t idx = ((size_t)co * taps + tap) * g.C + ci;
+            if (g.slab_stride) out[(size_t)blockIdx.y * g.slab_stride + idx] = v;     // private slab: plain coalesced store
+            else atomicAdd(out + idx, v);
+        }
     }
 }
 
@@ -474,26 +479,38 @@ __global__ __launch_bounds__(TN_THREADS, 1) void tn_taps9_kernel(TnGeom g, const
             live[i] = pm[i] < g.M;
             up[i] = pho[i] > 0; dn[i] = pho[i] < g.H - 1; lf[i] = pwo[i] > 0; rt[i] = pwo[i] < g.W - 1;
         }
+        // software pipeline over the 18 (kk, tap) groups: the transposed reads of group n+1 are issued before the
+        // four MFMAs of group n, so LDS latency hides behind the matrix pipe (two register sets, qa / qb)
+        bf16x8_t pf[2][2];
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
+            pf[kk][0] = tr8(base + pa[2 * kk], base + pa[2 * kk + 1]);
+            pf[kk][1] = tr8(base + (pa[2 * kk] ^ 32), base + (pa[2 * kk + 1] ^ 32));
+        }
+        auto loadq = [&](int n, bf16x8_t& q0, bf16x8_t& q1) {
+            const int kk = n / 9, t = n - kk * 9;
             const int i0 = 2 * kk, i1 = 2 * kk + 1;
-            bf16x8_t pf[2];
-            pf[0] = tr8(base + pa[i0], base + pa[i1]);
-            pf[1] = tr8(base + (pa[i0] ^ 32), base + (pa[i1] ^ 32));
+            const int dy = t / 3 - 1, dx = t % 3 - 1;
+            const bool v0 = live[i0] && (dy < 0 ? up[i0] : (dy > 0 ? dn[i0] : true)) && (dx < 0 ? lf[i0] : (dx > 0 ? rt[i0] : true));
+            const bool v1 = live[i1] && (dy < 0 ? up[i1] : (dy > 0 ? dn[i1] : true)) && (dx < 0 ? lf[i1] : (dx > 0 ? rt[i1] : true));
+            q0 = tr8(v0 ? base + qa[t][i0] : zero, v1 ? base + qa[t][i1] : zero);
+            q1 = tr8(v0 ? base + (qa[t][i0] ^ 32) : zero, v1 ? base + (qa[t][i1] ^ 32) : zero);
+        };
+        auto mma4 = [&](int n, const bf16x8_t& q0, const bf16x8_t& q1) {
+            const int kk = n / 9, t = n - kk * 9;
+            Mma<T>::run(pf[kk][0], q0, acc[t][0][0]);
+            Mma<T>::run(pf[kk][0], q1, acc[t][0][1]);
+            Mma<T>::run(pf[kk][1], q0, acc[t][1][0]);
+            Mma<T>::run(pf[kk][1], q1, acc[t][1][1]);
+        };
+        bf16x8_t qa0, qa1, qb0, qb1;
+        loadq(0, qa0, qa1);
 #pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                const int dy = t / 3 - 1, dx = t % 3 - 1;
-                const bool v0 = live[i0] && (dy < 0 ? up[i0] : (dy > 0 ? dn[i0] : true)) && (dx < 0 ? lf[i0] : (dx > 0 ? rt[i0] : true));
-                const bool v1 = live[i1] && (dy < 0 ? up[i1] : (dy > 0 ? dn[i1] : true)) && (dx < 0 ? lf[i1] : (dx > 0 ? rt[i1] : true));
-                const char* a0 = v0 ? base + qa[t][i0] : zero;
-                const char* a1 = v1 ? base + qa[t][i1] : zero;
-                const bf16x8_t q0 = tr8(a0, a1);
-                const bf16x8_t q1 = tr8(v0 ? base + (qa[t][i0] ^ 32) : zero, v1 ? base + (qa[t][i1] ^ 32) : zero);
-                Mma<T>::run(pf[0], q0, acc[t][0][0]);
-                Mma<T>::run(pf[0], q1, acc[t][0][1]);
-                Mma<T>::run(pf[1], q0, acc[t][1][0]);
-                Mma<T>::run(pf[1], q1, acc[t][1][1]);
-            }
+        for (int n = 0; n < 18; n += 2) {
+            loadq(n + 1, qb0, qb1);
+            mma4(n, qa0, qa1);
+            if (n + 2 < 18) loadq(n + 2, qa0, qa1);
+            mma4(n + 1, qb0, qb1);
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -538,8 +555,12 @@ __global__ __launch_bounds__(TN_THREADS, 1) void tn_taps9_kernel(TnGeom g, const
         for (int it = 0; it < 16; ++it) {
             const int row = it * 2 + rsub;
             const int co = co0 + wco * 32 + row;
-            if (co < g.Kc && ci < g.C)
-                atomicAdd(out + ((size_t)co * 9 + t) * g.C + ci, *reinterpret_cast<const float*>(mine + row * P + col * 4));
+            if (co < g.Kc && ci < g.C) {
+                const float v = *reinterpret_cast<const float*>(mine + row * P + col * 4);
+                const size_t idx = ((size_t)co * 9 + t) * g.C + ci;
+                if (g.slab_stride) out[(size_t)blockIdx.y * g.slab_stride + idx] = v;
+                else atomicAdd(out + idx, v);
+            }
         }
     }
 }
@@ -559,6 +580,19 @@ static int tn_taps9_launch(const TnGeom& g, const void* p, const void* q, float*
     hipLaunchKernelGGL(tn_taps9_kernel, dim3(co_tiles * ci_tiles, splits), dim3(TN_THREADS), TH_LDS, stream, g, p, q, out,
                        co_tiles, ci_tiles);
     return check_launch("igemm_tn(taps9)");
+}
+
+// out[i] += sum_s slabs[s][i]   (float4 per thread; the slabs were written by plain stores, so this is deterministic)
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slabs, int splits, size_t stride,
+                                                          float* __restrict__ out, size_t n4) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        f32x4_t acc = reinterpret_cast<const f32x4_t*>(out)[i];
+        for (int sp = 0; sp < splits; ++sp) {
+            const f32x4_t v = *reinterpret_cast<const f32x4_t*>(slabs + (size_t)sp * stride + i * 4);
+            acc[0] += v[0]; acc[1] += v[1]; acc[2] += v[2]; acc[3] += v[3];
+        }
+        reinterpret_cast<f32x4_t*>(out)[i] = acc;
+    }
 }
 
 static int g_tn_linear = 0;    // measured: no gain over the gather kernel (the TN main loop is not VALU-bound); kept for tests
@@ -600,8 +634,31 @@ static int tn_launch(const TnGeom& g, const void* p, const void* q, float* out, 
     return check_launch("igemm_tn");
 }
 
+// Decide where the K splits put their results: private slabs in the caller's workspace (plain stores + one
+// deterministic reduce pass) when it is large enough, else fp32 atomics straight into `out`.
+static float* tn_pick_dst(TnGeom& g, float* out, int splits, size_t out_elems, float* ws, size_t ws_bytes) {
+    g.slab_stride = 0;
+    // measured: slabs win up to a few dozen splits (163 vs 176 us at 14 splits); with hundreds of splits of a tiny
+    // output the serial slab walk of the reduce pass loses to atomics (372 vs 286 us at 512 splits)
+    if (splits > 1 && splits <= 48 && ws && (out_elems % 4) == 0 && out_elems >= 65536 &&
+        (size_t)splits * out_elems * sizeof(float) <= ws_bytes) {
+        g.slab_stride = (int)out_elems;
+        return ws;
+    }
+    return out;
+}
+
+static int tn_finish(const TnGeom& g, float* out, int splits, size_t out_elems, const float* ws, hipStream_t stream) {
+    if (!g.slab_stride) return FRHIP_OK;
+    const size_t n4 = out_elems / 4;
+    int blocks = (int)((n4 + 255) / 256); if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks), dim3(256), 0, stream, ws, splits, out_elems, out, n4);
+    return check_launch("igemm_tn(slab reduce)");
+}
+
 static int tn_run(int dtype, const void* p, const void* q, float* out, int n, int h, int w, int c, int kc, int ldp,
-                  int r, int s, int stride, int pad, int splits, hipStream_t stream, const char* who) {
+                  int r, int s, int stride, int pad, int splits, float* ws, size_t ws_bytes, hipStream_t stream,
+                  const char* who) {
     const int es = dtype == FRHIP_DT_BF16 ? 2 : 4;
     if (dtype != FRHIP_DT_BF16 && dtype != FRHIP_DT_F32) { set_error("%s: bad dtype %d", who, dtype); return FRHIP_EINVAL; }
     const int epv = 16 / es;
@@ -622,7 +679,11 @@ static int tn_run(int dtype, const void* p, const void* q, float* out, int n, in
     g.adv_ho = (TN_KP % (g.Ho * g.Wo)) / g.Wo;
     g.adv_wo = TN_KP % g.Wo;
     g.ksteps = (g.M + TN_KP - 1) / TN_KP;
+    g.slab_stride = 0;
     const int taps = r * s;
+    const size_t out_elems = (size_t)kc * taps * c;
+    if (out_elems > 0x7fffffffULL) { set_error("%s: output too large", who); return FRHIP_EINVAL; }
+    int rc;
     // measured (tools/bench_kernels.py wgrad, B=512): the nine-tap kernel wins where the per-tap tile is DMA-starved
     // (64 channels: 293 vs 455 us) and loses to the 128x128-per-tap kernel from 128 channels up (LDS-read latency
     // of its 32x32 wave tiles); g_tn_taps9 == 2 forces it everywhere (tests).
@@ -642,7 +703,9 @@ static int tn_run(int dtype, const void* p, const void* q, float* out, int n, in
         if (splits > g.ksteps) splits = g.ksteps;
         g.ksteps_per_split = (g.ksteps + splits - 1) / splits;
         splits = (g.ksteps + g.ksteps_per_split - 1) / g.ksteps_per_split;
-        return tn_taps9_launch(g, p, q, out, splits, stream);
+        float* dst = tn_pick_dst(g, out, splits, out_elems, ws, ws_bytes);
+        rc = tn_taps9_launch(g, p, q, dst, splits, stream);
+        return rc ? rc : tn_finish(g, out, splits, out_elems, ws, stream);
     }
     const bool big = (c * es >= 256) && (kc * es >= 256);
     if (splits <= 0) {
@@ -671,12 +734,14 @@ static int tn_run(int dtype, const void* p, const void* q, float* out, int n, in
     splits = (g.ksteps + g.ksteps_per_split - 1) / g.ksteps_per_split;
     const bool linear = g_tn_linear && dtype == FRHIP_DT_BF16 && stride == 1 && g.Ho == h && g.Wo == w && r == s &&
                         1LL * (M + 64 + 2LL * w + 2) * (ldp > c ? ldp : c) * es < 0x7fffffffLL;
-    if (linear) return big ? tn_lin_launch<256>(g, p, q, out, taps, splits, stream)
-                           : tn_lin_launch<128>(g, p, q, out, taps, splits, stream);
-    if (dtype == FRHIP_DT_BF16) return big ? tn_launch<bf16_t, 256>(g, p, q, out, taps, splits, stream)
-                                           : tn_launch<bf16_t, 128>(g, p, q, out, taps, splits, stream);
-    return big ? tn_launch<float, 256>(g, p, q, out, taps, splits, stream)
-               : tn_launch<float, 128>(g, p, q, out, taps, splits, stream);
+    float* dst = tn_pick_dst(g, out, splits, out_elems, ws, ws_bytes);
+    if (linear) rc = big ? tn_lin_launch<256>(g, p, q, dst, taps, splits, stream)
+                         : tn_lin_launch<128>(g, p, q, dst, taps, splits, stream);
+    else if (dtype == FRHIP_DT_BF16) rc = big ? tn_launch<bf16_t, 256>(g, p, q, dst, taps, splits, stream)
+                                              : tn_launch<bf16_t, 128>(g, p, q, dst, taps, splits, stream);
+    else rc = big ? tn_launch<float, 256>(g, p, q, dst, taps, splits, stream)
+                  : tn_launch<float, 128>(g, p, q, dst, taps, splits, stream);
+    return rc ? rc : tn_finish(g, out, splits, out_elems, ws, stream);
 }
 
 }  // namespace frhip
@@ -691,13 +756,16 @@ extern "C" int frhip_set_tn_linear(int enabled) {
 }
 
 extern "C" int frhip_conv_wgrad(int dtype, const void* dy, const void* x, float* dw, int n, int h, int w, int c,
-                                int k, int r, int s, int stride, int pad, int splits, hipStream_t stream) {
+                                int k, int r, int s, int stride, int pad, int splits, float* workspace,
+                                size_t workspace_bytes, hipStream_t stream) {
     // dw[k][r][s][c] (fp32, caller-zeroed) += sum over output pixels of dy[m][k] * x[pix(m,r,s)][c]
-    return tn_run(dtype, dy, x, dw, n, h, w, c, k, k, r, s, stride, pad, splits, stream, "frhip_conv_wgrad");
+    return tn_run(dtype, dy, x, dw, n, h, w, c, k, k, r, s, stride, pad, splits, workspace, workspace_bytes, stream,
+                  "frhip_conv_wgrad");
 }
 
 extern "C" int frhip_gemm_tn(int dtype, const void* p, const void* q, float* out, int m, int kc, int ldp, int c,
-                             int splits, hipStream_t stream) {
+                             int splits, float* workspace, size_t workspace_bytes, hipStream_t stream) {
     // out[kc][c] (fp32, caller-zeroed) += sum_m p[m][0..kc) (pitch ldp) * q[m][0..c)
-    return tn_run(dtype, p, q, out, m, 1, 1, c, kc, ldp, 1, 1, 1, 0, splits, stream, "frhip_gemm_tn");
+    return tn_run(dtype, p, q, out, m, 1, 1, c, kc, ldp, 1, 1, 1, 0, splits, workspace, workspace_bytes, stream,
+                  "frhip_gemm_tn");
 }

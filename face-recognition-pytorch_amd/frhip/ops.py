@@ -62,12 +62,26 @@ def conv_dgrad(dy, wt, x_shape, r, s, stride, pad, residual=None, out=None):
     return dx
 
 
+_WORKSPACES = {}
+WORKSPACE_BYTES = 160 << 20
+
+
+def workspace(device):
+    """one 160 MB split-K scratch per (device, stream): kernels on different streams never share it"""
+    key = (torch.device(device).index, _s())
+    ws = _WORKSPACES.get(key)
+    if ws is None:
+        ws = _WORKSPACES[key] = torch.empty(WORKSPACE_BYTES // 4, dtype=torch.float32, device=device)
+    return ws
+
+
 def conv_wgrad(dy, x, dw, r, s, stride, pad, splits=0):
     """dw [K,R,S,C] fp32 (zeroed by caller) += wgrad(dy [N,Ho,Wo,K], x [N,H,W,C])"""
     n, h, wd, c = x.shape
     k = dy.shape[3]
-    check(lib().frhip_conv_wgrad(dt_of(x), _p(dy), _p(x), _p(dw), n, h, wd, c, k, r, s, stride, pad, splits, _s()),
-          "frhip_conv_wgrad")
+    ws = workspace(x.device)
+    check(lib().frhip_conv_wgrad(dt_of(x), _p(dy), _p(x), _p(dw), n, h, wd, c, k, r, s, stride, pad, splits,
+                                 _p(ws), ws.numel() * 4, _s()), "frhip_conv_wgrad")
     return dw
 
 
@@ -86,7 +100,9 @@ def gemm_tn(p, q, out, kc=None, splits=0):
     m, ldp = p.shape
     c = q.shape[1]
     kc = ldp if kc is None else kc
-    check(lib().frhip_gemm_tn(dt_of(p), _p(p), _p(q), _p(out), m, kc, ldp, c, splits, _s()), "frhip_gemm_tn")
+    ws = workspace(p.device)
+    check(lib().frhip_gemm_tn(dt_of(p), _p(p), _p(q), _p(out), m, kc, ldp, c, splits, _p(ws), ws.numel() * 4, _s()),
+          "frhip_gemm_tn")
     return out
 
 

@@ -64,16 +64,19 @@ int frhip_conv_fwd(int dtype, const void* x, const void* w, void* y, float* stat
 int frhip_conv_dgrad(int dtype, const void* dy, const void* wt, void* dx, const void* residual,
                      int n, int h, int wd, int c, int k, int r, int s, int stride, int pad, frhip_stream_t stream);
 /* dw[k,r,s,c] (fp32, caller-zeroed) += sum over output pixels dy * x.  autograd of nn.Conv2d w.r.t. weight.
- * splits <= 0: library picks the split-K factor. */
+ * splits <= 0: library picks the split-K factor.  workspace (may be NULL): caller-owned scratch used by THIS call only
+ * (one per stream); when splits * sizeof(dw) fits, each K split stores a private slab with plain stores and one reduce
+ * pass adds them (deterministic, no same-address atomic contention); otherwise fp32 atomics are used. */
 int frhip_conv_wgrad(int dtype, const void* dy, const void* x, float* dw, int n, int h, int w, int c,
-                     int k, int r, int s, int stride, int pad, int splits, frhip_stream_t stream);
+                     int k, int r, int s, int stride, int pad, int splits, float* workspace, size_t workspace_bytes,
+                     frhip_stream_t stream);
 /* out[m][n] = sum_k a[m][k]*b[n][k].  atomic_f32 = 0: out has `dtype`, overwritten (splits ignored);
  * atomic_f32 = 1: out is fp32, caller-zeroed, K is split `splits` ways and added atomically.  nn.Linear: nets/resnet.py:244 */
 int frhip_gemm_nt(int dtype, const void* a, const void* b, void* out, int m, int n, int k, int splits,
                   int atomic_f32, frhip_stream_t stream);
 /* out[kc][c] (fp32, caller-zeroed) += sum_m p[m][0..kc) * q[m][0..c);  p has row pitch ldp elements. */
 int frhip_gemm_tn(int dtype, const void* p, const void* q, float* out, int m, int kc, int ldp, int c,
-                  int splits, frhip_stream_t stream);
+                  int splits, float* workspace, size_t workspace_bytes, frhip_stream_t stream);
 
 /* ---- BatchNorm + element-wise glue.  nn.BatchNorm2d/1d: nets/resnet.py:81-86, :187, :196-199 ---- */
 int frhip_colreduce_blocks(int rows, int c, int dtype);   /* number of partial rows frhip_colstats / _bn_bwd_reduce write */

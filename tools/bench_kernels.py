@@ -81,7 +81,9 @@ for (h, c, k, r, stride) in SHAPES:
     elif what == "wgrad":
         dy = torch.randn(B, ho, ho, k, device="cuda").bfloat16()
         dw = torch.zeros(k, r, r, c, device="cuda")
-        for splits in (0,):
-            us = timeit(lambda: ops.conv_wgrad(dy, x, dw, r, r, stride, pad, splits))
-            line += " wgrad %6.1fus %5.0fTF |" % (us, flops / us / 1e6)
+        for mode in (2, 4):      # 2 = automatic kernel choice, 4 = nine-tap kernel forced where it applies
+            lib().frhip_set_tn_linear(mode)
+            us = timeit(lambda: ops.conv_wgrad(dy, x, dw, r, r, stride, pad, 0))
+            line += " wgrad[m%d] %6.1fus %5.0fTF |" % (mode, us, flops / us / 1e6)
+        lib().frhip_set_tn_linear(2)
     print(line, flush=True)
