@@ -221,6 +221,10 @@ def main():
 
     if rank == 0:
         n, ms, fl = meter.measure()
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        if os.path.exists(tpath):      # HBM bytes per launch of the same kernels from the committed rocprofv3 --pmc passes
+            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
         achieved = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         line = {
             "metric": "train imgs/sec IR-50-layout ResNet50 + ArcFace/PartialFC head, 112x112",
@@ -235,7 +239,7 @@ def main():
                        "launch": "hip-graph" if use_graph else "eager"},
             "final_loss": round(loss, 4),
             "roofline": {"bound": "mfma", "achieved": round(achieved, 1), "peak": BF16_DENSE_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": round(achieved / BF16_DENSE_PEAK_TFLOPS, 4), "traffic": None,
+                         "unit": "TFLOP/s", "frac": round(achieved / BF16_DENSE_PEAK_TFLOPS, 4), "traffic": traffic,
                          "kernel": "frhip::nt_kernel<bf16> (conv forward + data-gradient implicit GEMM)",
                          "launches": n, "avg_launch_us": round(ms * 1e3 / max(n, 1), 2),
                          "flop_per_launch": round(fl / max(n, 1))},

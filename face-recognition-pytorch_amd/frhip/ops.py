@@ -346,3 +346,45 @@ def head_bwd_dt(ehat, what, labels_i32, s, m, rmax, rsum, gscale, upstream=None)
     check(lib().frhip_head_bwd_dt(dt_of(ehat), _p(ehat), _p(what), _p(labels_i32), n, classes, d, s, m, _p(rmax),
                                   _p(rsum), gscale, _p(upstream), _p(dt), ldt, _s()), "frhip_head_bwd_dt")
     return dt
+
+
+# ------------------------------------------------------------------------------------------ explicit-logit margin / CE
+def margin_fwd(logits, labels_i64, s, m, kind):
+    n, c = logits.shape
+    tsave = torch.zeros((n,), dtype=torch.float32, device=logits.device)
+    check(lib().frhip_margin_fwd(_p(logits), _p(labels_i64), n, c, s, m, kind, _p(tsave), _s()), "frhip_margin_fwd")
+    return tsave
+
+
+def margin_bwd(gout, labels_i64, tsave, s, m, kind):
+    n, c = gout.shape
+    gin = torch.empty_like(gout)
+    check(lib().frhip_margin_bwd(_p(gout), _p(labels_i64), _p(tsave), n, c, s, m, kind, _p(gin), _s()), "frhip_margin_bwd")
+    return gin
+
+
+def rows_max(x):
+    n, c = x.shape
+    out = torch.empty((n,), dtype=torch.float32, device=x.device)
+    check(lib().frhip_rows_max(_p(x), n, c, _p(out), _s()), "frhip_rows_max")
+    return out
+
+
+def rows_exp_sum(x, rowmax):
+    n, c = x.shape
+    out = torch.empty((n,), dtype=torch.float32, device=x.device)
+    check(lib().frhip_rows_exp_sum(_p(x), n, c, _p(rowmax), _p(out), _s()), "frhip_rows_exp_sum")
+    return out
+
+
+def rows_normalize(x, rowsum, labels_i64):
+    n, c = x.shape
+    pt = torch.empty((n,), dtype=torch.float32, device=x.device)
+    check(lib().frhip_rows_normalize(_p(x), n, c, _p(rowsum), _p(labels_i64), _p(pt), _s()), "frhip_rows_normalize")
+    return pt
+
+
+def ce_grad(p, labels_i64, inv_n, upstream):
+    n, c = p.shape
+    check(lib().frhip_ce_grad(_p(p), n, c, _p(labels_i64), inv_n, _p(upstream), _s()), "frhip_ce_grad")
+    return p

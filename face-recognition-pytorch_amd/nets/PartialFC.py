@@ -148,13 +148,42 @@ class _MarginSoftmaxFn(torch.autograd.Function):
         return d_e, d_w, None, None, None, None, None
 
 
-class DistCrossEntropy(torch.nn.Module):
-    """Kept for interface parity (reference :487-492).  The fused head never materialises `logit_part`, so this
-    module is not on the hot path; calling it with explicit logits is not supported by the HIP build."""
+class DistCrossEntropyFunc(torch.autograd.Function):
+    """Explicit-logit softmax-CE across class shards (reference :435-484): in place on `logits`, three all-reduces.
+    Row kernels of libfrhip (frhip_rows_max / _rows_exp_sum / _rows_normalize / _ce_grad); the backward scale is
+    read from the device (no `.item()` host sync).  PartialFC.forward does not use this: its CE is fused."""
 
+    @staticmethod
+    def forward(ctx, logits, label):
+        from frhip import ops
+        if not logits.is_cuda:
+            raise RuntimeError("nets.PartialFC.DistCrossEntropy (frhip): logits must live on the MI355X")
+        assert logits.dtype == torch.float32 and logits.is_contiguous()
+        logits = logits.detach()        # overwritten in place like the reference (:449-455); callers never reuse it
+        lab = label.reshape(-1).long().contiguous()
+        multi = distributed.is_initialized() and distributed.get_world_size() > 1
+        rmax = ops.rows_max(logits)
+        if multi:
+            distributed.all_reduce(rmax, distributed.ReduceOp.MAX)
+        rsum = ops.rows_exp_sum(logits, rmax)
+        if multi:
+            distributed.all_reduce(rsum, distributed.ReduceOp.SUM)
+        q = ops.rows_normalize(logits, rsum, lab)
+        if multi:
+            distributed.all_reduce(q, distributed.ReduceOp.SUM)
+        ctx.save_for_backward(logits, lab)
+        return ops.head_loss(q).reshape(())
+
+    @staticmethod
+    def backward(ctx, loss_gradient):
+        from frhip import ops
+        p, lab = ctx.saved_tensors
+        return ops.ce_grad(p, lab, 1.0 / p.shape[0], loss_gradient.reshape(1).float().contiguous()), None
+
+
+class DistCrossEntropy(torch.nn.Module):
     def forward(self, logit_part, label_part):
-        raise NotImplementedError("frhip fuses the distributed softmax-CE into PartialFC.forward; "
-                                  "explicit logits are never materialised on the MI355X path")
+        return DistCrossEntropyFunc.apply(logit_part, label_part)
 
 
 # --------------------------------------------------------------------------------------------- module

@@ -153,6 +153,20 @@ int frhip_head_bwd_dt(int dtype, const void* ehat, const void* what, const int* 
                       int d, float s, float m, const float* rowmax, const float* rowsum, float gscale,
                       const float* upstream, void* dt, int ldt, frhip_stream_t stream);
 
+/* ---- explicit-logit margin and softmax-CE (stand-alone use of nets/ArcFace.py:76-105, nets/PartialFC.py:441-484) ---- */
+/* logits[n][c] fp32 in place: target entry -> margin (kind 0 ArcFace, 1 CosFace), everything x s; tsave[n] = raw target cos.
+ * labels int64 [n], -1 = no target in this shard */
+int frhip_margin_fwd(float* logits, const int64_t* labels, int n, int c, float s, float m, int kind, float* tsave,
+                     frhip_stream_t stream);
+int frhip_margin_bwd(const float* gout, const int64_t* labels, const float* tsave, int n, int c, float s, float m,
+                     int kind, float* gin, frhip_stream_t stream);
+int frhip_rows_max(const float* x, int n, int c, float* rowmax, frhip_stream_t stream);
+int frhip_rows_exp_sum(float* x, int n, int c, const float* rowmax, float* rowsum, frhip_stream_t stream);
+int frhip_rows_normalize(float* x, int n, int c, const float* rowsum, const int64_t* labels, float* ptarget,
+                         frhip_stream_t stream);
+int frhip_ce_grad(float* p, int n, int c, const int64_t* labels, float inv_n, const float* upstream,
+                  frhip_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -80,3 +80,49 @@ def test_head_matches_reference_fixture_ws1(golden):
     np.testing.assert_allclose(loss, g["r0_loss"], rtol=1e-4)
     np.testing.assert_allclose(d_e.numpy(), g["r0_d_emb"], rtol=1e-3, atol=1e-6)
     np.testing.assert_allclose(d_w.numpy(), g["r0_d_w_act"], rtol=1e-3, atol=1e-6)
+
+
+@pytest.mark.parametrize("tag", ["s30_m035", "s64_m05"])
+def test_arcface_module_forward_matches_reference_fixture(golden, tag):
+    """nets.ArcFace.ArcFace.forward on explicit logits vs the reference's edge-case vectors (t at +-1, at the
+    cos(pi-m) threshold and its float neighbours, rows without a target)."""
+    import nets.ArcFace as A
+    g = golden("arcface_edge_" + tag)
+    logits = torch.from_numpy(g["logits_in"]).cuda()
+    labels = torch.from_numpy(g["labels"]).cuda()
+    out = A.ArcFace(float(g["s"]), float(g["m"]))(logits, labels)
+    np.testing.assert_allclose(out.cpu().numpy(), g["logits_out"], rtol=1e-6, atol=1e-6)
+
+
+def test_arcface_cosface_backward_against_autograd_formula():
+    import nets.ArcFace as A
+    gen = torch.Generator().manual_seed(5)
+    cos = (torch.rand((9, 33), generator=gen) * 1.8 - 0.9)
+    lab = torch.randint(0, 33, (9, 1), generator=gen)
+    lab[4, 0] = -1
+    gout = torch.randn((9, 33), generator=gen)
+    for mod, ref in ((A.ArcFace(30.0, 0.35), "arc"), (A.CosFace(30.0, 0.4), "cos")):
+        x = cos.clone().cuda().requires_grad_(True)
+        y = mod(x * 1.0, lab.cuda())
+        y.backward(gout.cuda())
+        xr = cos.clone().requires_grad_(True)
+        z, _ = head_ref.arcface_logits(xr, lab.flatten(), 30.0, 0.35) if ref == "arc" else (None, None)
+        if ref == "cos":
+            zz = xr.clone()
+            rows = torch.nonzero(lab.flatten() >= 0).flatten()
+            zz[rows, lab.flatten()[rows]] = zz[rows, lab.flatten()[rows]] - 0.4
+            z = zz * 30.0
+            z.backward(gout)
+            np.testing.assert_allclose(x.grad.cpu().numpy(), xr.grad.numpy(), rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(y.detach().cpu().numpy(), z.detach().numpy(), rtol=1e-5, atol=1e-5)
+
+
+def test_dist_cross_entropy_module_matches_reference_fixture(golden):
+    import nets.PartialFC as P
+    g = golden("distce_ws1")
+    z = torch.from_numpy(g["z"]).cuda().requires_grad_(True)
+    lab = torch.from_numpy(g["labels"]).cuda()
+    loss = P.DistCrossEntropy()(z.clone(), lab)
+    (loss * float(g["upstream"])).backward()
+    np.testing.assert_allclose(loss.item(), g["loss"], rtol=1e-5)
+    np.testing.assert_allclose(z.grad.cpu().numpy(), g["grad"], rtol=1e-4, atol=1e-7)
