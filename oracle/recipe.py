@@ -59,6 +59,9 @@ def fill_state(spec, seed):
         elif kind == "bn_nbt":
             out[name] = torch.zeros((), dtype=torch.int64)
             continue
+        elif kind in ("coords", "posidx", "logit_scale"):     # deterministic tables: filled by oracle.swin_ref.fill_special
+            out[name] = torch.zeros(shape)
+            continue
         else:
             raise ValueError(kind)
         out[name] = torch.from_numpy(np.asarray(a, dtype=np.float32))

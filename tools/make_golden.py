@@ -259,6 +259,76 @@ def gen_train_steps():
             dist.destroy_process_group()
 
 
+# ----------------------------------------------------------------------------- SwinV2-style backbone
+def _swin_ref():
+    """reference nets/SwinV2.py needs three symbols of timm.models.layers: stubbed, container only"""
+    _ref()
+    import torch.nn as nn
+    if "timm.models.layers" not in sys.modules:
+        class DropPath(nn.Module):
+            def __init__(self, p=0.0):
+                super().__init__()
+            def forward(self, x):
+                return x
+        ml = types.ModuleType("timm.models.layers")
+        ml.DropPath, ml.trunc_normal_ = DropPath, nn.init.trunc_normal_
+        ml.to_2tuple = lambda x: tuple(x) if isinstance(x, (tuple, list)) else (x, x)
+        sys.modules["timm"] = types.ModuleType("timm")
+        sys.modules["timm.models"] = types.ModuleType("timm.models")
+        sys.modules["timm.models.layers"] = ml
+    import nets.SwinV2 as S
+    return S
+
+
+def gen_swin():
+    from oracle import swin_ref
+    S = _swin_ref()
+    # --- one transformer block, training-mode BN, fwd + bwd
+    for tag, (c, heads, hw) in {"c128h4": (128, 4, 14), "c512h16": (512, 16, 7)}.items():
+        blk = S.SwinTransformerBlock(c, c, heads=heads)
+        spec = swin_ref.block_spec("blk", c, heads)
+        sd = swin_ref.fill_special(recipe.fill_state(spec, 6100 + heads), spec)
+        blk.load_state_dict({k[4:]: v for k, v in sd.items()}, strict=True)
+        x = recipe.normal(6101, (3, c, hw, hw)).requires_grad_(True)
+        g = recipe.normal(6102, (3, c, hw, hw))
+        blk.train()
+        y = blk(x)
+        y.backward(g)
+        arrs = dict(c=c, heads=heads, hw=hw, out=y.detach(), dx=x.grad.clone())
+        for k, p in blk.named_parameters():
+            arrs["grad." + k] = p.grad.clone() if p.numel() < 20000 else recipe.summary(p.grad)
+        for k, b in blk.named_buffers():
+            if "running" in k:
+                arrs["after." + k] = b.clone()
+        save("swin_block_" + tag, **arrs)
+    # --- whole nets
+    for name, seed in (("Swin18", 6200), ("Swin34", 6300)):
+        conf = types.SimpleNamespace(network=name, emd_size=512)
+        net = getattr(S, name)(conf)
+        spec = swin_ref.swin_spec(name)
+        assert [k for k, _, _ in spec] == list(net.state_dict().keys()), name
+        assert [tuple(s) for _, s, _ in spec] == [tuple(v.shape) for v in net.state_dict().values()]
+        sd = swin_ref.fill_special(recipe.fill_state(spec, seed), spec)
+        net.load_state_dict(sd, strict=True)
+        x = recipe.images(seed + 1, 2)
+        net.eval()
+        with torch.no_grad():
+            arrs = dict(eval_out=net(x), n_keys=len(spec))
+        if name == "Swin18":
+            net.load_state_dict(sd, strict=True)
+            net.train()
+            net.dropout.p = 0.0          # RNG-free training fixture (the reference's Dropout(0.5) is statistical only)
+            y = net(x)
+            y.backward(recipe.normal(seed + 2, (2, 512), 0.05))
+            arrs["train_out"] = y.detach()
+            for k, p in net.named_parameters():
+                arrs["gsum." + k] = recipe.summary(p.grad)
+            for k, b in net.named_buffers():
+                if "running" in k:
+                    arrs["after." + k] = recipe.summary(b.float())
+        save(name.lower() + "_b2", **arrs)
+
+
 # ----------------------------------------------------------------------------- lr schedule
 def gen_scheduler():
     _ref()
@@ -281,6 +351,7 @@ def gen_scheduler():
 
 GENS = {
     "scheduler": gen_scheduler,
+    "swin": gen_swin,
     "arcface": gen_arcface_edge,
     "distce": gen_distce,
     "head_ws1_rate10": lambda: gen_head(1, 1.0),
