@@ -79,7 +79,7 @@ class HipHeadKernels:
 
 
 def _default_kernels(conf):
-    from .resnet import compute_dtype
+    from ._backbone import compute_dtype
     return HipHeadKernels(compute_dtype(conf))
 
 

@@ -1,0 +1,302 @@
+"""Shared host-side pieces of the frhip backbones (nets.resnet, nets.SwinV2): parameter containers with the
+reference's names, and the forward / backward sequences of the parts every backbone of the reference shares --
+stem (conv3x3 - BN - ReLU - MaxPool, /root/reference/nets/resnet.py:232-235 == nets/SwinV2.py:534-537), the IR
+BasicBlock (nets/resnet.py:89-103) and the tail (bn2 - flatten - fc - bn3, nets/resnet.py:242-246).
+Only orchestration lives here: every tensor op is a libfrhip kernel (frhip.ops)."""
+import os
+
+import torch
+import torch.nn as nn
+
+from frhip import ops
+
+_OVERLAP_WGRAD = os.environ.get("FRHIP_OVERLAP_WGRAD", "1") == "1"
+_DTYPES = {"bf16": torch.bfloat16, "bfloat16": torch.bfloat16, "fp32": torch.float32, "float32": torch.float32}
+
+
+def compute_dtype(conf):
+    """bf16 MFMA by default; conf.frhip_dtype or $FRHIP_DTYPE = 'fp32' selects the exact-fp32 validation mode."""
+    name = getattr(conf, "frhip_dtype", None) or os.environ.get("FRHIP_DTYPE", "bf16")
+    return _DTYPES[str(name).lower()]
+
+
+# ------------------------------------------------------------------------------------------------- containers
+class _Conv(nn.Module):
+    """Parameter holder with the reference's name/shape ([K,C,R,S]); storage is channels_last = [K][R][S][C]."""
+
+    def __init__(self, cin, cout, k, stride, bias=False, pad=None):
+        super().__init__()
+        self.cin, self.cout, self.k, self.stride = cin, cout, k, stride
+        self.pad = (k - 1) // 2 if pad is None else pad
+        w = torch.empty(cout, cin, k, k).contiguous(memory_format=torch.channels_last)
+        self.weight = nn.Parameter(w)
+        if bias:
+            self.bias = nn.Parameter(torch.zeros(cout))
+
+    def physical(self):
+        """fp32 [K,R,S,C] view of the weight (a copy only if someone replaced the channels_last storage)."""
+        p = self.weight.data.permute(0, 2, 3, 1)
+        return p if p.is_contiguous() else p.contiguous()
+
+
+class _BN(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(c))
+        self.bias = nn.Parameter(torch.zeros(c))
+        self.register_buffer("running_mean", torch.zeros(c))
+        self.register_buffer("running_var", torch.ones(c))
+        self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
+        self.eps, self.momentum = 1e-5, 0.1
+
+
+class _Linear(nn.Module):
+    def __init__(self, cin, cout, bias=True):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(cout, cin))
+        if bias:
+            self.bias = nn.Parameter(torch.zeros(cout))
+
+
+class BasicBlock(nn.Module):
+    """conv3x3(inplanes->inplanes) - BN - ReLU - conv3x3(inplanes->planes, stride) - BN, + shortcut
+    (reference nets/resnet.py:55-103).  Holds parameters only; the math runs in basic_block_forward/backward."""
+    expansion = 1
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None):
+        super().__init__()
+        self.conv1 = _Conv(inplanes, inplanes, 3, 1)
+        self.bn1 = _BN(inplanes)
+        self.conv2 = _Conv(inplanes, planes, 3, stride)
+        self.bn2 = _BN(planes)
+        self.downsample = downsample
+        self.stride = stride
+
+
+class Saved:
+    pass
+
+
+# ------------------------------------------------------------------------------------------------- gradients
+def grad_like(p):
+    return torch.zeros_like(p.data, memory_format=torch.preserve_format)
+
+
+def phys_grad(g):
+    pg = g.permute(0, 2, 3, 1)
+    assert pg.is_contiguous()
+    return pg
+
+
+def flat_grads(params, device):
+    """One zeroed fp32 arena for every parameter gradient of the step (a single fill instead of ~160), carved
+    into views that have each parameter's own memory layout (channels_last for conv weights)."""
+    total = sum(p.numel() for p in params)
+    flat = torch.zeros(total, dtype=torch.float32, device=device)
+    views, off = {}, 0
+    for p in params:
+        n = p.numel()
+        chunk = flat[off:off + n]
+        if p.dim() == 4 and p.data.permute(0, 2, 3, 1).is_contiguous():
+            k, c, r, s = p.shape
+            views[p] = chunk.view(k, r, s, c).permute(0, 3, 1, 2)
+        elif p.data.is_contiguous():
+            views[p] = chunk.view(p.shape)
+        else:
+            views[p] = grad_like(p)
+        off += n
+    return views
+
+
+_SIDE_STREAMS = {}
+
+
+def side_stream(device):
+    """one long-lived side stream per device for the weight-gradient GEMMs"""
+    key = torch.device(device).index
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
+    return _SIDE_STREAMS[key]
+
+
+class BackwardCtx:
+    """Gradient arena + the side stream on which weight gradients run.
+
+    Weight gradients do not feed the rest of the backward chain, so they run on a side HIP stream and fill the gaps
+    (partially filled last rounds, HBM-bound BN passes) of the data-gradient chain on the main stream.  Every tensor a
+    side-stream kernel reads is kept referenced until the streams are joined again."""
+
+    def __init__(self, params, device):
+        self.grads = flat_grads(params, device)
+        self.main = torch.cuda.current_stream()
+        self.side = side_stream(device) if _OVERLAP_WGRAD else None
+        self.keep = []
+
+    def G(self, p):
+        return self.grads[p]
+
+    def on_side(self, fn, *tensors):
+        """run fn() on the side stream after everything enqueued so far on the main stream"""
+        if self.side is None:
+            fn()
+            return
+        self.keep.append(tensors)
+        self.side.wait_stream(self.main)
+        with torch.cuda.stream(self.side):
+            fn()
+
+    def wgrad(self, dy, x, gview, r, s, stride, pad):
+        self.on_side(lambda: ops.conv_wgrad(dy, x, gview, r, s, stride, pad), dy, x, gview)
+
+    def join(self):
+        if self.side is not None:
+            self.main.wait_stream(self.side)
+        self.keep = []
+        return self.grads
+
+
+# ------------------------------------------------------------------------------------------------- forward pieces
+def bn_forward_state(bn, part, count, training):
+    if training:
+        st = ops.bn_finalize(part, count, bn.weight.data, bn.bias.data, bn.running_mean, bn.running_var,
+                             bn.momentum, bn.eps)
+        bn.num_batches_tracked += 1
+        return st
+    return ops.bn_eval_affine(bn.weight.data, bn.bias.data, bn.running_mean, bn.running_var, bn.eps)
+
+
+def stem_forward(net, x, training, sv):
+    """conv3x3(3->64) as im2col + GEMM, then fused BN + ReLU + MaxPool(3,2,1) -> NHWC [B, H/2, W/2, 64]"""
+    dt = net.dtype
+    b, _, h, w = x.shape
+    col = ops.stem_im2col(x, dt)
+    wp0 = ops.pack_stem(net.conv1.physical().reshape(64, 27), dt)
+    y0, part = ops.conv_fwd(col.view(b * h * w, 1, 1, col.shape[1]), wp0, 1, 0, want_stats=training)
+    y0 = y0.view(b, h, w, 64)
+    st0 = bn_forward_state(net.bn1, part, b * h * w, training)
+    cur, arg0 = ops.bn_relu_maxpool_fwd(y0, st0)
+    if sv is not None:
+        sv.col, sv.y0, sv.st0, sv.arg0 = col, y0, st0, arg0
+    return cur
+
+
+def stem_backward(net, sv, dout, bc):
+    da0 = ops.maxpool_bwd(dout, sv.arg0, sv.y0.shape)
+    dy0 = ops.bn_backward(da0, sv.y0, sv.st0, net.bn1.weight.data, bc.G(net.bn1.weight), bc.G(net.bn1.bias), relu_mask=True)
+    m, kp = sv.col.shape
+    dwp0 = torch.zeros((64, 1, 1, kp), dtype=torch.float32, device=dout.device)
+    ops.conv_wgrad(dy0.view(m, 1, 1, 64), sv.col.view(m, 1, 1, kp), dwp0, 1, 1, 1, 0)
+    ops.unpack_stem_grad(dwp0, phys_grad(bc.G(net.conv1.weight)).view(64, 27))
+
+
+def basic_block_forward(blk, xin, dt, training, save):
+    w1 = ops.cast_from_f32(blk.conv1.physical(), dt)
+    y1, p1 = ops.conv_fwd(xin, w1, 1, 1, want_stats=training)
+    st1 = bn_forward_state(blk.bn1, p1, y1.numel() // y1.shape[3], training)
+    a1 = ops.bn_apply(y1, st1, relu=True)
+    w2 = ops.cast_from_f32(blk.conv2.physical(), dt)
+    y2, p2 = ops.conv_fwd(a1, w2, blk.stride, 1, want_stats=training)
+    st2 = bn_forward_state(blk.bn2, p2, y2.numel() // y2.shape[3], training)
+    yd = std = None
+    if blk.downsample is not None:
+        dconv, dbn = blk.downsample[0], blk.downsample[1]
+        wd = ops.cast_from_f32(dconv.physical(), dt)
+        yd, pd = ops.conv_fwd(xin, wd, dconv.stride, 0, want_stats=training)
+        std = bn_forward_state(dbn, pd, yd.numel() // yd.shape[3], training)
+        out = ops.bn_apply(y2, st2, res=yd, res_st=std)
+    else:
+        out = ops.bn_apply(y2, st2, res=xin)
+    s = None
+    if save:
+        s = Saved()
+        s.x, s.y1, s.st1, s.a1, s.y2, s.st2, s.yd, s.std = xin, y1, st1, a1, y2, st2, yd, std
+    return out, s
+
+
+def basic_block_backward(blk, s, dout, dt, bc):
+    G = bc.G
+    dy2 = ops.bn_backward(dout, s.y2, s.st2, blk.bn2.weight.data, G(blk.bn2.weight), G(blk.bn2.bias))
+    shortcut = dout
+    if blk.downsample is not None:
+        dconv, dbn = blk.downsample[0], blk.downsample[1]
+        dyd = ops.bn_backward(dout, s.yd, s.std, dbn.weight.data, G(dbn.weight), G(dbn.bias))
+        wdt = ops.pack_wt(dconv.physical(), dt)
+        shortcut = ops.conv_dgrad(dyd, wdt, s.x.shape, 1, 1, dconv.stride, 0)
+        bc.wgrad(dyd, s.x, phys_grad(G(dconv.weight)), 1, 1, dconv.stride, 0)
+    w2t = ops.pack_wt(blk.conv2.physical(), dt)
+    da1 = ops.conv_dgrad(dy2, w2t, s.a1.shape, 3, 3, blk.stride, 1)
+    bc.wgrad(dy2, s.a1, phys_grad(G(blk.conv2.weight)), 3, 3, blk.stride, 1)
+    dy1 = ops.bn_backward(da1, s.y1, s.st1, blk.bn1.weight.data, G(blk.bn1.weight), G(blk.bn1.bias), relu_mask=True)
+    w1t = ops.pack_wt(blk.conv1.physical(), dt)
+    dx = ops.conv_dgrad(dy1, w1t, s.x.shape, 3, 3, 1, 1, residual=shortcut)
+    bc.wgrad(dy1, s.x, phys_grad(G(blk.conv1.weight)), 3, 3, 1, 1)
+    return dx
+
+
+def tail_forward(net, cur, training, sv, dropout_mask=None):
+    """bn2 -> [dropout] -> flatten (NHWC order; fc columns permuted to match) -> fc -> bn3 (fp32 embeddings)"""
+    dt = net.dtype
+    bo, ho, wo, co = cur.shape
+    rows = bo * ho * wo
+    part = ops.colstats(cur.view(rows, co)) if training else None
+    stt = bn_forward_state(net.bn2, part, rows, training)
+    z = ops.bn_apply(cur, stt)
+    if dropout_mask is not None:
+        z = z * dropout_mask
+    flat = z.view(bo, ho * wo * co)
+    wfc = ops.fc_permute(net.fc.weight.data, co, ho * wo, dt)
+    f = ops.gemm_nt(flat, wfc, splits=16, atomic_f32=True)
+    ops.add_bias(f, net.fc.bias.data)
+    part = ops.colstats(f) if training else None
+    st3 = bn_forward_state(net.bn3, part, bo, training)
+    emb = ops.bn_apply(f, st3)
+    if sv is not None:
+        sv.out4, sv.stt, sv.flat, sv.wfc, sv.f, sv.st3, sv.dropout_mask = cur, stt, flat, wfc, f, st3, dropout_mask
+    return emb
+
+
+def tail_backward(net, sv, d_emb, bc):
+    dt = net.dtype
+    G = bc.G
+    df = ops.bn_backward(d_emb.contiguous().float(), sv.f, sv.st3, net.bn3.weight.data, G(net.bn3.weight), G(net.bn3.bias))
+    ops.colsum_accumulate(df, G(net.fc.bias))
+    dft = ops.cast_from_f32(df, dt)
+    b, kfc = sv.flat.shape
+    wfct = ops.transpose2d(sv.wfc)                                  # [25088][512]
+    dflat = ops.gemm_nt(dft, wfct)                                  # [B][25088]
+    dwp = torch.zeros((net.emd_size, kfc), dtype=torch.float32, device=d_emb.device)
+    ops.gemm_tn(dft, sv.flat, dwp)
+    co = sv.out4.shape[3]
+    ops.fc_unpermute_grad(dwp, G(net.fc.weight), co, kfc // co)
+    dz = dflat.view(sv.out4.shape)
+    if sv.dropout_mask is not None:
+        dz = dz * sv.dropout_mask
+    return ops.bn_backward(dz, sv.out4, sv.stt, net.bn2.weight.data, G(net.bn2.weight), G(net.bn2.bias))
+
+
+class EncoderFn(torch.autograd.Function):
+    """The whole backbone as ONE autograd node: forward keeps what backward needs, backward runs the hand-written
+    gradient kernels and returns every parameter gradient."""
+
+    @staticmethod
+    def forward(ctx, net, x, *params):
+        emb, sv = net._forward_impl(x, True, True)
+        ctx.net, ctx.sv, ctx.params = net, sv, params
+        return emb
+
+    @staticmethod
+    def backward(ctx, d_emb):
+        grads = ctx.net._backward_impl(ctx.sv, d_emb, ctx.params)
+        ctx.sv = None
+        return (None, None) + tuple(grads.get(p) for p in ctx.params)
+
+
+def encoder_call(net, x):
+    if not x.is_cuda:
+        raise RuntimeError("frhip backbone: input must live on the MI355X; there is no CPU path "
+                           "(the CPU restatement lives in oracle/ and is test-only)")
+    x = x.contiguous().float()
+    if net.training and torch.is_grad_enabled():
+        return EncoderFn.apply(net, x, *[p for p in net.parameters()])
+    out, _ = net._forward_impl(x, net.training, False)
+    return out

@@ -167,6 +167,20 @@ int frhip_rows_normalize(float* x, int n, int c, const float* rowsum, const int6
 int frhip_ce_grad(float* p, int n, int c, const int64_t* labels, float inv_n, const float* upstream,
                   frhip_stream_t stream);
 
+/* ---- SwinV2 window attention (7x7 windows, head dim 32).  nets/SwinV2.py:139-179 with window_partition/reverse
+ * (:35-62) as index arithmetic ---- */
+/* qkv [b*h*w][3c] (pixel order), bias fp32 [heads][49][49] = 16*sigmoid(cpb table)[index], scale fp32 [heads] =
+ * exp(min(logit_scale, ln 100)); out [b*h*w][c] */
+int frhip_winattn_fwd(int dtype, const void* qkv, const float* bias, const float* scale, void* out, int b, int h,
+                      int w, int c, int heads, frhip_stream_t stream);
+/* dqkv [b*h*w][3c]; dbias [heads][49][49] and dscale [heads] are fp32, caller-zeroed, accumulated atomically */
+int frhip_winattn_bwd(int dtype, const void* qkv, const void* dout, const float* bias, const float* scale,
+                      void* dqkv, float* dbias, float* dscale, int b, int h, int w, int c, int heads,
+                      frhip_stream_t stream);
+/* y[rows][c] += bias (in place); act_out (may be NULL) = gelu(y).  Mlp fc1 + GELU: nets/SwinV2.py:16-32 */
+int frhip_bias_gelu_fwd(int dtype, void* y, const float* bias, void* act_out, int rows, int c, frhip_stream_t stream);
+int frhip_gelu_bwd(int dtype, const void* da, const void* h, void* dh, size_t n, frhip_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
