@@ -388,3 +388,36 @@ def ce_grad(p, labels_i64, inv_n, upstream):
     n, c = p.shape
     check(lib().frhip_ce_grad(_p(p), n, c, _p(labels_i64), inv_n, _p(upstream), _s()), "frhip_ce_grad")
     return p
+
+
+# ------------------------------------------------------------------------------------------ SwinV2 window attention
+def winattn_fwd(qkv, bias, scale, b, h, w, heads):
+    c = qkv.shape[1] // 3
+    out = torch.empty((qkv.shape[0], c), dtype=qkv.dtype, device=qkv.device)
+    check(lib().frhip_winattn_fwd(dt_of(qkv), _p(qkv), _p(bias), _p(scale), _p(out), b, h, w, c, heads, _s()),
+          "frhip_winattn_fwd")
+    return out
+
+
+def winattn_bwd(qkv, dout, bias, scale, b, h, w, heads):
+    c = qkv.shape[1] // 3
+    dqkv = torch.empty_like(qkv)
+    dbias = torch.zeros_like(bias)
+    dscale = torch.zeros_like(scale)
+    check(lib().frhip_winattn_bwd(dt_of(qkv), _p(qkv), _p(dout), _p(bias), _p(scale), _p(dqkv), _p(dbias), _p(dscale),
+                                  b, h, w, c, heads, _s()), "frhip_winattn_bwd")
+    return dqkv, dbias, dscale
+
+
+def bias_gelu_fwd(y, bias, want_act):
+    """y [rows, c] += bias in place; returns gelu(y) when want_act"""
+    rows, c = y.shape
+    act = torch.empty_like(y) if want_act else None
+    check(lib().frhip_bias_gelu_fwd(dt_of(y), _p(y), _p(bias), _p(act), rows, c, _s()), "frhip_bias_gelu_fwd")
+    return act
+
+
+def gelu_bwd(da, h):
+    dh = torch.empty_like(h)
+    check(lib().frhip_gelu_bwd(dt_of(h), _p(da), _p(h), _p(dh), h.numel(), _s()), "frhip_gelu_bwd")
+    return dh

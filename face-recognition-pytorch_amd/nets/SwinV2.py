@@ -1,0 +1,304 @@
+"""MI355X-native drop-in for the reference SwinV2-style backbone `nets/SwinV2.py`.
+
+Same surface as /root/reference/nets/SwinV2.py: `Swin18/34/50/100/200(conf)`, `Encoder(conf)` (:570-656), modules
+`WindowAttention`, `SwinTransformerBlock`, `Mlp`; `forward(x: float32[B,3,112,112]) -> float32[B, emd_size]`; the
+state_dict has the reference's keys and shapes (`layerL.I.attn.{logit_scale,q_bias,v_bias,relative_coords_table,
+relative_position_index,cpb_mlp.0.weight,cpb_mlp.0.bias,cpb_mlp.2.weight,qkv.weight,proj.weight,proj.bias}`,
+`norm2.*`, `mlp.fc1/fc2.{weight,bias}`, `norm3.*`, the 2x2/s2 stage convolutions as `layerL.0.weight`).
+
+Underneath (window_size 7, shift 0 -- the only configuration the reference can run):
+  * activations stay NHWC; window_partition / window_reverse (:35-62) are index arithmetic inside the attention
+    kernel, so the permute/contiguous copies of the reference do not exist;
+  * qkv / proj / fc1 / fc2 are the MFMA NT GEMM on [B*H*W, C] rows, their weight gradients the TN GEMM, the
+    data gradients the NT GEMM with the residual add fused; biases and the exact-erf GELU are one element-wise
+    pass; BN post-norm + residual is the fused bn_apply of the ResNet path;
+  * cosine attention with the continuous-position bias and the clamped learnable scale is frhip_winattn_fwd/_bwd;
+  * the 169-entry continuous-position-bias MLP (2 -> 512 -> heads) is parameter-space work done once per block
+    and step; it runs as three torch ops on the device and its gradient through torch.autograd.grad.
+The whole backbone is one autograd node (nets/_backbone.EncoderFn).  No CPU fallback.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from frhip import ops
+
+from ._backbone import (BackwardCtx, BasicBlock, Saved, _BN, _Conv, _Linear, bn_forward_state, compute_dtype,  # noqa: F401
+                        encoder_call, phys_grad, stem_backward, stem_forward, tail_backward, tail_forward)
+
+LN100 = math.log(1.0 / 0.01)
+
+
+class Mlp(nn.Module):
+    """1x1-conv MLP, hidden = 4*dim, GELU (reference :16-32): parameter holder."""
+
+    def __init__(self, in_features, hidden_features=None, out_features=None, act_layer=None, drop=0.0):
+        super().__init__()
+        out_features = out_features or in_features
+        hidden_features = hidden_features or in_features
+        self.fc1 = _Conv(in_features, hidden_features, 1, 1, bias=True)
+        self.fc2 = _Conv(hidden_features, out_features, 1, 1, bias=True)
+
+
+class WindowAttention(nn.Module):
+    """Cosine window attention with continuous relative position bias (reference :65-179): parameter holder +
+    the two table buffers, registered in the reference's order."""
+
+    def __init__(self, dim, window_size, num_heads, dim_head=32, qkv_bias=True, attn_drop=0.0, proj_drop=0.0,
+                 pretrained_window_size=(0, 0)):
+        super().__init__()
+        assert dim_head * num_heads == dim, "Not match dim_head * num_heads and hidden_dim"
+        assert tuple(window_size) == (7, 7) and dim_head == 32, "frhip window attention: 7x7 windows, head dim 32"
+        self.dim, self.window_size, self.num_heads = dim, tuple(window_size), num_heads
+        self.logit_scale = nn.Parameter(torch.log(10 * torch.ones((num_heads, 1, 1))))
+        self.cpb_mlp = nn.Sequential(nn.Linear(2, 512, bias=True), nn.ReLU(inplace=True), nn.Linear(512, num_heads, bias=False))
+        ws = 7
+        r = torch.arange(-(ws - 1), ws, dtype=torch.float32) / (ws - 1) * 8
+        table = torch.stack(torch.meshgrid([r, r], indexing="ij")).permute(1, 2, 0).contiguous().unsqueeze(0)
+        table = torch.sign(table) * torch.log2(torch.abs(table) + 1.0) / np.log2(8)
+        self.register_buffer("relative_coords_table", table)
+        c = torch.stack(torch.meshgrid([torch.arange(ws), torch.arange(ws)], indexing="ij")).flatten(1)
+        rel = (c[:, :, None] - c[:, None, :]).permute(1, 2, 0) + (ws - 1)
+        self.register_buffer("relative_position_index", rel[:, :, 0] * (2 * ws - 1) + rel[:, :, 1])
+        self.qkv = _Linear(dim, dim * 3, bias=False)
+        if qkv_bias:
+            self.q_bias = nn.Parameter(torch.zeros(dim))
+            self.v_bias = nn.Parameter(torch.zeros(dim))
+        else:
+            self.q_bias = self.v_bias = None
+        self.proj = _Linear(dim, dim)
+
+    def cpb_params(self):
+        return [self.cpb_mlp[0].weight, self.cpb_mlp[0].bias, self.cpb_mlp[2].weight, self.logit_scale]
+
+    def bias_and_scale(self, params):
+        """[heads,49,49] fp32 bias = 16*sigmoid(cpb_mlp(table))[index] and [heads] scale = exp(min(logit_scale, ln 100))"""
+        w0, b0, w2, ls = params
+        t = F.linear(F.relu(F.linear(self.relative_coords_table, w0, b0)), w2).view(-1, self.num_heads)
+        b = t[self.relative_position_index.view(-1)].view(49, 49, self.num_heads).permute(2, 0, 1).contiguous()
+        return 16 * torch.sigmoid(b), torch.clamp(ls, max=LN100).exp().reshape(-1)
+
+
+class SwinTransformerBlock(nn.Module):
+    """x = x + BN(attn(x)); x = x + BN(mlp(x))  (reference :183-300, shift_size 0): parameter holder."""
+
+    def __init__(self, dim, dim_out, heads, window_size=7, shift_size=0, qkv_bias=True, drop=0.0, attn_drop=0.0,
+                 drop_path=0.0, norm_layer=None, pretrained_window_size=0, activation=None):
+        super().__init__()
+        if shift_size != 0:
+            raise NotImplementedError("shifted windows: the reference itself cannot run them (SURVEY.md F8)")
+        self.dim, self.num_heads, self.window_size, self.shift_size = dim, heads, window_size, shift_size
+        self.attn = WindowAttention(dim, (window_size, window_size), heads, qkv_bias=qkv_bias)
+        self.norm2 = _BN(dim)
+        self.mlp = Mlp(in_features=dim, out_features=dim_out, hidden_features=dim * 4)
+        self.norm3 = _BN(dim)
+        self.register_buffer("attn_mask", None)
+
+
+# ------------------------------------------------------------------------------------------------- block math
+def _w2d(conv_or_lin, dt):
+    w = conv_or_lin.weight.data
+    return ops.cast_from_f32(w.reshape(w.shape[0], -1).contiguous(), dt)
+
+
+def _colsum_via_gemm(x2d, out_accum):
+    """out_accum[c] += sum_rows x2d[:, c] for rows wider than the element-wise reducer handles (3C up to 1536)"""
+    ones = torch.ones((x2d.shape[0], 8), dtype=x2d.dtype, device=x2d.device)
+    tmp = torch.zeros((x2d.shape[1], 8), dtype=torch.float32, device=x2d.device)
+    ops.gemm_tn(x2d, ones, tmp)
+    out_accum += tmp[:, 0]
+
+
+def swin_block_forward(blk, x, dt, training, save):
+    b, h, w, c = x.shape
+    m = b * h * w
+    at = blk.attn
+    x2 = x.view(m, c)
+    wqkv = _w2d(at.qkv, dt)
+    qkv = ops.gemm_nt(x2, wqkv)
+    qb = torch.cat([at.q_bias.data, torch.zeros_like(at.v_bias.data), at.v_bias.data])
+    ops.bias_gelu_fwd(qkv, qb, False)
+    with torch.enable_grad():
+        cpb = [p.detach().requires_grad_(True) for p in at.cpb_params()]
+        bias_t, scale_t = at.bias_and_scale(cpb)
+    bias, scale = bias_t.detach().contiguous(), scale_t.detach().contiguous()
+    ao = ops.winattn_fwd(qkv, bias, scale, b, h, w, at.num_heads)
+    wproj = _w2d(at.proj, dt)
+    po = ops.gemm_nt(ao, wproj)
+    ops.bias_gelu_fwd(po, at.proj.bias.data, False)
+    st2 = bn_forward_state(blk.norm2, ops.colstats(po) if training else None, m, training)
+    x1 = ops.bn_apply(po, st2, res=x2)
+    w1 = _w2d(blk.mlp.fc1, dt)
+    hid = ops.gemm_nt(x1, w1)
+    act = ops.bias_gelu_fwd(hid, blk.mlp.fc1.bias.data, True)
+    w2 = _w2d(blk.mlp.fc2, dt)
+    mo = ops.gemm_nt(act, w2)
+    ops.bias_gelu_fwd(mo, blk.mlp.fc2.bias.data, False)
+    st3 = bn_forward_state(blk.norm3, ops.colstats(mo) if training else None, m, training)
+    out = ops.bn_apply(mo, st3, res=x1).view(b, h, w, c)
+    s = None
+    if save:
+        s = Saved()
+        (s.x2, s.wqkv, s.qkv, s.cpb, s.bias_t, s.scale_t, s.bias, s.scale, s.ao, s.wproj, s.po, s.st2, s.x1, s.w1, s.hid,
+         s.act, s.w2, s.mo, s.st3, s.shape) = (x2, wqkv, qkv, cpb, bias_t, scale_t, bias, scale, ao, wproj, po, st2, x1, w1,
+                                                hid, act, w2, mo, st3, (b, h, w, c))
+    return out, s
+
+
+def _dgrad_add(dy2d, w2d, residual2d):
+    """dy [M,K] @ w [K,C] + residual [M,C], as a 1x1 data-gradient with the residual add fused"""
+    m, k = dy2d.shape
+    c = w2d.shape[1]
+    wt = ops.transpose2d(w2d)                       # [C][K]: K-contiguous rows of the transposed weight
+    return ops.conv_dgrad(dy2d.view(m, 1, 1, k), wt.view(c, 1, 1, k), (m, 1, 1, c), 1, 1, 1, 0,
+                          residual=residual2d.view(m, 1, 1, c)).view(m, c)
+
+
+def swin_block_backward(blk, s, dout, dt, bc):
+    G = bc.G
+    b, h, w, c = s.shape
+    m = b * h * w
+    at = blk.attn
+    d2 = dout.reshape(m, c)
+    # ---- MLP branch: x2 = x1 + BN(fc2(gelu(fc1(x1))))
+    dmo = ops.bn_backward(d2, s.mo, s.st3, blk.norm3.weight.data, G(blk.norm3.weight), G(blk.norm3.bias))
+    ops.colsum_accumulate(dmo, G(blk.mlp.fc2.bias))
+    bc.on_side(lambda: ops.gemm_tn(dmo, s.act, G(blk.mlp.fc2.weight).view(c, 4 * c)), dmo, s.act)
+    dact = ops.gemm_nt(dmo, ops.transpose2d(s.w2))                 # [M, 4C]
+    dhid = ops.gelu_bwd(dact, s.hid)
+    _colsum_via_gemm(dhid, G(blk.mlp.fc1.bias))
+    bc.on_side(lambda: ops.gemm_tn(dhid, s.x1, G(blk.mlp.fc1.weight).view(4 * c, c)), dhid, s.x1)
+    dx1 = _dgrad_add(dhid, s.w1, d2)
+    # ---- attention branch: x1 = x + BN(proj(attn(qkv(x))))
+    dpo = ops.bn_backward(dx1, s.po, s.st2, blk.norm2.weight.data, G(blk.norm2.weight), G(blk.norm2.bias))
+    ops.colsum_accumulate(dpo, G(at.proj.bias))
+    bc.on_side(lambda: ops.gemm_tn(dpo, s.ao, G(at.proj.weight)), dpo, s.ao)
+    dao = ops.gemm_nt(dpo, ops.transpose2d(s.wproj))
+    dqkv, dbias, dscale = ops.winattn_bwd(s.qkv, dao, s.bias, s.scale, b, h, w, at.num_heads)
+    gsum = torch.zeros(3 * c, dtype=torch.float32, device=dout.device)
+    _colsum_via_gemm(dqkv, gsum)
+    G(at.q_bias).add_(gsum[:c])
+    G(at.v_bias).add_(gsum[2 * c:])
+    bc.on_side(lambda: ops.gemm_tn(dqkv, s.x2, G(at.qkv.weight)), dqkv, s.x2)
+    dx = _dgrad_add(dqkv, s.wqkv, dx1)
+    # ---- the 169-entry position-bias MLP and the logit scale (parameter space, torch autograd)
+    gs = torch.autograd.grad([s.bias_t, s.scale_t], s.cpb, [dbias, dscale])
+    for p, g in zip(at.cpb_params(), gs):
+        G(p).add_(g.reshape(p.shape))
+    return dx.view(b, h, w, c)
+
+
+# ------------------------------------------------------------------------------------------------- network
+class Swin(nn.Module):
+    def __init__(self, conf, block, block2, num_blocks, heads):
+        super().__init__()
+        self.emd_size = conf.emd_size
+        self.dtype = compute_dtype(conf)
+        self.inplanes = 64
+        self.conv1 = _Conv(3, 64, 3, 1)
+        self.bn1 = _BN(64)
+        self.layer1 = self.stack_layers(block, block2, 64, num_blocks[0], heads[0])
+        self.layer2 = self.stack_layers(block, block2, 128, num_blocks[1], heads[1], stride=2)
+        self.layer3 = self.stack_layers(block, block2, 256, num_blocks[2], heads[2], stride=2)
+        self.layer4 = self.stack_layers(block, block2, conf.emd_size, num_blocks[3], heads[3], stride=2)
+        self.bn2 = _BN(block.expansion * conf.emd_size)
+        self.dropout = nn.Dropout()
+        self.fc = _Linear(block.expansion * conf.emd_size * 7 * 7, conf.emd_size)
+        self.bn3 = _BN(conf.emd_size)
+        for m in self.modules():             # same initialisation rule as the reference (:518-532)
+            if isinstance(m, (_Conv, _Linear, nn.Linear)):
+                nn.init.xavier_normal_(m.weight)
+                if getattr(m, "bias", None) is not None:
+                    nn.init.constant_(m.bias, 0)
+
+    def stack_layers(self, block, block2, planes, blocks, heads, stride=1):
+        layers = []
+        if stride > 1:
+            layers.append(_Conv(self.inplanes, planes, 2, 2, pad=0))
+        self.inplanes = planes * block.expansion
+        for _ in range(blocks):
+            layers.append(block2(self.inplanes, planes, heads=heads))
+        return nn.Sequential(*layers)
+
+    def _layers(self):
+        for layer in (self.layer1, self.layer2, self.layer3, self.layer4):
+            for mod in layer:
+                yield mod
+
+    def forward(self, x):
+        return encoder_call(self, x)
+
+    def _forward_impl(self, x, training, save):
+        dt = self.dtype
+        sv = Saved() if save else None
+        cur = stem_forward(self, x, training, sv)
+        saved = []
+        for mod in self._layers():
+            if isinstance(mod, _Conv):           # 2x2 / stride-2 stage convolution, no norm (reference :545-546)
+                wd = ops.cast_from_f32(mod.physical(), dt)
+                nxt, _ = ops.conv_fwd(cur, wd, 2, 0, want_stats=False)
+                saved.append(cur if save else None)
+                cur = nxt
+            else:
+                cur, s = swin_block_forward(mod, cur, dt, training, save)
+                saved.append(s)
+        if cur.shape[1] != 7 or cur.shape[2] != 7:
+            raise NotImplementedError("AdaptiveAvgPool2d((7,7)) is the identity only for 112x112 inputs")
+        mask = None
+        if training and self.dropout.p > 0:
+            keep = 1.0 - self.dropout.p
+            mask = (torch.rand(cur.shape, device=cur.device) < keep).to(cur.dtype) / keep
+        emb = tail_forward(self, cur, training, sv, dropout_mask=mask)
+        if save:
+            sv.layers = saved
+        return emb, sv
+
+    def _backward_impl(self, sv, d_emb, params):
+        dt = self.dtype
+        bc = BackwardCtx(params, d_emb.device)
+        dout = tail_backward(self, sv, d_emb, bc)
+        for mod, s in zip(reversed(list(self._layers())), reversed(sv.layers)):
+            if isinstance(mod, _Conv):
+                wt = ops.pack_wt(mod.physical(), dt)
+                bc.wgrad(dout, s, phys_grad(bc.G(mod.weight)), 2, 2, 2, 0)
+                dout = ops.conv_dgrad(dout, wt, s.shape, 2, 2, 2, 0)
+            else:
+                dout = swin_block_backward(mod, s, dout, dt, bc)
+        stem_backward(self, sv, dout, bc)
+        return bc.join()
+
+
+def _make(conf, blocks, **kw):
+    return Swin(conf, BasicBlock, SwinTransformerBlock, num_blocks=blocks, heads=(2, 4, 8, 16), **kw)
+
+
+def Swin18(conf, **kwargs):
+    return _make(conf, [0, 1, 1, 1], **kwargs)
+
+
+def Swin34(conf, **kwargs):
+    return _make(conf, [0, 0, 4, 6], **kwargs)
+
+
+def Swin50(conf, **kwargs):
+    return _make(conf, [0, 0, 4, 10], **kwargs)
+
+
+def Swin100(conf, **kwargs):
+    return _make(conf, [0, 0, 6, 14], **kwargs)
+
+
+def Swin200(conf, **kwargs):
+    return _make(conf, [0, 0, 6, 30], **kwargs)
+
+
+def Encoder(conf):
+    """Name dispatch of the reference (:645-656: Swin200/100/50/34) -- plus 'Swin18', whose constructor exists there
+    but which its dispatcher forgets."""
+    table = {"Swin200": Swin200, "Swin100": Swin100, "Swin50": Swin50, "Swin34": Swin34, "Swin18": Swin18}
+    if conf.network in table:
+        return table[conf.network](conf)
+    return None

@@ -53,6 +53,8 @@ CONV_CASES = [
     (9, 7, 7, 512, 512, 3, 1, 1),      # 441 pixels: ragged last tile, 5+ images per tile
     (3, 7, 7, 128, 64, 3, 1, 1),       # narrow output, multi-chunk
     (2, 12, 12, 64, 128, 3, 1, 1),     # wide output, single chunk
+    (3, 14, 14, 64, 128, 2, 2, 0),     # 2x2 / stride-2 stage convolution of the Swin backbone
+    (2, 28, 28, 128, 256, 2, 2, 0),
 ]
 
 
