@@ -37,7 +37,7 @@ BATCH = 512
 def make_conf(args, rank, world):
     rate = 1.0 if world == 1 else 0.1            # cfg 2 (1 GPU, full head) / cfg 3 (PartialFC rate 0.1 over the node)
     return types.SimpleNamespace(
-        network="ResNet50", emd_size=512, img_size=112, local_rank=rank % max(torch.cuda.device_count(), 1),
+        network=args.network, emd_size=512, img_size=112, local_rank=rank % max(torch.cuda.device_count(), 1),
         world_size=world, sample_rate=rate, mixed_precision=True, loss_s=30.0, loss_m=0.35, n_classes=args.classes,
         optimizer="SGD", lr=0.1, wd=5e-4, mom=0.9, loss="PartialFC", lr_scheduler=None, frhip_dtype="bf16",
         ckpt_path=None)
@@ -143,6 +143,7 @@ def main():
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--classes", type=int, default=NUM_CLASSES)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--network", default="ResNet50", help="ResNet50 (headline, BASELINE cfg 2/3) or Swin34 (cfg 4)")
     ap.add_argument("--graph", action="store_true",
                     help="replay the step as one HIP graph (default: eager launches; eager is GPU-bound at B=512 and "
                          "lets the side-stream weight-gradient GEMMs overlap the main stream)")
@@ -231,8 +232,9 @@ def main():
             "value": round(args.batch * world * args.steps / dt, 1), "unit": "imgs/sec", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "BASELINE cfg %d: ResNet50([3,4,14,4] BasicBlock)+%s, %d ids, B=%d/GPU, SGD "
-                                   "mom 0.9 wd 5e-4, s=30 m=0.35" % (2 if world == 1 else 3,
+            "config": {"workload": "BASELINE cfg %d: %s+%s, %d ids, B=%d/GPU, SGD "
+                                   "mom 0.9 wd 5e-4, s=30 m=0.35" % ((2 if world == 1 else 3) if args.network == "ResNet50" else 4,
+                                                                     "ResNet50([3,4,14,4] BasicBlock)" if args.network == "ResNet50" else args.network,
                                                                      "ArcFace (PartialFC rate 1.0)" if world == 1 else "PartialFC rate 0.1",
                                                                      args.classes, args.batch),
                        "global_batch": args.batch * world, "parallelism": "dp%d+class-shard%d" % (world, world),
@@ -244,7 +246,7 @@ def main():
                          "launches": n, "avg_launch_us": round(ms * 1e3 / max(n, 1), 2),
                          "flop_per_launch": round(fl / max(n, 1))},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.network == "ResNet50":
             line["cpu_baseline"] = cpu_baseline(args.classes)
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -6,17 +6,19 @@
 
 namespace frhip {
 
-// x: NCHW fp32 [B,3,H,W]  ->  col: [B*H*W][KP] of T, k = (r*3+s)*3 + ci for k < 27, zero for k >= 27.
+// x: NCHW fp32 [B,3,H,W]  ->  col: [B*Ho*Wo][KP] of T (3x3, pad 1, stride 1 or 2), k = (r*3+s)*3 + ci for k < 27,
+// zero for k >= 27.
 template <typename T>
 __global__ __launch_bounds__(256) void stem_im2col_kernel(const float* __restrict__ x, T* __restrict__ col,
-                                                          int B, int H, int W) {
+                                                          int B, int H, int W, int stride) {
     constexpr int EPV = 16 / (int)sizeof(T);
     constexpr int VPP = 8;                                // vectors per pixel (KP = 8*EPV: 64 bf16 / 32 f32)
-    const size_t total = (size_t)B * H * W * VPP;
+    const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+    const size_t total = (size_t)B * Ho * Wo * VPP;
     for (size_t t = (size_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (size_t)gridDim.x * 256) {
         const int v = (int)(t % VPP);
         const size_t pix = t / VPP;
-        const int w = (int)(pix % W), h = (int)((pix / W) % H), n = (int)(pix / ((size_t)W * H));
+        const int w = (int)(pix % Wo) * stride, h = (int)((pix / Wo) % Ho) * stride, n = (int)(pix / ((size_t)Wo * Ho));
         Vec16<T> o;
 #pragma unroll
         for (int e = 0; e < EPV; ++e) {
@@ -118,12 +120,13 @@ static int stem_grid(size_t total) {
 
 using namespace frhip;
 
-extern "C" int frhip_stem_im2col(int dtype, const float* x, void* col, int b, int h, int w, hipStream_t stream) {
-    const size_t total = (size_t)b * h * w * 8;
+extern "C" int frhip_stem_im2col(int dtype, const float* x, void* col, int b, int h, int w, int stride, hipStream_t stream) {
+    if (stride != 1 && stride != 2) { set_error("frhip_stem_im2col: stride must be 1 or 2"); return FRHIP_EINVAL; }
+    const size_t total = (size_t)b * ((h - 1) / stride + 1) * ((w - 1) / stride + 1) * 8;
     if (dtype == FRHIP_DT_BF16)
-        hipLaunchKernelGGL(stem_im2col_kernel<bf16_t>, dim3(stem_grid(total)), dim3(256), 0, stream, x, (bf16_t*)col, b, h, w);
+        hipLaunchKernelGGL(stem_im2col_kernel<bf16_t>, dim3(stem_grid(total)), dim3(256), 0, stream, x, (bf16_t*)col, b, h, w, stride);
     else if (dtype == FRHIP_DT_F32)
-        hipLaunchKernelGGL(stem_im2col_kernel<float>, dim3(stem_grid(total)), dim3(256), 0, stream, x, (float*)col, b, h, w);
+        hipLaunchKernelGGL(stem_im2col_kernel<float>, dim3(stem_grid(total)), dim3(256), 0, stream, x, (float*)col, b, h, w, stride);
     else { set_error("frhip_stem_im2col: bad dtype %d", dtype); return FRHIP_EINVAL; }
     return check_launch("frhip_stem_im2col");
 }

@@ -14,7 +14,7 @@
 
 namespace frhip {
 
-constexpr int WA_N = 49, WA_D = 32, WA_WS = 7;
+constexpr int WA_N = 49, WA_D = 32;     // largest window (7x7 tokens); smaller windows (6x6, 3x3) use the same tiles
 constexpr int WA_LD = WA_D + 1;        // padded row of the [49][32] LDS tiles
 constexpr int WA_LM = WA_N + 1;        // padded row of the [49][49] LDS tile
 
@@ -42,52 +42,71 @@ template <> __device__ __forceinline__ void store32<bf16_t>(bf16_t* p, const flo
         *reinterpret_cast<bf16x8_t*>(p + 8 * c) = t; }
 }
 
-__device__ __forceinline__ size_t wa_pixel(int win, int tok, int H, int W) {
-    const int wpr = W / WA_WS, wpi = (H / WA_WS) * wpr;
+// Window geometry: `ws` x `ws` tokens, optional cyclic shift (SW-MSA, nets/AlterNet_SwinV2_FAN.py:420-440): token
+// (ty,tx) of window (wy,wx) of the ROLLED image is pixel ((wy*ws+ty+shift) % H, (wx*ws+tx+shift) % W) of the original,
+// and the output goes back to that same pixel (the reverse roll).  `region` is the 3x3 region id of the rolled
+// position used by the reference's attention mask (:375-397): tokens of different regions get -100 added.
+struct WaGeom { int H, W, ws, shift, n; };
+
+__device__ __forceinline__ size_t wa_pixel(int win, int tok, const WaGeom& g, int* region) {
+    const int wpr = g.W / g.ws, wpi = (g.H / g.ws) * wpr;
     const int b = win / wpi, r = win - b * wpi, wy = r / wpr, wx = r - wy * wpr;
-    const int ty = tok / WA_WS, tx = tok - ty * WA_WS;
-    return ((size_t)b * H + wy * WA_WS + ty) * W + wx * WA_WS + tx;
+    const int ty = tok / g.ws, tx = tok - ty * g.ws;
+    const int hs = wy * g.ws + ty, wsx = wx * g.ws + tx;                 // position in the rolled image
+    int hh = hs + g.shift, ww = wsx + g.shift;
+    if (hh >= g.H) hh -= g.H;
+    if (ww >= g.W) ww -= g.W;
+    if (region) {
+        const int rh = hs < g.H - g.ws ? 0 : (hs < g.H - g.shift ? 1 : 2);
+        const int rw = wsx < g.W - g.ws ? 0 : (wsx < g.W - g.shift ? 1 : 2);
+        *region = g.shift > 0 ? rh * 3 + rw : 0;
+    }
+    return ((size_t)b * g.H + hh) * g.W + ww;
 }
 
-// Score row of this lane's query against all 49 keys, softmax'ed, kept in the lane's own LDS row `srow`
+// Score row of this lane's query against all n keys, softmax'ed, kept in the lane's own LDS row `srow`
 // (loops over keys stay rolled: a 49-element register array per lane makes hipcc unroll 49x32 FMAs and spill).
-//   srow[j] <- softmax_j( scale * <qh, kh_j> + bias[j] )
+//   srow[j] <- softmax_j( scale * <qh, kh_j> + bias[j] + (region_j != region_i ? -100 : 0) )
 __device__ __forceinline__ void wa_softmax_row(const float* qh, const float* sk, const float* bias_row, float scale,
-                                               float* srow) {
+                                               float* srow, int n, const int* sreg, int my_region) {
     float mx = -INFINITY;
 #pragma unroll 1
-    for (int j = 0; j < WA_N; ++j) {
+    for (int j = 0; j < n; ++j) {
         float d = 0.f;
 #pragma unroll
         for (int e = 0; e < WA_D; ++e) d += qh[e] * sk[j * WA_LD + e];
-        const float sv = d * scale + bias_row[j];
+        const float sv = d * scale + bias_row[j] + (sreg[j] != my_region ? -100.f : 0.f);
         srow[j] = sv;
         mx = fmaxf(mx, sv);
     }
     float sum = 0.f;
 #pragma unroll 1
-    for (int j = 0; j < WA_N; ++j) { const float ev = __expf(srow[j] - mx); srow[j] = ev; sum += ev; }
+    for (int j = 0; j < n; ++j) { const float ev = __expf(srow[j] - mx); srow[j] = ev; sum += ev; }
     const float inv = 1.f / sum;
 #pragma unroll 1
-    for (int j = 0; j < WA_N; ++j) srow[j] *= inv;
+    for (int j = 0; j < n; ++j) srow[j] *= inv;
 }
 
 template <typename T>
 __global__ __launch_bounds__(256) void winattn_fwd_kernel(const T* __restrict__ qkv, const float* __restrict__ bias,
                                                           const float* __restrict__ scale, T* __restrict__ out,
-                                                          int nwin, int H, int W, int C, int heads) {
+                                                          int nwin, WaGeom g, int C, int heads) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    constexpr int PER_WAVE = 2 * WA_N * WA_LD + (WA_N + 1) * WA_LM;
+    constexpr int PER_WAVE = 2 * WA_N * WA_LD + (WA_N + 1) * WA_LM + 64;
     float* sk = reinterpret_cast<float*>(smem_raw) + wave * PER_WAVE;
     float* sv = sk + WA_N * WA_LD;
     float* ss = sv + WA_N * WA_LD;                    // [50][50]: score / probability rows (row 49 = idle lanes)
+    int* sreg = reinterpret_cast<int*>(ss + (WA_N + 1) * WA_LM);      // mask region of every token
     const int pair = blockIdx.x * 4 + wave;
     if (pair >= nwin * heads) return;                 // whole wave exits together
     const int win = pair / heads, h = pair - win * heads;
-    const bool active = lane < WA_N;
+    const int n = g.n;
+    const bool active = lane < n;
     const int tok = active ? lane : 0;
-    const size_t pix = wa_pixel(win, tok, H, W);
+    int region;
+    const size_t pix = wa_pixel(win, tok, g, &region);
+    if (active) sreg[tok] = region;
     const T* row = qkv + pix * 3 * C + h * WA_D;
     float q[WA_D], t[WA_D];
     load32<T>(row, q);
@@ -110,12 +129,12 @@ __global__ __launch_bounds__(256) void winattn_fwd_kernel(const T* __restrict__ 
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     float* srow = ss + (active ? tok : WA_N) * WA_LM;
-    wa_softmax_row(q, sk, bias + ((size_t)h * WA_N + tok) * WA_N, scale[h], srow);
+    wa_softmax_row(q, sk, bias + ((size_t)h * n + tok) * n, scale[h], srow, n, sreg, region);
     float o[WA_D];
 #pragma unroll
     for (int e = 0; e < WA_D; ++e) o[e] = 0.f;
 #pragma unroll 1
-    for (int j = 0; j < WA_N; ++j) {
+    for (int j = 0; j < n; ++j) {
         const float pj = srow[j];
 #pragma unroll
         for (int e = 0; e < WA_D; ++e) o[e] += pj * sv[j * WA_LD + e];
@@ -129,28 +148,31 @@ template <typename T>
 __global__ __launch_bounds__(256, 1) void winattn_bwd_kernel(const T* __restrict__ qkv, const T* __restrict__ dout,
                                                           const float* __restrict__ bias, const float* __restrict__ scale,
                                                           T* __restrict__ dqkv, float* __restrict__ dbias,
-                                                          float* __restrict__ dscale, int nwin, int H, int W, int C,
+                                                          float* __restrict__ dscale, int nwin, WaGeom g, int C,
                                                           int heads, int win_per_block) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    constexpr int PER_WAVE = 2 * WA_N * WA_LD + 2 * (WA_N + 1) * WA_LM;
+    constexpr int PER_WAVE = 2 * WA_N * WA_LD + 2 * (WA_N + 1) * WA_LM + 64;
     float* sa = reinterpret_cast<float*>(smem_raw) + wave * PER_WAVE;      // k-hat, later q-hat
     float* sb = sa + WA_N * WA_LD;                                          // v, later dO
     float* sp = sb + WA_N * WA_LD;                                          // P   [50][50]
     float* sd = sp + (WA_N + 1) * WA_LM;                                    // dP, then dS [50][50]
+    int* sreg = reinterpret_cast<int*>(sd + (WA_N + 1) * WA_LM);
     const int h = blockIdx.x;
-    const bool active = lane < WA_N;
+    const int n = g.n;
+    const bool active = lane < n;
     const int tok = active ? lane : 0;
     const int myrow = (active ? tok : WA_N) * WA_LM;
     const float sc = scale[h];
-    const float* bias_row = bias + ((size_t)h * WA_N + tok) * WA_N;
+    const float* bias_row = bias + ((size_t)h * n + tok) * n;
     float db[WA_N];
 #pragma unroll
     for (int j = 0; j < WA_N; ++j) db[j] = 0.f;
     float dsc = 0.f;
     const int w_begin = blockIdx.y * win_per_block, w_end = min(nwin, w_begin + win_per_block);
     for (int win = w_begin + wave; win < w_end; win += 4) {
-        const size_t pix = wa_pixel(win, tok, H, W);
+        int region;
+        const size_t pix = wa_pixel(win, tok, g, &region);
         const T* row = qkv + pix * 3 * C + h * WA_D;
         float q[WA_D], kh[WA_D], go[WA_D];
         load32<T>(row, q);
@@ -164,17 +186,18 @@ __global__ __launch_bounds__(256, 1) void winattn_bwd_kernel(const T* __restrict
         load32<T>(row + 2 * C, go);                                           // v (staged through `go`)
         __builtin_amdgcn_wave_barrier();                                      // previous window's LDS reads are done
         if (active) {
+            sreg[tok] = region;
 #pragma unroll
             for (int e = 0; e < WA_D; ++e) { sa[tok * WA_LD + e] = kh[e]; sb[tok * WA_LD + e] = go[e]; }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        wa_softmax_row(q, sa, bias_row, sc, sp + myrow);
+        wa_softmax_row(q, sa, bias_row, sc, sp + myrow, n, sreg, region);
         load32<T>(dout + pix * C + h * WA_D, go);
         // dP_ij = <dO_i, v_j>; dS = P o (dP - rowsum(P o dP))
         float rd = 0.f;
 #pragma unroll 1
-        for (int j = 0; j < WA_N; ++j) {
+        for (int j = 0; j < n; ++j) {
             float d = 0.f;
 #pragma unroll
             for (int e = 0; e < WA_D; ++e) d += go[e] * sb[j * WA_LD + e];
@@ -186,7 +209,7 @@ __global__ __launch_bounds__(256, 1) void winattn_bwd_kernel(const T* __restrict
         for (int e = 0; e < WA_D; ++e) acc[e] = 0.f;
         float dsc_w = 0.f;
 #pragma unroll 1
-        for (int j = 0; j < WA_N; ++j) {
+        for (int j = 0; j < n; ++j) {
             const float dsj = sp[myrow + j] * (sd[myrow + j] - rd);
             sd[myrow + j] = dsj;
             float c = 0.f;
@@ -197,7 +220,7 @@ __global__ __launch_bounds__(256, 1) void winattn_bwd_kernel(const T* __restrict
         if (active) {
             dsc += dsc_w;
 #pragma unroll
-            for (int j = 0; j < WA_N; ++j) db[j] += sd[myrow + j];            // static register indices
+            for (int j = 0; j < WA_N; ++j) if (j < n) db[j] += sd[myrow + j];  // static register indices
         }
         float dotq = 0.f;
 #pragma unroll
@@ -217,7 +240,7 @@ __global__ __launch_bounds__(256, 1) void winattn_bwd_kernel(const T* __restrict
 #pragma unroll
         for (int e = 0; e < WA_D; ++e) acc[e] = 0.f;
 #pragma unroll 1
-        for (int i = 0; i < WA_N; ++i) {
+        for (int i = 0; i < n; ++i) {
             const float pij = sp[i * WA_LM + tok];
 #pragma unroll
             for (int e = 0; e < WA_D; ++e) acc[e] += pij * sb[i * WA_LD + e];
@@ -227,7 +250,7 @@ __global__ __launch_bounds__(256, 1) void winattn_bwd_kernel(const T* __restrict
 #pragma unroll
         for (int e = 0; e < WA_D; ++e) acc[e] = 0.f;
 #pragma unroll 1
-        for (int i = 0; i < WA_N; ++i) {
+        for (int i = 0; i < n; ++i) {
             const float dij = sd[i * WA_LM + tok];
 #pragma unroll
             for (int e = 0; e < WA_D; ++e) acc[e] += dij * sa[i * WA_LD + e];
@@ -251,11 +274,11 @@ __global__ __launch_bounds__(256, 1) void winattn_bwd_kernel(const T* __restrict
     __shared__ float red_s[4];
     if (lane == 0) red_s[wave] = dsc;
     __syncthreads();
-    for (int idx = threadIdx.x; idx < WA_N * WA_N; idx += 256) {
-        const int i = idx / WA_N, j = idx - i * WA_N;
+    for (int idx = threadIdx.x; idx < n * n; idx += 256) {
+        const int i = idx / n, j = idx - i * n;
         const float v = red[(0 * WA_N + i) * WA_LM + j] + red[(1 * WA_N + i) * WA_LM + j] + red[(2 * WA_N + i) * WA_LM + j] +
                         red[(3 * WA_N + i) * WA_LM + j];
-        atomicAdd(dbias + (size_t)h * WA_N * WA_N + idx, v);
+        atomicAdd(dbias + (size_t)h * n * n + idx, v);
     }
     if (threadIdx.x == 0) atomicAdd(dscale + h, red_s[0] + red_s[1] + red_s[2] + red_s[3]);
 }
@@ -305,19 +328,22 @@ static int ew_blocks(size_t nvec) { size_t b = (nvec + 255) / 256; if (b > 4096)
 
 using namespace frhip;
 
-static bool wa_shape_ok(int dtype, int b, int h, int w, int c, int heads, const char* who) {
-    if ((dtype != FRHIP_DT_BF16 && dtype != FRHIP_DT_F32) || b <= 0 || (h % WA_WS) || (w % WA_WS) || heads <= 0 || c != heads * WA_D) {
-        set_error("%s: needs 7x7 windows (h,w multiples of 7) and head dim 32 (c=%d heads=%d h=%d w=%d)", who, c, heads, h, w);
+static bool wa_shape_ok(int dtype, int b, int h, int w, int c, int heads, int ws, int shift, const char* who) {
+    if ((dtype != FRHIP_DT_BF16 && dtype != FRHIP_DT_F32) || b <= 0 || ws < 1 || ws > 7 || (h % ws) || (w % ws) || heads <= 0 ||
+        c != heads * WA_D || shift < 0 || shift >= ws) {
+        set_error("%s: needs ws <= 7 dividing h and w, 0 <= shift < ws, head dim 32 (c=%d heads=%d h=%d w=%d ws=%d shift=%d)",
+                  who, c, heads, h, w, ws, shift);
         return false;
     }
     return true;
 }
 
 extern "C" int frhip_winattn_fwd(int dtype, const void* qkv, const float* bias, const float* scale, void* out, int b, int h,
-                                 int w, int c, int heads, hipStream_t stream) {
-    if (!wa_shape_ok(dtype, b, h, w, c, heads, "frhip_winattn_fwd")) return FRHIP_EINVAL;
-    const int nwin = b * (h / WA_WS) * (w / WA_WS);
-    const int blocks = (nwin * heads + 3) / 4, lds = 4 * (2 * WA_N * WA_LD + (WA_N + 1) * WA_LM) * 4;
+                                 int w, int c, int heads, int ws, int shift, hipStream_t stream) {
+    if (!wa_shape_ok(dtype, b, h, w, c, heads, ws, shift, "frhip_winattn_fwd")) return FRHIP_EINVAL;
+    const int nwin = b * (h / ws) * (w / ws);
+    WaGeom g; g.H = h; g.W = w; g.ws = ws; g.shift = shift; g.n = ws * ws;
+    const int blocks = (nwin * heads + 3) / 4, lds = 4 * (2 * WA_N * WA_LD + (WA_N + 1) * WA_LM + 64) * 4;
     static bool fattr[2] = {false, false};
     if (!fattr[dtype]) {
         const void* fn = dtype == FRHIP_DT_BF16 ? reinterpret_cast<const void*>(winattn_fwd_kernel<bf16_t>) : reinterpret_cast<const void*>(winattn_fwd_kernel<float>);
@@ -325,21 +351,22 @@ extern "C" int frhip_winattn_fwd(int dtype, const void* qkv, const float* bias, 
         fattr[dtype] = true;
     }
     if (dtype == FRHIP_DT_BF16)
-        hipLaunchKernelGGL(winattn_fwd_kernel<bf16_t>, dim3(blocks), dim3(256), lds, stream, (const bf16_t*)qkv, bias, scale, (bf16_t*)out, nwin, h, w, c, heads);
+        hipLaunchKernelGGL(winattn_fwd_kernel<bf16_t>, dim3(blocks), dim3(256), lds, stream, (const bf16_t*)qkv, bias, scale, (bf16_t*)out, nwin, g, c, heads);
     else
-        hipLaunchKernelGGL(winattn_fwd_kernel<float>, dim3(blocks), dim3(256), lds, stream, (const float*)qkv, bias, scale, (float*)out, nwin, h, w, c, heads);
+        hipLaunchKernelGGL(winattn_fwd_kernel<float>, dim3(blocks), dim3(256), lds, stream, (const float*)qkv, bias, scale, (float*)out, nwin, g, c, heads);
     return check_launch("frhip_winattn_fwd");
 }
 
 extern "C" int frhip_winattn_bwd(int dtype, const void* qkv, const void* dout, const float* bias, const float* scale,
                                  void* dqkv, float* dbias, float* dscale, int b, int h, int w, int c, int heads,
-                                 hipStream_t stream) {
-    if (!wa_shape_ok(dtype, b, h, w, c, heads, "frhip_winattn_bwd")) return FRHIP_EINVAL;
-    const int nwin = b * (h / WA_WS) * (w / WA_WS);
+                                 int ws, int shift, hipStream_t stream) {
+    if (!wa_shape_ok(dtype, b, h, w, c, heads, ws, shift, "frhip_winattn_bwd")) return FRHIP_EINVAL;
+    const int nwin = b * (h / ws) * (w / ws);
+    WaGeom g; g.H = h; g.W = w; g.ws = ws; g.shift = shift; g.n = ws * ws;
     int chunks = (1024 + heads - 1) / heads;                 // ~1024 workgroups
     int wpb = (nwin + chunks - 1) / chunks; if (wpb < 4) wpb = 4;
     chunks = (nwin + wpb - 1) / wpb;
-    const int lds = 4 * (2 * WA_N * WA_LD + 2 * (WA_N + 1) * WA_LM) * 4;
+    const int lds = 4 * (2 * WA_N * WA_LD + 2 * (WA_N + 1) * WA_LM + 64) * 4;
     static bool attr_done[2] = {false, false};
     const void* fn = dtype == FRHIP_DT_BF16 ? reinterpret_cast<const void*>(winattn_bwd_kernel<bf16_t>) : reinterpret_cast<const void*>(winattn_bwd_kernel<float>);
     if (!attr_done[dtype]) {
@@ -347,9 +374,9 @@ extern "C" int frhip_winattn_bwd(int dtype, const void* qkv, const void* dout, c
         attr_done[dtype] = true;
     }
     if (dtype == FRHIP_DT_BF16)
-        hipLaunchKernelGGL(winattn_bwd_kernel<bf16_t>, dim3(heads, chunks), dim3(256), lds, stream, (const bf16_t*)qkv, (const bf16_t*)dout, bias, scale, (bf16_t*)dqkv, dbias, dscale, nwin, h, w, c, heads, wpb);
+        hipLaunchKernelGGL(winattn_bwd_kernel<bf16_t>, dim3(heads, chunks), dim3(256), lds, stream, (const bf16_t*)qkv, (const bf16_t*)dout, bias, scale, (bf16_t*)dqkv, dbias, dscale, nwin, g, c, heads, wpb);
     else
-        hipLaunchKernelGGL(winattn_bwd_kernel<float>, dim3(heads, chunks), dim3(256), lds, stream, (const float*)qkv, (const float*)dout, bias, scale, (float*)dqkv, dbias, dscale, nwin, h, w, c, heads, wpb);
+        hipLaunchKernelGGL(winattn_bwd_kernel<float>, dim3(heads, chunks), dim3(256), lds, stream, (const float*)qkv, (const float*)dout, bias, scale, (float*)dqkv, dbias, dscale, nwin, g, c, heads, wpb);
     return check_launch("frhip_winattn_bwd");
 }
 

@@ -206,12 +206,13 @@ def cast_to_f32(src, out=None):
 
 
 # ------------------------------------------------------------------------------------------ stem
-def stem_im2col(x_nchw, dtype):
+def stem_im2col(x_nchw, dtype, stride=1):
     b, c, h, w = x_nchw.shape
     assert c == 3 and x_nchw.dtype == torch.float32
     kp = 64 if dtype == torch.bfloat16 else 32
-    col = torch.empty((b * h * w, kp), dtype=dtype, device=x_nchw.device)
-    check(lib().frhip_stem_im2col(_DT[dtype], _p(x_nchw), _p(col), b, h, w, _s()), "frhip_stem_im2col")
+    ho, wo = (h - 1) // stride + 1, (w - 1) // stride + 1
+    col = torch.empty((b * ho * wo, kp), dtype=dtype, device=x_nchw.device)
+    check(lib().frhip_stem_im2col(_DT[dtype], _p(x_nchw), _p(col), b, h, w, stride, _s()), "frhip_stem_im2col")
     return col
 
 
@@ -391,21 +392,21 @@ def ce_grad(p, labels_i64, inv_n, upstream):
 
 
 # ------------------------------------------------------------------------------------------ SwinV2 window attention
-def winattn_fwd(qkv, bias, scale, b, h, w, heads):
+def winattn_fwd(qkv, bias, scale, b, h, w, heads, ws=7, shift=0):
     c = qkv.shape[1] // 3
     out = torch.empty((qkv.shape[0], c), dtype=qkv.dtype, device=qkv.device)
-    check(lib().frhip_winattn_fwd(dt_of(qkv), _p(qkv), _p(bias), _p(scale), _p(out), b, h, w, c, heads, _s()),
+    check(lib().frhip_winattn_fwd(dt_of(qkv), _p(qkv), _p(bias), _p(scale), _p(out), b, h, w, c, heads, ws, shift, _s()),
           "frhip_winattn_fwd")
     return out
 
 
-def winattn_bwd(qkv, dout, bias, scale, b, h, w, heads):
+def winattn_bwd(qkv, dout, bias, scale, b, h, w, heads, ws=7, shift=0):
     c = qkv.shape[1] // 3
     dqkv = torch.empty_like(qkv)
     dbias = torch.zeros_like(bias)
     dscale = torch.zeros_like(scale)
     check(lib().frhip_winattn_bwd(dt_of(qkv), _p(qkv), _p(dout), _p(bias), _p(scale), _p(dqkv), _p(dbias), _p(dscale),
-                                  b, h, w, c, heads, _s()), "frhip_winattn_bwd")
+                                  b, h, w, c, heads, ws, shift, _s()), "frhip_winattn_bwd")
     return dqkv, dbias, dscale
 
 

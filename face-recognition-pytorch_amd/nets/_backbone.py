@@ -169,7 +169,9 @@ def stem_forward(net, x, training, sv):
     """conv3x3(3->64) as im2col + GEMM, then fused BN + ReLU + MaxPool(3,2,1) -> NHWC [B, H/2, W/2, 64]"""
     dt = net.dtype
     b, _, h, w = x.shape
-    col = ops.stem_im2col(x, dt)
+    stride = net.conv1.stride
+    col = ops.stem_im2col(x, dt, stride)
+    h, w = (h - 1) // stride + 1, (w - 1) // stride + 1
     wp0 = ops.pack_stem(net.conv1.physical().reshape(64, 27), dt)
     y0, part = ops.conv_fwd(col.view(b * h * w, 1, 1, col.shape[1]), wp0, 1, 0, want_stats=training)
     y0 = y0.view(b, h, w, 64)
@@ -233,14 +235,14 @@ def basic_block_backward(blk, s, dout, dt, bc):
     return dx
 
 
-def tail_forward(net, cur, training, sv, dropout_mask=None):
-    """bn2 -> [dropout] -> flatten (NHWC order; fc columns permuted to match) -> fc -> bn3 (fp32 embeddings)"""
+def tail_forward(net, cur, training, sv, dropout_mask=None, relu=False):
+    """bn2 -> [relu] -> [dropout] -> flatten (NHWC order; fc columns permuted to match) -> fc -> bn3 (fp32 embeddings)"""
     dt = net.dtype
     bo, ho, wo, co = cur.shape
     rows = bo * ho * wo
     part = ops.colstats(cur.view(rows, co)) if training else None
     stt = bn_forward_state(net.bn2, part, rows, training)
-    z = ops.bn_apply(cur, stt)
+    z = ops.bn_apply(cur, stt, relu=relu)
     if dropout_mask is not None:
         z = z * dropout_mask
     flat = z.view(bo, ho * wo * co)
@@ -251,7 +253,7 @@ def tail_forward(net, cur, training, sv, dropout_mask=None):
     st3 = bn_forward_state(net.bn3, part, bo, training)
     emb = ops.bn_apply(f, st3)
     if sv is not None:
-        sv.out4, sv.stt, sv.flat, sv.wfc, sv.f, sv.st3, sv.dropout_mask = cur, stt, flat, wfc, f, st3, dropout_mask
+        sv.out4, sv.stt, sv.flat, sv.wfc, sv.f, sv.st3, sv.dropout_mask, sv.tail_relu = cur, stt, flat, wfc, f, st3, dropout_mask, relu
     return emb
 
 
@@ -271,7 +273,8 @@ def tail_backward(net, sv, d_emb, bc):
     dz = dflat.view(sv.out4.shape)
     if sv.dropout_mask is not None:
         dz = dz * sv.dropout_mask
-    return ops.bn_backward(dz, sv.out4, sv.stt, net.bn2.weight.data, G(net.bn2.weight), G(net.bn2.bias))
+    return ops.bn_backward(dz, sv.out4, sv.stt, net.bn2.weight.data, G(net.bn2.weight), G(net.bn2.bias),
+                           relu_mask=sv.tail_relu)
 
 
 class EncoderFn(torch.autograd.Function):

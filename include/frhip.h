@@ -110,8 +110,9 @@ int frhip_cast_from_f32(int dtype, const float* src, void* dst, size_t n, frhip_
 int frhip_cast_to_f32(int dtype, const void* src, float* dst, size_t n, frhip_stream_t stream);
 
 /* ---- stem.  conv1 + bn1 + relu + maxpool: nets/resnet.py:186-189, :232-235 ---- */
-/* x NCHW fp32 [b,3,h,w] -> col [b*h*w][64 (bf16) | 32 (f32)], k = (r*3+s)*3+ci, zero beyond 27 */
-int frhip_stem_im2col(int dtype, const float* x, void* col, int b, int h, int w, frhip_stream_t stream);
+/* x NCHW fp32 [b,3,h,w] -> col [b*ho*wo][64 (bf16) | 32 (f32)], k = (r*3+s)*3+ci, zero beyond 27; stride 1
+ * (nets/resnet.py:186) or 2 (nets/AlterNet_SwinV2_FAN.py:652) */
+int frhip_stem_im2col(int dtype, const float* x, void* col, int b, int h, int w, int stride, frhip_stream_t stream);
 int frhip_bn_relu_maxpool_fwd(int dtype, const void* y, const float* scale, const float* shift, void* out,
                               uint8_t* argmax, int b, int h, int w, int c, frhip_stream_t stream);
 int frhip_maxpool_bwd(int dtype, const void* dpool, const uint8_t* argmax, void* da, int b, int h, int w,
@@ -167,16 +168,17 @@ int frhip_rows_normalize(float* x, int n, int c, const float* rowsum, const int6
 int frhip_ce_grad(float* p, int n, int c, const int64_t* labels, float inv_n, const float* upstream,
                   frhip_stream_t stream);
 
-/* ---- SwinV2 window attention (7x7 windows, head dim 32).  nets/SwinV2.py:139-179 with window_partition/reverse
- * (:35-62) as index arithmetic ---- */
-/* qkv [b*h*w][3c] (pixel order), bias fp32 [heads][49][49] = 16*sigmoid(cpb table)[index], scale fp32 [heads] =
- * exp(min(logit_scale, ln 100)); out [b*h*w][c] */
+/* ---- SwinV2 window attention (ws x ws windows, ws <= 7, head dim 32).  nets/SwinV2.py:139-179 and
+ * nets/AlterNet_SwinV2_FAN.py:263-302; window_partition/reverse, the cyclic roll and the SW-MSA mask
+ * (nets/AlterNet_SwinV2_FAN.py:375-397, :420-440) are index arithmetic inside the kernel ---- */
+/* qkv [b*h*w][3c] (pixel order), bias fp32 [heads][n][n] (n = ws*ws) = 16*sigmoid(cpb table)[index], scale fp32 [heads] =
+ * exp(min(logit_scale, ln 100)); shift = 0 (W-MSA) or ws/2 (SW-MSA); out [b*h*w][c] */
 int frhip_winattn_fwd(int dtype, const void* qkv, const float* bias, const float* scale, void* out, int b, int h,
-                      int w, int c, int heads, frhip_stream_t stream);
-/* dqkv [b*h*w][3c]; dbias [heads][49][49] and dscale [heads] are fp32, caller-zeroed, accumulated atomically */
+                      int w, int c, int heads, int ws, int shift, frhip_stream_t stream);
+/* dqkv [b*h*w][3c]; dbias [heads][n][n] and dscale [heads] are fp32, caller-zeroed, accumulated atomically */
 int frhip_winattn_bwd(int dtype, const void* qkv, const void* dout, const float* bias, const float* scale,
                       void* dqkv, float* dbias, float* dscale, int b, int h, int w, int c, int heads,
-                      frhip_stream_t stream);
+                      int ws, int shift, frhip_stream_t stream);
 /* y[rows][c] += bias (in place); act_out (may be NULL) = gelu(y).  Mlp fc1 + GELU: nets/SwinV2.py:16-32 */
 int frhip_bias_gelu_fwd(int dtype, void* y, const float* bias, void* act_out, int rows, int c, frhip_stream_t stream);
 int frhip_gelu_bwd(int dtype, const void* da, const void* h, void* dh, size_t n, frhip_stream_t stream);

@@ -59,7 +59,7 @@ def fill_state(spec, seed):
         elif kind == "bn_nbt":
             out[name] = torch.zeros((), dtype=torch.int64)
             continue
-        elif kind in ("coords", "posidx", "logit_scale"):     # deterministic tables: filled by oracle.swin_ref.fill_special
+        elif kind in ("coords", "posidx", "logit_scale") or ":" in kind:     # deterministic tables: see oracle.*_ref.fill_special
             out[name] = torch.zeros(shape)
             continue
         else:

@@ -101,12 +101,13 @@ def fill_special(sd, spec):
 def relative_bias(sd, p, heads):
     t = F.linear(F.relu(F.linear(sd[p + ".relative_coords_table"], sd[p + ".cpb_mlp.0.weight"], sd[p + ".cpb_mlp.0.bias"])),
                  sd[p + ".cpb_mlp.2.weight"]).view(-1, heads)
-    b = t[sd[p + ".relative_position_index"].view(-1)].view(49, 49, heads).permute(2, 0, 1)
-    return 16 * torch.sigmoid(b)            # [heads, 49, 49]
+    n = sd[p + ".relative_position_index"].shape[0]
+    b = t[sd[p + ".relative_position_index"].view(-1)].view(n, n, heads).permute(2, 0, 1)
+    return 16 * torch.sigmoid(b)            # [heads, n, n]
 
 
-def window_attention(sd, p, xw, heads):
-    """xw [B_, 49, C] -> [B_, 49, C]"""
+def window_attention(sd, p, xw, heads, mask=None):
+    """xw [B_, n, C] -> [B_, n, C]; mask [nW, n, n] (0 / -100) for shifted windows"""
     b_, n, c = xw.shape
     bias = torch.cat([sd[p + ".q_bias"], torch.zeros_like(sd[p + ".v_bias"]), sd[p + ".v_bias"]])
     qkv = F.linear(xw, sd[p + ".qkv.weight"], bias).reshape(b_, n, 3, heads, c // heads).permute(2, 0, 3, 1, 4)
@@ -114,19 +115,22 @@ def window_attention(sd, p, xw, heads):
     attn = F.normalize(q, dim=-1) @ F.normalize(k, dim=-1).transpose(-2, -1)
     scale = torch.clamp(sd[p + ".logit_scale"], max=math.log(100.0)).exp()
     attn = attn * scale + relative_bias(sd, p, heads).unsqueeze(0)
+    if mask is not None:
+        nw = mask.shape[0]
+        attn = (attn.view(b_ // nw, nw, heads, n, n) + mask.unsqueeze(1).unsqueeze(0)).view(-1, heads, n, n)
     attn = torch.softmax(attn, dim=-1)
     out = (attn @ v).transpose(1, 2).reshape(b_, n, c)
     return F.linear(out, sd[p + ".proj.weight"], sd[p + ".proj.bias"])
 
 
-def to_windows(x_nhwc):
+def to_windows(x_nhwc, ws=WS):
     b, h, w, c = x_nhwc.shape
-    return x_nhwc.view(b, h // WS, WS, w // WS, WS, c).permute(0, 1, 3, 2, 4, 5).reshape(-1, WS * WS, c)
+    return x_nhwc.reshape(b, h // ws, ws, w // ws, ws, c).permute(0, 1, 3, 2, 4, 5).reshape(-1, ws * ws, c)
 
 
-def from_windows(xw, b, h, w):
+def from_windows(xw, b, h, w, ws=WS):
     c = xw.shape[-1]
-    return xw.view(b, h // WS, w // WS, WS, WS, c).permute(0, 1, 3, 2, 4, 5).reshape(b, h, w, c)
+    return xw.view(b, h // ws, w // ws, ws, ws, c).permute(0, 1, 3, 2, 4, 5).reshape(b, h, w, c)
 
 
 def swin_block(sd, p, x, heads, training):

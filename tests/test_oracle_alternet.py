@@ -1,0 +1,43 @@
+"""Pin oracle/alternet_ref.py to vectors produced by the real reference nets/AlterNet_SwinV2_FAN.py."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import alternet_ref, recipe
+
+NOISE = ("proj.bias", "v_bias")
+
+
+@pytest.mark.parametrize("tag", ["c128_w6", "c512_w3"])
+def test_attention_pair(golden, tag):
+    g = golden("alternet_pair_" + tag)
+    c, heads, ws, res = int(g["c"]), int(g["heads"]), int(g["ws"]), int(g["res"])
+    x = recipe.normal(7101, (2, c, res, res)).requires_grad_(True)
+    sds, y = [], x
+    for j, shift in enumerate((0, ws // 2)):
+        spec = alternet_ref.attn_block_spec("blk", c, heads, ws, shift, res)
+        sd = alternet_ref.fill_special(recipe.fill_state(spec, 7000 + 10 * heads + j), spec)
+        names = [k for k, _, kind in spec if kind in ("linear_w", "linear_b", "bn_w", "bn_b", "logit_scale")]
+        for k in names:
+            sd[k] = sd[k].clone().requires_grad_(True)
+        y = alternet_ref.attn_block(sd, "blk", y, heads, ws, shift, True)
+        sds.append((sd, names))
+    y.backward(recipe.normal(7102, (2, c, res, res)))
+    np.testing.assert_allclose(y.detach().numpy(), g["out"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(x.grad.numpy(), g["dx"], rtol=1e-3, atol=1e-5)
+    for j, (sd, names) in enumerate(sds):
+        for k in names:
+            want = g["b%d.grad.%s" % (j, k[4:])]
+            got = sd[k].grad
+            got = recipe.summary(got) if (want.shape == (10,) and got.numel() != 10) else got.numpy()
+            np.testing.assert_allclose(got, want, rtol=2e-3, atol=2e-4 if k.endswith(NOISE) else 2e-5, err_msg=k)
+
+
+def test_alternet50_eval(golden):
+    g = golden("alternet50_b2_eval")
+    spec = alternet_ref.alter_spec("AlterNet50")
+    assert len(spec) == int(g["n_keys"])
+    sd = alternet_ref.fill_special(recipe.fill_state(spec, 7300), spec)
+    with torch.no_grad():
+        y = alternet_ref.alter_forward(sd, recipe.images(7301, 2, 192, 192), "AlterNet50", False)
+    np.testing.assert_allclose(y.numpy(), g["out"], rtol=1e-3, atol=1e-4)

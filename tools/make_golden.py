@@ -329,6 +329,53 @@ def gen_swin():
         save(name.lower() + "_b2", **arrs)
 
 
+# ----------------------------------------------------------------------------- hybrid AlterNet backbone
+def gen_alternet():
+    from oracle import alternet_ref
+    _swin_ref()        # installs the timm stub
+    sys.modules.setdefault("einops", types.ModuleType("einops"))
+    if not hasattr(sys.modules["einops"], "rearrange"):
+        sys.modules["einops"].rearrange = lambda *a, **k: (_ for _ in ()).throw(RuntimeError("unused"))
+        sys.modules["einops"].repeat = sys.modules["einops"].rearrange
+    import torch.nn as nn
+    import nets.AlterNet_SwinV2_FAN as A
+    # --- a (W-MSA, SW-MSA) pair, training-mode BN, DropPath disabled, fwd + bwd
+    for tag, (c, heads, ws, res) in {"c128_w6": (128, 4, 6, 12), "c512_w3": (512, 16, 3, 6)}.items():
+        arrs = dict(c=c, heads=heads, ws=ws, res=res)
+        x = recipe.normal(7101, (2, c, res, res)).requires_grad_(True)
+        g = recipe.normal(7102, (2, c, res, res))
+        blks, sds = [], []
+        for j, shift in enumerate((0, ws // 2)):
+            blk = A.SwinTransformerBlock(c, c, heads=heads, input_resolution=(res, res), window_size=ws, shift_size=shift)
+            blk.drop_path = nn.Identity()
+            spec = alternet_ref.attn_block_spec("blk", c, heads, ws, shift, res)
+            sd = alternet_ref.fill_special(recipe.fill_state(spec, 7000 + 10 * heads + j), spec)
+            blk.load_state_dict({k[4:]: v for k, v in sd.items()}, strict=True)
+            blk.train()
+            blks.append(blk)
+        y = blks[1](blks[0](x))
+        y.backward(g)
+        arrs.update(out=y.detach(), dx=x.grad.clone())
+        for j, blk in enumerate(blks):
+            for k, p in blk.named_parameters():
+                arrs["b%d.grad.%s" % (j, k)] = p.grad.clone() if p.numel() < 20000 else recipe.summary(p.grad)
+            for k, b in blk.named_buffers():
+                if "running" in k:
+                    arrs["b%d.after.%s" % (j, k)] = b.clone()
+        save("alternet_pair_" + tag, **arrs)
+    # --- whole net, eval, 192x192
+    conf = types.SimpleNamespace(network="AlterNet50", emd_size=512, img_size=192)
+    net = A.AlterNet50(conf)
+    spec = alternet_ref.alter_spec("AlterNet50")
+    assert [k for k, _, _ in spec] == list(net.state_dict().keys())
+    assert [tuple(s) for _, s, _ in spec] == [tuple(v.shape) for v in net.state_dict().values()]
+    sd = alternet_ref.fill_special(recipe.fill_state(spec, 7300), spec)
+    net.load_state_dict(sd, strict=True)
+    net.eval()
+    with torch.no_grad():
+        save("alternet50_b2_eval", out=net(recipe.images(7301, 2, 192, 192)), n_keys=len(spec))
+
+
 # ----------------------------------------------------------------------------- lr schedule
 def gen_scheduler():
     _ref()
@@ -352,6 +399,7 @@ def gen_scheduler():
 GENS = {
     "scheduler": gen_scheduler,
     "swin": gen_swin,
+    "alternet": gen_alternet,
     "arcface": gen_arcface_edge,
     "distce": gen_distce,
     "head_ws1_rate10": lambda: gen_head(1, 1.0),
