@@ -50,7 +50,9 @@ class Model(nn.Module):
         self._graph = None             # set by capture_training_step()
         if "ResNet" in conf.network:
             self.encoder = importlib.import_module("nets.resnet").Encoder(conf=conf)
-        elif "Swin" in conf.network and "Alter" not in conf.network:
+        elif "AlterNet" in conf.network:
+            self.encoder = importlib.import_module("nets.AlterNet_SwinV2_FAN").Encoder(conf=conf)
+        elif "Swin" in conf.network:
             self.encoder = importlib.import_module("nets.SwinV2").Encoder(conf=conf)
         else:
             raise NotImplementedError("frhip: backbone %r is not built yet (SURVEY.md section 8f)" % conf.network)

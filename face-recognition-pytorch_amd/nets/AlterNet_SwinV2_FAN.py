@@ -1,0 +1,246 @@
+"""MI355X-native drop-in for the reference hybrid conv + window-attention backbone `nets/AlterNet_SwinV2_FAN.py`.
+
+Same surface as /root/reference/nets/AlterNet_SwinV2_FAN.py: `AlterNet50(conf)`, `Encoder(conf)` (:786-839; only
+AlterNet50 is constructible in the reference, and only at conf.img_size 192 -- SURVEY.md F9), modules
+`WindowAttention`, `SwinTransformerBlock` (attention only, no MLP), `BasicBlock`;
+`forward(x: float32[B,3,192,192]) -> float32[B, emd_size]`; state_dict keys/shapes identical (incl. the
+`attn_mask` buffers of the shifted blocks and the per-window-size coordinate tables).
+
+Underneath: IR BasicBlocks run on the MFMA conv kernels of nets.resnet; the (W-MSA, SW-MSA) attention pairs on
+frhip_winattn_fwd/_bwd with 6x6 / 3x3 windows, where the cyclic roll (:420-440), window partition and the -100
+region mask (:375-397) are index arithmetic inside the kernel -- no rolled or partitioned copy of the activation
+is ever materialised; qkv / proj are MFMA GEMMs, BN post-norm + residual is the fused bn_apply.
+Stem = conv3x3 stride 2 (im2col + GEMM) + fused BN-ReLU-MaxPool; tail = bn2 + ReLU (fused) -> dropout -> fc -> bn3.
+DropPath(0.1) (:371) is stochastic depth per sample: identity in eval; in training the per-sample keep mask is
+applied to the normalised branch.  One autograd node for the whole net; no CPU fallback.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from frhip import ops
+
+from . import SwinV2 as _S
+from ._backbone import (BackwardCtx, BasicBlock, Saved, _BN, _Conv, _Linear, basic_block_backward,  # noqa: F401
+                        basic_block_forward, bn_forward_state, compute_dtype, encoder_call, stem_backward,
+                        stem_forward, tail_backward, tail_forward)
+
+conv1x1 = lambda cin, cout, stride=1: _Conv(cin, cout, 1, stride)  # noqa: E731
+
+
+class WindowAttention(_S.WindowAttention):
+    """Cosine window attention holder for any window size <= 7 (reference :187-302)."""
+
+    def __init__(self, dim, window_size, num_heads, dim_head=32, qkv_bias=True, attn_drop=0.0, proj_drop=0.0,
+                 pretrained_window_size=(0, 0)):
+        nn.Module.__init__(self)
+        assert dim_head * num_heads == dim, "Not match dim_head * num_heads and hidden_dim"
+        ws = int(window_size[0])
+        assert ws == int(window_size[1]) and 2 <= ws <= 7
+        self.dim, self.window_size, self.num_heads = dim, tuple(window_size), num_heads
+        self.logit_scale = nn.Parameter(torch.log(10 * torch.ones((num_heads, 1, 1))))
+        self.cpb_mlp = nn.Sequential(nn.Linear(2, 512, bias=True), nn.ReLU(inplace=True), nn.Linear(512, num_heads, bias=False))
+        r = torch.arange(-(ws - 1), ws, dtype=torch.float32) / (ws - 1) * 8
+        table = torch.stack(torch.meshgrid([r, r], indexing="ij")).permute(1, 2, 0).contiguous().unsqueeze(0)
+        self.register_buffer("relative_coords_table", torch.sign(table) * torch.log2(torch.abs(table) + 1.0) / np.log2(8))
+        c = torch.stack(torch.meshgrid([torch.arange(ws), torch.arange(ws)], indexing="ij")).flatten(1)
+        rel = (c[:, :, None] - c[:, None, :]).permute(1, 2, 0) + (ws - 1)
+        self.register_buffer("relative_position_index", rel[:, :, 0] * (2 * ws - 1) + rel[:, :, 1])
+        self.qkv = _Linear(dim, dim * 3, bias=False)
+        self.q_bias = nn.Parameter(torch.zeros(dim)) if qkv_bias else None
+        self.v_bias = nn.Parameter(torch.zeros(dim)) if qkv_bias else None
+        self.proj = _Linear(dim, dim)
+
+    def bias_and_scale(self, params):
+        w0, b0, w2, ls = params
+        n = self.window_size[0] * self.window_size[1]
+        t = torch.nn.functional.linear(torch.relu(torch.nn.functional.linear(self.relative_coords_table, w0, b0)), w2).view(-1, self.num_heads)
+        b = t[self.relative_position_index.view(-1)].view(n, n, self.num_heads).permute(2, 0, 1).contiguous()
+        return 16 * torch.sigmoid(b), torch.clamp(ls, max=_S.LN100).exp().reshape(-1)
+
+
+class SwinTransformerBlock(nn.Module):
+    """x = x + DropPath(BN(attn(x)))  (reference :306-450): parameter holder; dim == dim_out in every AlterNet."""
+
+    def __init__(self, dim, dim_out, heads, input_resolution, window_size=7, shift_size=0, qkv_bias=True, drop=0.0,
+                 attn_drop=0.0, drop_path=0.1, norm_layer=None, pretrained_window_size=0, activation=None):
+        super().__init__()
+        if dim != dim_out:
+            raise NotImplementedError("the 1x1 shortcut branch (reference :351-356) is unused by every AlterNet config")
+        self.dim, self.num_heads, self.window_size, self.shift_size = dim, heads, window_size, shift_size
+        self.drop_path_rate = drop_path
+        if shift_size > 0:
+            h, w = input_resolution
+            img = torch.zeros((1, h, w, 1))
+            cnt = 0
+            for hs in (slice(0, -window_size), slice(-window_size, -shift_size), slice(-shift_size, None)):
+                for wsl in (slice(0, -window_size), slice(-window_size, -shift_size), slice(-shift_size, None)):
+                    img[:, hs, wsl, :] = cnt
+                    cnt += 1
+            mw = img.view(1, h // window_size, window_size, w // window_size, window_size, 1).permute(0, 1, 3, 2, 4, 5)
+            mw = mw.reshape(-1, window_size * window_size)
+            m = mw.unsqueeze(1) - mw.unsqueeze(2)
+            mask = m.masked_fill(m != 0, -100.0).masked_fill(m == 0, 0.0)
+        else:
+            mask = None
+        self.register_buffer("attn_mask", mask)          # kept for state_dict parity; the kernel derives it from indices
+        self.attn = WindowAttention(dim, (window_size, window_size), heads, qkv_bias=qkv_bias)
+        self.norm2 = _BN(dim)
+
+
+def attn_block_forward(blk, x, dt, training, save):
+    b, h, w, c = x.shape
+    m = b * h * w
+    at = blk.attn
+    x2 = x.view(m, c)
+    wqkv = _S._w2d(at.qkv, dt)
+    qkv = ops.gemm_nt(x2, wqkv)
+    qb = torch.cat([at.q_bias.data, torch.zeros_like(at.v_bias.data), at.v_bias.data])
+    ops.bias_gelu_fwd(qkv, qb, False)
+    with torch.enable_grad():
+        cpb = [p.detach().requires_grad_(True) for p in at.cpb_params()]
+        bias_t, scale_t = at.bias_and_scale(cpb)
+    bias, scale = bias_t.detach().contiguous(), scale_t.detach().contiguous()
+    ao = ops.winattn_fwd(qkv, bias, scale, b, h, w, at.num_heads, blk.window_size, blk.shift_size)
+    wproj = _S._w2d(at.proj, dt)
+    po = ops.gemm_nt(ao, wproj)
+    ops.bias_gelu_fwd(po, at.proj.bias.data, False)
+    st2 = bn_forward_state(blk.norm2, ops.colstats(po) if training else None, m, training)
+    keep = None
+    if training and blk.drop_path_rate > 0:
+        # stochastic depth: one Bernoulli(keep) per sample scales the whole normalised branch (timm DropPath)
+        kp = 1.0 - blk.drop_path_rate
+        keep = (torch.rand(b, device=x.device) < kp).to(x.dtype) / kp
+        branch = ops.bn_apply(po, st2).view(b, h * w * c) * keep[:, None]
+        out = (x.view(b, -1) + branch).view(b, h, w, c)
+    else:
+        out = ops.bn_apply(po, st2, res=x2).view(b, h, w, c)
+    s = None
+    if save:
+        s = Saved()
+        (s.x2, s.wqkv, s.qkv, s.cpb, s.bias_t, s.scale_t, s.bias, s.scale, s.ao, s.wproj, s.po, s.st2, s.keep, s.shape) = (
+            x2, wqkv, qkv, cpb, bias_t, scale_t, bias, scale, ao, wproj, po, st2, keep, (b, h, w, c))
+    return out, s
+
+
+def attn_block_backward(blk, s, dout, dt, bc):
+    G = bc.G
+    b, h, w, c = s.shape
+    m = b * h * w
+    at = blk.attn
+    d2 = dout.reshape(m, c)
+    dbranch = d2 if s.keep is None else (d2.view(b, -1) * s.keep[:, None]).view(m, c).contiguous()
+    dpo = ops.bn_backward(dbranch, s.po, s.st2, blk.norm2.weight.data, G(blk.norm2.weight), G(blk.norm2.bias))
+    ops.colsum_accumulate(dpo, G(at.proj.bias))
+    bc.on_side(lambda: ops.gemm_tn(dpo, s.ao, G(at.proj.weight)), dpo, s.ao)
+    dao = ops.gemm_nt(dpo, ops.transpose2d(s.wproj))
+    dqkv, dbias, dscale = ops.winattn_bwd(s.qkv, dao, s.bias, s.scale, b, h, w, at.num_heads, blk.window_size, blk.shift_size)
+    gsum = torch.zeros(3 * c, dtype=torch.float32, device=dout.device)
+    _S._colsum_via_gemm(dqkv, gsum)
+    G(at.q_bias).add_(gsum[:c])
+    G(at.v_bias).add_(gsum[2 * c:])
+    bc.on_side(lambda: ops.gemm_tn(dqkv, s.x2, G(at.qkv.weight)), dqkv, s.x2)
+    dx = _S._dgrad_add(dqkv, s.wqkv, d2)
+    gs = torch.autograd.grad([s.bias_t, s.scale_t], s.cpb, [dbias, dscale])
+    for p, g in zip(at.cpb_params(), gs):
+        G(p).add_(g.reshape(p.shape))
+    return dx.view(b, h, w, c)
+
+
+class AlterNet(nn.Module):
+    def __init__(self, conf, block, block2, num_blocks, num_blocks2, heads):
+        super().__init__()
+        self.emd_size = conf.emd_size
+        self.dtype = compute_dtype(conf)
+        res = (conf.img_size, conf.img_size)
+        self.inplanes = 64
+        self.conv1 = _Conv(3, 64, 3, 2)
+        self.bn1 = _BN(64)
+        self.layer1 = self.stack_layers(block, block2, 64, num_blocks[0], num_blocks2[0], heads[0], (res[0] // 4, res[1] // 4), window_size=6)
+        self.layer2 = self.stack_layers(block, block2, 128, num_blocks[1], num_blocks2[1], heads[1], (res[0] // 8, res[1] // 8), stride=2, window_size=6)
+        self.layer3 = self.stack_layers(block, block2, 256, num_blocks[2], num_blocks2[2], heads[2], (res[0] // 16, res[1] // 16), stride=2, window_size=6)
+        self.layer4 = self.stack_layers(block, block2, conf.emd_size, num_blocks[3], num_blocks2[3], heads[3], (res[0] // 32, res[1] // 32), stride=2, window_size=3)
+        self.bn2 = _BN(block.expansion * conf.emd_size)
+        self.dropout = nn.Dropout()
+        self.fc = _Linear(block.expansion * conf.emd_size * 6 * 6, conf.emd_size)
+        self.bn3 = _BN(conf.emd_size)
+        for m in self.modules():
+            if isinstance(m, (_Conv, _Linear, nn.Linear)):
+                nn.init.xavier_normal_(m.weight)
+                if getattr(m, "bias", None) is not None:
+                    nn.init.constant_(m.bias, 0)
+
+    def stack_layers(self, block, block2, planes, blocks, blocks2, heads, input_resolution, window_size=3, stride=1):
+        downsample = None
+        if stride != 1 or self.inplanes != planes * block.expansion:
+            downsample = nn.Sequential(conv1x1(self.inplanes, planes * block.expansion, stride), _BN(planes * block.expansion))
+        num_blocks = 2 * (blocks // 3) + (blocks % 3) - 1
+        assert 2 * blocks2 + blocks2 <= blocks, "The number of transformers must not exceed cnn !!!"
+        alt_seq = [False] * num_blocks
+        for i in range(blocks2):
+            alt_seq[-2 * i - 1] = True
+        layers = [block(self.inplanes, planes, stride, downsample)]
+        self.inplanes = planes * block.expansion
+        for is_alt in alt_seq:
+            if not is_alt:
+                layers.append(block(self.inplanes, planes))
+            else:
+                layers.append(block2(self.inplanes, planes, heads=heads, input_resolution=input_resolution, window_size=window_size))
+                layers.append(block2(self.inplanes, planes, heads=heads, input_resolution=input_resolution,
+                                     shift_size=window_size // 2, window_size=window_size))
+        return nn.Sequential(*layers)
+
+    def _layers(self):
+        for layer in (self.layer1, self.layer2, self.layer3, self.layer4):
+            for mod in layer:
+                yield mod
+
+    def forward(self, x):
+        return encoder_call(self, x)
+
+    def _forward_impl(self, x, training, save):
+        dt = self.dtype
+        sv = Saved() if save else None
+        cur = stem_forward(self, x, training, sv)
+        saved = []
+        for mod in self._layers():
+            if isinstance(mod, BasicBlock):
+                cur, s = basic_block_forward(mod, cur, dt, training, save)
+            else:
+                cur, s = attn_block_forward(mod, cur, dt, training, save)
+            saved.append(s)
+        if cur.shape[1] != 6 or cur.shape[2] != 6:
+            raise NotImplementedError("AdaptiveAvgPool2d((6,6)) is the identity only for 192x192 inputs")
+        mask = None
+        if training and self.dropout.p > 0:
+            keep = 1.0 - self.dropout.p
+            mask = (torch.rand(cur.shape, device=cur.device) < keep).to(cur.dtype) / keep
+        emb = tail_forward(self, cur, training, sv, dropout_mask=mask, relu=True)
+        if save:
+            sv.layers = saved
+        return emb, sv
+
+    def _backward_impl(self, sv, d_emb, params):
+        dt = self.dtype
+        bc = BackwardCtx(params, d_emb.device)
+        dout = tail_backward(self, sv, d_emb, bc)
+        for mod, s in zip(reversed(list(self._layers())), reversed(sv.layers)):
+            if isinstance(mod, BasicBlock):
+                dout = basic_block_backward(mod, s, dout, dt, bc)
+            else:
+                dout = attn_block_backward(mod, s, dout, dt, bc)
+        stem_backward(self, sv, dout, bc)
+        return bc.join()
+
+
+def AlterNet50(conf, **kwargs):
+    return AlterNet(conf, BasicBlock, SwinTransformerBlock, num_blocks=[3, 4, 14, 4], num_blocks2=[0, 1, 4, 1],
+                    heads=(2, 4, 8, 16), **kwargs)
+
+
+def Encoder(conf):
+    """Name dispatch of the reference (:831-839).  AlterNet18/34/100/200 fail the reference's own block-budget assert
+    (SURVEY.md F9), so only AlterNet50 exists."""
+    if conf.network == "AlterNet50":
+        return AlterNet50(conf)
+    return None
