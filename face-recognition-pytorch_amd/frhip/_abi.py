@@ -27,6 +27,8 @@ def _ctype(decl):
         return ctypes.c_int
     if base == "float":
         return ctypes.c_float
+    if base == "double":
+        return ctypes.c_double
     if base == "size_t":
         return ctypes.c_size_t
     raise ValueError("frhip.h: cannot map parameter %r" % decl)

@@ -142,3 +142,34 @@ extern "C" int frhip_ce_grad(float* p, int n, int c, const int64_t* labels, floa
     hipLaunchKernelGGL(ce_grad_kernel, dim3(n), dim3(256), 0, stream, p, c, labels, inv_n, upstream);
     return check_launch("frhip_ce_grad");
 }
+
+// ---- verification pair scores (/root/reference/utils/eval.py:68-99): score = 1 - |a-b|^2 / 4 accumulated in float64
+// from float32 differences in index order (the reference's arithmetic, so hist_idx = int(99999*score) is
+// bit-exact), plus the two 100001-bin histograms by integer atomics.  One thread per pair.
+namespace frhip {
+__global__ void pair_score_kernel(const float* __restrict__ e1, const float* __restrict__ e2, const int64_t* __restrict__ labels,
+                                  int n, int d, double* __restrict__ scores, int* __restrict__ hist_idx,
+                                  int* __restrict__ hist_genuine, int* __restrict__ hist_imposter) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double sum = 0.0;
+    for (int k = 0; k < d; ++k) {
+        const float df = e1[(size_t)i * d + k] - e2[(size_t)i * d + k];
+        const double dd = (double)df;
+        sum += dd * dd;
+    }
+    const double score = 1.0 - sum / 4.0;
+    const int idx = (int)((1e5 - 1.0) * score);
+    scores[i] = score;
+    hist_idx[i] = idx;
+    if (idx >= 0 && idx <= 100000) atomicAdd(labels[i] ? hist_genuine + idx : hist_imposter + idx, 1);
+}
+}  // namespace frhip
+
+extern "C" int frhip_pair_score(const float* e1, const float* e2, const int64_t* labels, int n, int d, double* scores,
+                                int* hist_idx, int* hist_genuine, int* hist_imposter, hipStream_t stream) {
+    if (n <= 0) return FRHIP_OK;
+    hipLaunchKernelGGL(frhip::pair_score_kernel, dim3((n + 127) / 128), dim3(128), 0, stream, e1, e2, labels, n, d, scores,
+                       hist_idx, hist_genuine, hist_imposter);
+    return frhip::check_launch("frhip_pair_score");
+}

@@ -422,3 +422,16 @@ def gelu_bwd(da, h):
     dh = torch.empty_like(h)
     check(lib().frhip_gelu_bwd(dt_of(h), _p(da), _p(h), _p(dh), h.numel(), _s()), "frhip_gelu_bwd")
     return dh
+
+
+# ------------------------------------------------------------------------------------------ verification metrics
+def pair_score(e1, e2, labels_i64):
+    n, d = e1.shape
+    dev = e1.device
+    scores = torch.empty((n,), dtype=torch.float64, device=dev)
+    idx = torch.empty((n,), dtype=torch.int32, device=dev)
+    hg = torch.zeros((100001,), dtype=torch.int32, device=dev)
+    hi = torch.zeros((100001,), dtype=torch.int32, device=dev)
+    check(lib().frhip_pair_score(_p(e1), _p(e2), _p(labels_i64), n, d, _p(scores), _p(idx), _p(hg), _p(hi), _s()),
+          "frhip_pair_score")
+    return scores, idx, hg, hi

@@ -128,6 +128,45 @@ class Model(nn.Module):
             self._g_loss = self._step(self._g_img, self._g_id.clone())
         self._graph = graph
 
+    # ---- evaluation (reference :196-270, :345-373): pairs [b,2,c,h,w] -> eval-mode embeddings -> verification metrics
+    def _shared_eval_step(self, batch, dataset_name, prefix):
+        pair, label = batch
+        pair, label = pair.to(self.conf.local_rank), label.to(self.conf.local_rank)
+        pair = pair.reshape(-1, *pair.shape[2:])                     # 'b p c h w -> (b p) c h w'
+        self.encoder.eval()
+        start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        start.record()
+        with torch.no_grad():
+            embedding = normalize(self.forward(pair))
+        end.record()
+        torch.cuda.synchronize()
+        return {f"{dataset_name}_embedding_1": embedding[0::2].cpu().numpy(),
+                f"{dataset_name}_embedding_2": embedding[1::2].cpu().numpy(),
+                f"{dataset_name}_infer_time": start.elapsed_time(end),
+                f"{dataset_name}_label_list": label.cpu().numpy(), "dataset_name": dataset_name}
+
+    def validation_step(self, batch, dataset_idx):
+        return self._shared_eval_step(batch, self.conf.val_dataset[dataset_idx], "val")
+
+    def test_step(self, batch, dataset_idx):
+        return self._shared_eval_step(batch, self.conf.test_dataset[dataset_idx], "test")
+
+    def _eval_epoch_end(self, outputs):
+        ev = importlib.import_module("utils.eval")
+        name = outputs[0]["dataset_name"]
+        labels = np.concatenate([o[f"{name}_label_list"] for o in outputs]).reshape(-1)
+        e1 = np.concatenate([o[f"{name}_embedding_1"] for o in outputs])
+        e2 = np.concatenate([o[f"{name}_embedding_2"] for o in outputs])
+        hg, hi, scores = ev.pair_score(e1, e2, labels)
+        roc, eer_th = ev.performance_roc(hg, hi, min_level=getattr(self.conf, "min_level", 3),
+                                         max_level=getattr(self.conf, "max_level", 9))
+        acc = ev.performance_acc(scores, labels, eer_th)
+        return {"dataset_name": name, "acc": acc, "roc": roc, "eer_th": eer_th,
+                "infer_time": float(np.mean([o[f"{name}_infer_time"] for o in outputs]))}
+
+    validation_epoch_end = _eval_epoch_end
+    test_epoch_end = _eval_epoch_end
+
     def training_epoch_end(self, outputs, t=None):
         self.sch.step() if self.sch is not None else None
         self.epoch += 1

@@ -183,6 +183,11 @@ int frhip_winattn_bwd(int dtype, const void* qkv, const void* dout, const float*
 int frhip_bias_gelu_fwd(int dtype, void* y, const float* bias, void* act_out, int rows, int c, frhip_stream_t stream);
 int frhip_gelu_bwd(int dtype, const void* da, const void* h, void* dh, size_t n, frhip_stream_t stream);
 
+/* ---- verification metrics: utils/eval.py:68-99 pair_score.  scores[n] float64, hist_idx[n] = int(99999*score),
+ * hist_genuine / hist_imposter int32[100001] (caller-zeroed) ---- */
+int frhip_pair_score(const float* e1, const float* e2, const int64_t* labels, int n, int d, double* scores,
+                     int* hist_idx, int* hist_genuine, int* hist_imposter, frhip_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -376,6 +376,30 @@ def gen_alternet():
         save("alternet50_b2_eval", out=net(recipe.images(7301, 2, 192, 192)), n_keys=len(spec))
 
 
+# ----------------------------------------------------------------------------- verification metrics
+def gen_eval():
+    _ref()
+    nb = types.ModuleType("numba")          # utils/eval.py needs numba (absent): identity decorators, container only
+    nb.njit = lambda *a, **k: (lambda f: f)
+    nb.prange = range
+    sys.modules.setdefault("numba", nb)
+    import utils.eval as E
+    n, d = 600, 512
+    base = recipe.normal(8101, (n, d))
+    other = recipe.normal(8102, (n, d))
+    labels = (recipe.rng(8103).random(n) < 0.5).astype(np.int64)
+    e1 = torch.nn.functional.normalize(base)
+    mix = torch.from_numpy(np.where(labels[:, None] == 1, 0.12, 0.0).astype(np.float32))
+    e2 = torch.nn.functional.normalize(mix * base + (1 - mix) * other + 0.0 * recipe.normal(8104, (n, d)))
+    e1n, e2n = e1.numpy(), e2.numpy()
+    hg, hi, scores = E.pair_score(e1n, e2n, labels)
+    roc, eer_th = E.performance_roc(hg, hi, min_level=1, max_level=3)
+    acc = E.performance_acc(scores, labels, eer_th)
+    idx = np.array([int((1e5 - 1.) * s) for s in scores], dtype=np.int64)
+    save("eval_pairs", n=n, d=d, labels=labels, scores=scores, hist_idx=idx, hist_genuine=hg, hist_imposter=hi,
+         eer_th=eer_th, acc=acc, roc=np.array(roc))
+
+
 # ----------------------------------------------------------------------------- lr schedule
 def gen_scheduler():
     _ref()
@@ -400,6 +424,7 @@ GENS = {
     "scheduler": gen_scheduler,
     "swin": gen_swin,
     "alternet": gen_alternet,
+    "eval": gen_eval,
     "arcface": gen_arcface_edge,
     "distce": gen_distce,
     "head_ws1_rate10": lambda: gen_head(1, 1.0),
