@@ -16,6 +16,12 @@
 #include <type_traits>
 #include "igemm_nt.h"
 
+// Timing-only ablation switches (tools/ablate.py builds variants with -DFRHIP_ABL=bits; results are WRONG with any bit
+// set): 1 no per-iteration barrier, 2 no MFMA, 4 no LDS fragment reads, 8 no in-loop DMA, 16 no epilogue.
+#ifndef FRHIP_ABL
+#define FRHIP_ABL 0
+#endif
+
 namespace frhip {
 
 struct HaloGeom {
@@ -110,7 +116,9 @@ struct HaloMainloop {
         //      halo buffer) of the 16-byte chunk this lane feeds to the MFMA, or the buffer's zero row when the
         //      neighbour lies outside the image.  The K loop then only adds compile-time constants to them.
         const int fi = lane & 15, fg = lane >> 4;
-        int xa[9][MT];
+        // two 16-bit offsets per register (a halo buffer is < 64 KiB): low half = even mt, high half = odd mt
+        static_assert(Tile::HALO_BYTES < 65536 && MT % 2 == 0, "packed fragment offsets");
+        uint32_t xa[9][MT / 2];
         {
             const int HW = g.H * g.W;
 #pragma unroll
@@ -125,34 +133,66 @@ struct HaloMainloop {
                     const int dy = g.sign * (tap / 3 - 1), dx = g.sign * (tap % 3 - 1);
                     const bool ok = live && (unsigned)(y + dy) < (unsigned)g.H && (unsigned)(x + dx) < (unsigned)g.W;
                     const int row = q + g.W + 1 + dy * g.W + dx;
-                    xa[tap][mt] = ok ? row * NT_ROWB + ((fg ^ (row & 7)) << 4) : Tile::ZROW + (fg << 4);
+                    const uint32_t off = ok ? (uint32_t)(row * NT_ROWB + ((fg ^ (row & 7)) << 4)) : (uint32_t)(Tile::ZROW + (fg << 4));
+                    if (mt & 1) xa[tap][mt >> 1] |= off << 16;
+                    else xa[tap][mt >> 1] = off;
                 }
             }
         }
         const int wa = (wn * 64 + fi) * NT_ROWB + ((fg ^ (fi & 7)) << 4);     // weight rows: chunk fg of row (wn*64 + t*16 + fi)
 
-        // MFMAs of one (halo buffer, weight ring slot, tap) -- all three are compile-time after unrolling
-        auto compute = [&](auto hb_c, auto slot_c, auto tap_c) {
-            constexpr int HB = decltype(hb_c)::value, SLOT = decltype(slot_c)::value, TAP = decltype(tap_c)::value;
+        // ---- software pipeline.  An iteration (= one tap of one 64-channel chunk) has two K halves of 32.  The
+        //      fragments of a half are read from LDS while the MFMAs of the PREVIOUS half run (two register sets), so
+        //      LDS latency and bandwidth hide behind the matrix pipe.  The one barrier per iteration sits BETWEEN
+        //      the halves: it publishes the weights of iteration t+1 (issued at the top of t-1) just before the
+        //      second half of t starts prefetching them, and it orders the last reads of ring slot (t+2)%3 / of the
+        //      other halo buffer (first half of t-1 at the latest) before the DMA that overwrites them (top of t+1).
+        Frag xf[2][MT], wf[2][4];
+        auto load_frags = [&](auto set_c, auto h_c, auto hb_c, auto slot_c, auto tap_c) {
+            constexpr int SET = decltype(set_c)::value, HH = decltype(h_c)::value, HB = decltype(hb_c)::value,
+                          SLOT = decltype(slot_c)::value, TAP = decltype(tap_c)::value;
             const char* hbase = smem + HB * Tile::HALO_BYTES;
             const char* wbase = smem + Tile::W_OFF + SLOT * Tile::WBUF_BYTES;
+            // second K half = chunk index ^ 4  <=>  byte offset ^ 64 (the zero row is 128 B, so ^64 stays inside it)
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                Frag xf[MT], wf[4];
-                // second K half = chunk index ^ 4  <=>  byte offset ^ 64 (the zero row is 128 B, so ^64 stays inside it)
+            for (int t = 0; t < 4; ++t) {
+                if constexpr (FRHIP_ABL & 4) asm volatile("" : "=v"(wf[SET][t]));
+                else wf[SET][t] = *reinterpret_cast<const Frag*>(wbase + ((wa + t * 16 * NT_ROWB) ^ (HH << 6)));
+            }
 #pragma unroll
-                for (int t = 0; t < 4; ++t)
-                    wf[t] = *reinterpret_cast<const Frag*>(wbase + ((wa + t * 16 * NT_ROWB) ^ (h << 6)));
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) xf[mt] = *reinterpret_cast<const Frag*>(hbase + (xa[TAP][mt] ^ (h << 6)));
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                    for (int nt = 0; nt < 4; ++nt) Mma<T>::run(wf[nt], xf[mt], acc[nt][mt]);
+            for (int mt = 0; mt < MT; ++mt) {
+                if constexpr (FRHIP_ABL & 4) asm volatile("" : "=v"(xf[SET][mt]));
+                else {
+                    uint32_t pk = xa[TAP][mt >> 1];
+                    asm volatile("" : "+v"(pk));          // keep the unpack inside the loop (hoisting it costs 72 VGPRs)
+                    xf[SET][mt] = *reinterpret_cast<const Frag*>(hbase + (((mt & 1) ? (pk >> 16) : (pk & 0xffffu)) ^ (uint32_t)(HH << 6)));
+                }
             }
         };
+        auto mfma_set = [&](auto set_c) {
+            constexpr int SET = decltype(set_c)::value;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) {
+                    if constexpr (FRHIP_ABL & 2) { Frag fa = wf[SET][nt], fb = xf[SET][mt]; asm volatile("" :: "v"(fa), "v"(fb)); }
+                    else Mma<T>::run(wf[SET][nt], xf[SET][mt], acc[nt][mt]);
+                }
+        };
+        // ask the scheduler to spread the (4 + MT) fragment reads of a half between its 4*MT MFMAs
+        auto interleave = [&]() {
+            constexpr int NREAD = (4 + MT) * (int)(sizeof(Frag) / 16), NMFMA = 4 * MT * (sizeof(T) == 2 ? 1 : 4);
+            constexpr int PER = NMFMA / NREAD > 0 ? NMFMA / NREAD : 1;
+#pragma unroll
+            for (int i = 0; i < NREAD; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, PER, 0);     // MFMA
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);       // DS read
+            }
+        };
+        typedef std::integral_constant<int, 0> I0;
+        typedef std::integral_constant<int, 1> I1;
 
-        // ---- prologue: zero rows, halo of chunk 0, weights of iterations 0 and 1
+        // ---- prologue: zero rows, halo of chunk 0, weights of iterations 0 and 1, first fragment set
         if (threadIdx.x < 8 * HBUFS) {
             const int hbz = threadIdx.x >> 3;
             *reinterpret_cast<f32x4_t*>(smem + hbz * Tile::HALO_BYTES + Tile::ZROW + (threadIdx.x & 7) * 16) = f32x4_t{0.f, 0.f, 0.f, 0.f};
@@ -162,49 +202,59 @@ struct HaloMainloop {
         weights(1);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        load_frags(I0{}, I0{}, I0{}, I0{}, I0{});
 
         // one chunk = nine taps; hb (halo buffer) is a compile-time constant per instantiation of this lambda
         auto chunk_body = [&](auto hb_c, int ch) {
             constexpr int HB = decltype(hb_c)::value;
+            constexpr int HBN = HBUFS == 2 ? (HB ^ 1) : 0;        // halo buffer of the next chunk
             const int c0 = ch * BKE;
             const int it0 = ch * 9;
             auto tap_body = [&](auto tap_c) {
                 constexpr int TAP = decltype(tap_c)::value;
-                // DMA two iterations ahead (weights) + one slice of the next chunk's halo.  The ring slot / halo
-                // buffer written here was last read one iteration / one chunk ago, i.e. before the previous barrier.
-                weights(it0 + TAP + 2);
-                if (HBUFS == 2) {
-                    const int piece = TAP * Tile::WAVES + wave;
-                    if (ch + 1 < nchunks && piece < npieces) halo_piece(HB ^ 1, piece, c0 + BKE);
-                    else glds16(ra, smem + Tile::DUMP_OFF, OOB_OFFSET);
+                // DMA: weights two iterations ahead + (taps 0..7) one slice of the next chunk's halo
+                if constexpr (!(FRHIP_ABL & 8)) {
+                    weights(it0 + TAP + 2);
+                    if (HBUFS == 2) {
+                        const int piece = TAP * Tile::WAVES + wave;
+                        if (TAP < 8 && ch + 1 < nchunks && piece < npieces) halo_piece(HBN, piece, c0 + BKE);
+                        else glds16(ra, smem + Tile::DUMP_OFF, OOB_OFFSET);
+                    }
                 }
-                compute(hb_c, std::integral_constant<int, TAP % Tile::WRING>{}, tap_c);     // (9*ch + TAP) % 3 == TAP % 3
-                // all but this iteration's pieces have landed -> everything the NEXT iteration reads is in LDS
-                if constexpr (Tile::ITER_PIECES == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+                load_frags(I1{}, I1{}, hb_c, std::integral_constant<int, TAP % Tile::WRING>{}, tap_c);   // (9*ch + TAP) % 3 == TAP % 3
+                mfma_set(I0{});
+                interleave();
+                // everything but this iteration's pieces has landed -> weights of the next iteration are in LDS
+                if constexpr (FRHIP_ABL & 8) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                else if constexpr (Tile::ITER_PIECES == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
                 else if constexpr (Tile::ITER_PIECES == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
                 else if constexpr (Tile::ITER_PIECES == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
                 else if constexpr (Tile::ITER_PIECES == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
                 static_assert(Tile::ITER_PIECES <= 5, "add a vmcnt case");
-                __builtin_amdgcn_s_barrier();
+                if constexpr (!(FRHIP_ABL & 1)) __builtin_amdgcn_s_barrier();
+                if constexpr (TAP < 8)
+                    load_frags(I0{}, I0{}, hb_c, std::integral_constant<int, (TAP + 1) % Tile::WRING>{}, std::integral_constant<int, (TAP + 1) % 9>{});
+                else
+                    load_frags(I0{}, I0{}, std::integral_constant<int, HBN>{}, I0{}, I0{});
+                mfma_set(I1{});
+                interleave();
             };
             tap_body(std::integral_constant<int, 0>{}); tap_body(std::integral_constant<int, 1>{});
             tap_body(std::integral_constant<int, 2>{}); tap_body(std::integral_constant<int, 3>{});
             tap_body(std::integral_constant<int, 4>{}); tap_body(std::integral_constant<int, 5>{});
             tap_body(std::integral_constant<int, 6>{}); tap_body(std::integral_constant<int, 7>{});
             tap_body(std::integral_constant<int, 8>{});
-            if (ch + 1 < nchunks) {
-                if (HBUFS == 1) {              // single halo buffer: reload it now (exposed latency)
-                    for (int piece = wave; piece < npieces; piece += Tile::WAVES) halo_piece(0, piece, c0 + BKE);
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    __builtin_amdgcn_s_barrier();
-                } else if (npieces > 9 * Tile::WAVES) {   // halo larger than the nine slices cover: fetch the rest
-                    for (int piece = 9 * Tile::WAVES + wave; piece < npieces; piece += Tile::WAVES) halo_piece(HB ^ 1, piece, c0 + BKE);
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    __builtin_amdgcn_s_barrier();
-                }
+            if (HBUFS == 1 && ch + 1 < nchunks) {       // single halo buffer: reload it now (exposed latency)
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                for (int piece = wave; piece < npieces; piece += Tile::WAVES) halo_piece(0, piece, c0 + BKE);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                load_frags(I0{}, I0{}, I0{}, I0{}, I0{});
             }
         };
+        static_assert(HBUFS == 1 || Tile::HROWS / 8 <= 8 * Tile::WAVES, "eight halo slices must cover the halo");
         for (int ch = 0; ch < nchunks; ch += HBUFS) {
             chunk_body(std::integral_constant<int, 0>{}, ch);
             if (HBUFS == 2 && ch + 1 < nchunks) chunk_body(std::integral_constant<int, HBUFS - 1>{}, ch + 1);

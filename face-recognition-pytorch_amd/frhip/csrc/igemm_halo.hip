@@ -16,6 +16,15 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void halo_kernel(HaloG
     const int ntile = (int)(lin % (uint32_t)ntiles), mtile = (int)(lin / (uint32_t)ntiles);
     HaloMainloop<T, WM, WN, MT, HBUFS> ml;
     ml.run(g, a, b, smem, mtile, ntile);
+    if constexpr (FRHIP_ABL & 16) {
+        if (g.M >= 0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < MT; ++j) asm volatile("" :: "v"(ml.acc[i][j]));
+            return;
+        }
+    }
     const int wave = wave_id();
     const int wm = wave / WN, wn = wave % WN;
     const int m0 = mtile * Tile::BM + wm * Tile::WROWS, n0 = ntile * Tile::BN + wn * 64;
