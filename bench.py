@@ -62,12 +62,13 @@ class ConvMeter:
                 self.calls.append((self._fwd, (x, w, stride, pad, want_stats), 2.0 * n * ho * wo * k * r * s * c))
             return self._fwd(x, w, stride, pad, want_stats)
 
-        def conv_dgrad(dy, wt, x_shape, r, s, stride, pad, residual=None, out=None):
+        def conv_dgrad(dy, wt, x_shape, r, s, stride, pad, residual=None, out=None, bnred=None):
             if self.collect and dy.dtype == torch.bfloat16:
                 n, ho, wo, k = dy.shape
-                self.calls.append((self._dgrad, (dy, wt, tuple(x_shape), r, s, stride, pad, residual),
+                # the probe re-issues the launch as the step does (incl. the fused BN-backward reduction in its epilogue)
+                self.calls.append((self._dgrad, (dy, wt, tuple(x_shape), r, s, stride, pad, residual, None, bnred),
                                    2.0 * n * ho * wo * k * r * s * x_shape[3]))    # algorithmic MACs = forward's
-            return self._dgrad(dy, wt, x_shape, r, s, stride, pad, residual, out)
+            return self._dgrad(dy, wt, x_shape, r, s, stride, pad, residual, out, bnred)
 
         ops.conv_fwd, ops.conv_dgrad = conv_fwd, conv_dgrad
 

@@ -30,6 +30,19 @@ struct NtGeom {
 
 constexpr int NT_ROWB = 128;                 // bytes per LDS row = one K step
 
+// Optional BatchNorm-backward reduction fused into the store epilogue of a data-gradient kernel: the tensor being
+// written (dx) is the upstream gradient of a BatchNorm whose saved input is `y` (same shape).  Instead of
+// {sum x, sum x^2} the per-tile partials become { sum d, sum d * (y - mean) * invstd } with
+// d = dx * (y*mscale + mshift > 0) when the BN is followed by a ReLU (mscale != NULL), d = dx otherwise --
+// exactly what frhip_bn_bwd_reduce computes in a separate pass over dx and y.
+struct EpiBnRed {
+    const void* y;
+    const float* mean;
+    const float* invstd;
+    const float* mscale;
+    const float* mshift;
+};
+
 // WM x WN waves; each wave owns (MT*16) pixel rows x 64 channels (4 MFMA tiles wide).
 template <typename T, int WM, int WN, int MT = 4>
 struct NtTile {
@@ -205,13 +218,53 @@ struct NtMainloop {
     }
 };
 
+// Global operands of the store epilogue (residual rows, saved BN input rows), fetched into registers BEFORE the
+// accumulators are staged through LDS so their latency hides behind the staging instead of stalling the store loop.
+template <typename T, int WROWS>
+struct EpiOperands {
+    static constexpr int EPV = 16 / (int)sizeof(T), LPR = 64 / EPV, RPI = 64 / LPR, ITERS = WROWS / RPI;
+    static constexpr bool PRE = ITERS <= 8;          // 128-row wave tiles would need 128 registers: those load in the loop
+    Vec16<T> rv[PRE ? ITERS : 1], yv[PRE ? ITERS : 1];
+    const T* r; const T* y;
+    int M, Nout, m0, n, rsub;
+    __device__ __forceinline__ void fetch(const void* __restrict__ res, const void* __restrict__ ybn, int M_, int Nout_,
+                                          int m0_, int n0) {
+        const int lane = lane_id();
+        M = M_; Nout = Nout_; m0 = m0_;
+        n = n0 + (lane % LPR) * EPV; rsub = lane / LPR;
+        r = reinterpret_cast<const T*>(res);
+        y = reinterpret_cast<const T*>(ybn);
+        if constexpr (PRE) {
+#pragma unroll
+            for (int it = 0; it < ITERS; ++it) {
+                const int m = m0 + it * RPI + rsub;
+                const bool ok = m < M && n < Nout;
+                const size_t idx = (size_t)m * Nout + n;
+                if (r && ok) rv[it] = *reinterpret_cast<const Vec16<T>*>(r + idx);
+                if (y && ok) yv[it] = *reinterpret_cast<const Vec16<T>*>(y + idx);
+            }
+        }
+    }
+    // valid for rows inside the tensor only
+    __device__ __forceinline__ Vec16<T> res_row(int it) const {
+        if constexpr (PRE) return rv[it];
+        else return *reinterpret_cast<const Vec16<T>*>(r + (size_t)(m0 + it * RPI + rsub) * Nout + n);
+    }
+    __device__ __forceinline__ Vec16<T> y_row(int it) const {
+        if constexpr (PRE) return yv[it];
+        else return *reinterpret_cast<const Vec16<T>*>(y + (size_t)(m0 + it * RPI + rsub) * Nout + n);
+    }
+};
+
 // Shared store epilogue: the wave's (WROWS x 64) tile sits in its LDS staging area `mine` as T (row = pixel).
 // Rows are written back as whole 128/256-byte lines (+ optional residual); the same read-back accumulates the
-// per-channel sum / sum of squares of the STORED values -> BN batch-statistic partials [mtile][2][Nout].
+// per-channel sum / sum of squares of the STORED values -> BN batch-statistic partials [mtile][2][Nout]
+// (or the BN-backward partials, see EpiBnRed).
 template <typename T, int WM, int WN, int WROWS, int THREADS, int BN>
 __device__ __forceinline__ void nt_epilogue_store(const char* mine, int P, char* smem, int M, int Nout,
-                                                  void* __restrict__ out, const void* __restrict__ res,
-                                                  float* __restrict__ stats, int mtile, int ntile, int m0, int n0) {
+                                                  void* __restrict__ out, bool has_res, float* __restrict__ stats,
+                                                  const EpiBnRed& br, const EpiOperands<T, WROWS>& ops, int mtile,
+                                                  int ntile, int m0, int n0) {
     constexpr int EPV = 16 / (int)sizeof(T);          // elements per 16-byte vector
     constexpr int LPR = 64 / EPV;                     // lanes per 64-channel row
     constexpr int RPI = 64 / LPR;                     // rows per wave instruction
@@ -222,23 +275,53 @@ __device__ __forceinline__ void nt_epilogue_store(const char* mine, int P, char*
 #pragma unroll
     for (int e = 0; e < EPV; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
     T* o = reinterpret_cast<T*>(out);
-    const T* r = reinterpret_cast<const T*>(res);
-#pragma unroll 4
-    for (int it = 0; it < WROWS / RPI; ++it) {
-        const int row = it * RPI + rsub;
-        const int m = m0 + row;
-        Vec16<T> v = *reinterpret_cast<const Vec16<T>*>(mine + row * P + chunk * 16);
-        if (m < M && n < Nout) {
-            const size_t idx = (size_t)m * Nout + n;
-            if (r) {
-                const Vec16<T> rv = *reinterpret_cast<const Vec16<T>*>(r + idx);
+    if (stats && br.y) {
+        // BN-backward partials: per-channel constants of this lane's EPV channels
+        float mu[EPV], is[EPV], ms[EPV], mb[EPV];
 #pragma unroll
-                for (int e = 0; e < EPV; ++e) v.set(e, v.get(e) + rv.get(e));
-            }
-            *reinterpret_cast<Vec16<T>*>(o + idx) = v;
+        for (int e = 0; e < EPV; ++e) {
+            const bool ok = n + e < Nout;
+            mu[e] = ok ? br.mean[n + e] : 0.f; is[e] = ok ? br.invstd[n + e] : 0.f;
+            ms[e] = (ok && br.mscale) ? br.mscale[n + e] : 0.f; mb[e] = (ok && br.mscale) ? br.mshift[n + e] : 1.f;
         }
 #pragma unroll
-        for (int e = 0; e < EPV; ++e) { const float x = v.get(e); s1[e] += x; s2[e] += x * x; }
+        for (int it = 0; it < WROWS / RPI; ++it) {
+            const int row = it * RPI + rsub;
+            const int m = m0 + row;
+            Vec16<T> v = *reinterpret_cast<const Vec16<T>*>(mine + row * P + chunk * 16);
+            if (m < M && n < Nout) {
+                if (has_res) {
+                    const Vec16<T> rr = ops.res_row(it);
+#pragma unroll
+                    for (int e = 0; e < EPV; ++e) v.set(e, v.get(e) + rr.get(e));
+                }
+                *reinterpret_cast<Vec16<T>*>(o + (size_t)m * Nout + n) = v;
+                const Vec16<T> yr = ops.y_row(it);
+#pragma unroll
+                for (int e = 0; e < EPV; ++e) {
+                    const float yy = yr.get(e);
+                    const float d = (yy * ms[e] + mb[e] > 0.f) ? v.get(e) : 0.f;      // the value as stored (rounded to T)
+                    s1[e] += d; s2[e] += d * (yy - mu[e]) * is[e];
+                }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int it = 0; it < WROWS / RPI; ++it) {
+            const int row = it * RPI + rsub;
+            const int m = m0 + row;
+            Vec16<T> v = *reinterpret_cast<const Vec16<T>*>(mine + row * P + chunk * 16);
+            if (m < M && n < Nout) {
+                if (has_res) {
+                    const Vec16<T> rr = ops.res_row(it);
+#pragma unroll
+                    for (int e = 0; e < EPV; ++e) v.set(e, v.get(e) + rr.get(e));
+                }
+                *reinterpret_cast<Vec16<T>*>(o + (size_t)m * Nout + n) = v;
+            }
+#pragma unroll
+            for (int e = 0; e < EPV; ++e) { const float x = v.get(e); s1[e] += x; s2[e] += x * x; }
+        }
     }
     if (stats) {
         // rows beyond M were gathered as zeros -> contribute 0.  Reduce over the lanes that share `chunk`.

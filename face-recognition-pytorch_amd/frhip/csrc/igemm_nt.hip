@@ -8,8 +8,8 @@ namespace frhip {
 
 bool halo_applicable(int dtype, int h, int w, int c, int k, int r, int s, int stride, int pad);
 int halo_block_m();
-int halo_run(int dtype, const void* a, const void* b, void* out, const void* res, float* stats, int n, int h, int w,
-             int c, int k, int sign, hipStream_t stream);
+int halo_run(int dtype, const void* a, const void* b, void* out, const void* res, float* stats, const EpiBnRed& br,
+             int n, int h, int w, int c, int k, int sign, hipStream_t stream);
 
 enum { EPI_STORE = 0, EPI_ATOMIC = 1 };
 
@@ -17,7 +17,7 @@ template <typename T, int WM, int WN, int MT, int EPI>
 __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void nt_kernel(NtGeom g, const void* __restrict__ a,
                                                            const void* __restrict__ b, void* __restrict__ out,
                                                            const void* __restrict__ res, float* __restrict__ stats,
-                                                           int mtiles, int ntiles) {
+                                                           EpiBnRed br, int mtiles, int ntiles) {
     typedef NtTile<T, WM, WN, MT> Tile;
     constexpr int WROWS = Tile::WROWS, THREADS = Tile::THREADS;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -34,9 +34,11 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void nt_kernel(NtGeom 
     const int m0 = mtile * Tile::BM + wm * WROWS, n0 = ntile * Tile::BN + wn * 64;
 
     if constexpr (EPI == EPI_STORE) {
+        EpiOperands<T, WROWS> eo;
+        eo.fetch(res, stats ? br.y : nullptr, g.M, g.Nout, m0, n0);
         const char* mine = ml.template stage_out<T>(smem);
-        nt_epilogue_store<T, WM, WN, WROWS, THREADS, Tile::BN>(mine, Tile::template stage_pitch<T>(), smem, g.M, g.Nout, out, res,
-                                                               stats, mtile, ntile, m0, n0);
+        nt_epilogue_store<T, WM, WN, WROWS, THREADS, Tile::BN>(mine, Tile::template stage_pitch<T>(), smem, g.M, g.Nout, out,
+                                                               res != nullptr, stats, br, eo, mtile, ntile, m0, n0);
     } else {
         constexpr int P = Tile::template stage_pitch<float>();
         const char* mine = ml.template stage_out<float>(smem);
@@ -52,7 +54,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void nt_kernel(NtGeom 
 
 template <typename T, int WM, int WN, int MT, int EPI>
 static int nt_launch_cfg(const NtGeom& g, const void* a, const void* b, void* out, const void* res,
-                         float* stats, int splits, hipStream_t stream) {
+                         float* stats, const EpiBnRed& br, int splits, hipStream_t stream) {
     typedef NtTile<T, WM, WN, MT> Tile;
     const int mtiles = (g.M + Tile::BM - 1) / Tile::BM, ntiles = (g.Nout + Tile::BN - 1) / Tile::BN;
     const int lds = (EPI == EPI_STORE) ? Tile::template lds_bytes<T>() : Tile::template lds_bytes<float>();
@@ -66,7 +68,7 @@ static int nt_launch_cfg(const NtGeom& g, const void* a, const void* b, void* ou
         attr_done = true;
     }
     dim3 grid(mtiles * ntiles, splits);
-    hipLaunchKernelGGL(kern, grid, dim3(Tile::THREADS), lds, stream, g, a, b, out, res, stats, mtiles, ntiles);
+    hipLaunchKernelGGL(kern, grid, dim3(Tile::THREADS), lds, stream, g, a, b, out, res, stats, br, mtiles, ntiles);
     return check_launch("igemm_nt");
 }
 
@@ -82,17 +84,19 @@ static int nt_pick_tile(int dtype, const NtGeom& g) {
     return 1;
 }
 
+static const EpiBnRed NO_BNRED = {nullptr, nullptr, nullptr, nullptr, nullptr};
+
 static int nt_dispatch(int dtype, const NtGeom& g, const void* a, const void* b, void* out, const void* res,
-                       float* stats, int splits, bool atomic, hipStream_t stream) {
+                       float* stats, const EpiBnRed& br, int splits, bool atomic, hipStream_t stream) {
     const int tile = nt_pick_tile(dtype, g);
 #define NT_GO(T, WM, WN, MT)                                                                              \
-    return atomic ? nt_launch_cfg<T, WM, WN, MT, EPI_ATOMIC>(g, a, b, out, res, stats, splits, stream)     \
-                  : nt_launch_cfg<T, WM, WN, MT, EPI_STORE>(g, a, b, out, res, stats, splits, stream)
+    return atomic ? nt_launch_cfg<T, WM, WN, MT, EPI_ATOMIC>(g, a, b, out, res, stats, br, splits, stream)     \
+                  : nt_launch_cfg<T, WM, WN, MT, EPI_STORE>(g, a, b, out, res, stats, br, splits, stream)
     if (dtype == FRHIP_DT_BF16) {
         switch (tile) {
             case 2: NT_GO(bf16_t, 4, 1, 4);
             case 3: NT_GO(bf16_t, 4, 2, 4);
-            case 4: if (!atomic) return nt_launch_cfg<bf16_t, 2, 4, 8, EPI_STORE>(g, a, b, out, res, stats, splits, stream);
+            case 4: if (!atomic) return nt_launch_cfg<bf16_t, 2, 4, 8, EPI_STORE>(g, a, b, out, res, stats, br, splits, stream);
                     NT_GO(bf16_t, 4, 2, 4);
             default: NT_GO(bf16_t, 2, 2, 4);
         }
@@ -156,21 +160,49 @@ extern "C" int frhip_conv_fwd(int dtype, const void* x, const void* w, void* y, 
     int rc = fill_geom(g, dtype, n, h, wd, c, ho, wo, k, r, s, stride, pad, 0, "frhip_conv_fwd");
     if (rc) return rc;
     if (halo_applicable(dtype, h, wd, c, k, r, s, stride, pad))
-        return halo_run(dtype, x, w, y, nullptr, stats_partial, n, h, wd, c, k, +1, stream);
-    return nt_dispatch(dtype, g, x, w, y, nullptr, stats_partial, 1, false, stream);
+        return halo_run(dtype, x, w, y, nullptr, stats_partial, NO_BNRED, n, h, wd, c, k, +1, stream);
+    return nt_dispatch(dtype, g, x, w, y, nullptr, stats_partial, NO_BNRED, 1, false, stream);
+}
+
+static int dgrad_run(int dtype, const void* dy, const void* wt, void* dx, const void* residual, float* stats,
+                     const EpiBnRed& br, int n, int h, int wd, int c, int k, int r, int s, int stride, int pad,
+                     hipStream_t stream, const char* who) {
+    // dx is [n,h,wd,c]; dy is [n,ho,wo,k]; wt is the transposed pack [c][r][s][k].
+    NtGeom g;
+    const int ho = (h + 2 * pad - r) / stride + 1, wo = (wd + 2 * pad - s) / stride + 1;
+    int rc = fill_geom(g, dtype, n, ho, wo, k, h, wd, c, r, s, stride, pad, 1, who);
+    if (rc) return rc;
+    if (halo_applicable(dtype, h, wd, k, c, r, s, stride, pad))       // gathered tensor = dy [n,h,w,k] -> dx [n,h,w,c]
+        return halo_run(dtype, dy, wt, dx, residual, stats, br, n, h, wd, k, c, -1, stream);
+    return nt_dispatch(dtype, g, dy, wt, dx, residual, stats, br, 1, false, stream);
 }
 
 extern "C" int frhip_conv_dgrad(int dtype, const void* dy, const void* wt, void* dx, const void* residual,
                                 int n, int h, int wd, int c, int k, int r, int s, int stride, int pad,
                                 hipStream_t stream) {
-    // dx is [n,h,wd,c]; dy is [n,ho,wo,k]; wt is the transposed pack [c][r][s][k].
-    NtGeom g;
-    const int ho = (h + 2 * pad - r) / stride + 1, wo = (wd + 2 * pad - s) / stride + 1;
-    int rc = fill_geom(g, dtype, n, ho, wo, k, h, wd, c, r, s, stride, pad, 1, "frhip_conv_dgrad");
-    if (rc) return rc;
-    if (halo_applicable(dtype, h, wd, k, c, r, s, stride, pad))       // gathered tensor = dy [n,h,w,k] -> dx [n,h,w,c]
-        return halo_run(dtype, dy, wt, dx, residual, nullptr, n, h, wd, k, c, -1, stream);
-    return nt_dispatch(dtype, g, dy, wt, dx, residual, nullptr, 1, false, stream);
+    return dgrad_run(dtype, dy, wt, dx, residual, nullptr, NO_BNRED, n, h, wd, c, k, r, s, stride, pad, stream, "frhip_conv_dgrad");
+}
+
+extern "C" int frhip_dgrad_stat_rows(int dtype, int n, int h, int wd, int c, int k, int r, int s, int stride, int pad) {
+    const int m = n * h * wd;
+    if (halo_applicable(dtype, h, wd, k, c, r, s, stride, pad)) return (m + halo_block_m() - 1) / halo_block_m();
+    NtGeom g; g.M = m; g.Nout = c;
+    static const int bm_of[5] = {128, 128, 256, 256, 256};
+    const int bm = bm_of[nt_pick_tile(dtype, g)];
+    return (m + bm - 1) / bm;
+}
+
+extern "C" int frhip_conv_dgrad_bnred(int dtype, const void* dy, const void* wt, void* dx, const void* residual,
+                                      const void* y_bn, const float* mean, const float* invstd, const float* mask_scale,
+                                      const float* mask_shift, float* stats_partial, int n, int h, int wd, int c, int k,
+                                      int r, int s, int stride, int pad, hipStream_t stream) {
+    if (!y_bn || !mean || !invstd || !stats_partial || (mask_scale && !mask_shift)) {
+        set_error("frhip_conv_dgrad_bnred: y_bn, mean, invstd and stats_partial are required");
+        return FRHIP_EINVAL;
+    }
+    const EpiBnRed br = {y_bn, mean, invstd, mask_scale, mask_shift};
+    return dgrad_run(dtype, dy, wt, dx, residual, stats_partial, br, n, h, wd, c, k, r, s, stride, pad, stream,
+                     "frhip_conv_dgrad_bnred");
 }
 
 extern "C" int frhip_gemm_nt(int dtype, const void* a, const void* b, void* out, int m, int n, int k,
@@ -184,5 +216,5 @@ extern "C" int frhip_gemm_nt(int dtype, const void* a, const void* b, void* out,
     if (splits > g.ksteps) splits = g.ksteps;
     g.ksteps_per_split = (g.ksteps + splits - 1) / splits;
     splits = (g.ksteps + g.ksteps_per_split - 1) / g.ksteps_per_split;
-    return nt_dispatch(dtype, g, a, b, out, nullptr, nullptr, splits, atomic_f32 != 0, stream);
+    return nt_dispatch(dtype, g, a, b, out, nullptr, nullptr, NO_BNRED, splits, atomic_f32 != 0, stream);
 }

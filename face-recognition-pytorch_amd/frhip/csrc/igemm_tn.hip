@@ -369,84 +369,119 @@ __global__ __launch_bounds__(TN_THREADS, 2) void tn_lin_kernel(TnGeom g, const v
 
 // ------------------------------------------------------------------------------------------------------------------
 // "All nine taps" weight-gradient for 3x3 / stride-1 / pad-1 convolutions, bf16.
-// One workgroup owns a (64 co x 64 ci) tile for ALL nine taps.  Per K step (64 output pixels) it stages the dy rows
-// once and ONE input window of 64 + 2W + 2 pixel rows (stride 1: the nine taps read the same rows at offsets
-// dy*W + dx), instead of nine (dy tile + x tile) pairs spread over nine workgroups: ~6x fewer LDS-DMA bytes, and the
-// dy fragments are transposed-read once and reused by all taps.  Padding is resolved at the transposed read (lanes
-// whose row is padding point at a zero block).  Every LDS address is computed once before the K loop.
-// Accumulators: 9 taps x (32x32 per wave) = 144 VGPRs.
-constexpr int TH_RB = 128;                                  // 64 channels of bf16 per row
-constexpr int TH_MAXW = 56;
-constexpr int TH_QROWS = ((TN_KP + 2 * TH_MAXW + 2 + 7) / 8) * 8;        // 184
-constexpr int TH_P_BYTES = TN_KP * TH_RB;                    // 8 KB
-constexpr int TH_STAGE = TH_P_BYTES + TH_QROWS * TH_RB;      // 31.5 KB
-constexpr int TH_ZERO = 2 * TH_STAGE;
-constexpr int TH_LDS = TH_ZERO + 16 > 4 * 32 * (32 * 4 + 16) ? TH_ZERO + 16 : 4 * 32 * (32 * 4 + 16);
+// The per-tap kernel above moves 32 KB of LDS-DMA per 1 M MACs (32 MAC/B): at ~70 GB/s of L2 -> LDS per CU it is
+// DMA-bound at less than half the MFMA rate.  Here one workgroup owns a (CO_T co x 64 ci) tile for ALL nine taps.
+// Per K step (64 output pixels) it stages the dy rows once and ONE input window of 64 + 2W + 2 pixel rows (stride 1:
+// the nine taps read the same rows at offsets dy*W + dx): 150-240 MAC/B, and the dy fragments are transposed-read once
+// and reused by all taps.  Padding is resolved at the transposed read (lanes whose row is padding point at a zero
+// block).  Every LDS address is computed once before the K loop.
+//   <2,4,4,1>: 128 co x 64 ci, eight waves, wave tile 64 x 16, 144 accumulator registers
+//              (a 64 x 32 wave tile needs 288 accumulators: more than the 256 AGPRs, the compiler then shuffles them)
+//   <1,4,4,1>:  64 co x 64 ci, four waves, same wave tile, two workgroups per CU
+// The inner loop is VALU-issue-bound before it is MFMA-bound (an MFMA shadows only ~3 VALU issues), so per fragment
+// read it does ONE select: offsets are stage-relative registers, the stage base is an instruction immediate.
+// Timing-only ablation switches (tools/ablate.py; results are WRONG with any bit set): 1 no per-step barrier, 2 no MFMA,
+// 4 no LDS fragment reads, 8 no in-loop DMA, 16 no epilogue.
+#ifndef FRHIP_ABL
+#define FRHIP_ABL 0
+#endif
+#ifndef T9_DEPTH
+#define T9_DEPTH 4
+#endif
+constexpr int T9_MAXW = 56;
+constexpr int T9_QROWS = 192;                               // 24 pieces of 8 rows >= 64 + 2*56 + 2
 
-__global__ __launch_bounds__(TN_THREADS, 1) void tn_taps9_kernel(TnGeom g, const void* __restrict__ p_ptr,
-                                                                 const void* __restrict__ q_ptr, float* __restrict__ out,
-                                                                 int co_tiles, int ci_tiles) {
+template <int WCO, int WCI, int COF, int CIF>
+struct T9Cfg {
+    static_assert(WCI * CIF * 16 == 64 && COF == 4, "64 input channels per tile");
+    static constexpr int NW = WCO * WCI;                     // waves: 4 or 8
+    static constexpr int QPW_MAX = 24 / NW;                  // window pieces per wave (upper bound)
+    static constexpr int CO_T = WCO * COF * 16;              // 64 or 128 output channels per tile
+    static constexpr int P_RB = CO_T * 2;                    // bytes per dy row: 128 or 256
+    static constexpr int P_BYTES = TN_KP * P_RB;
+    static constexpr int P_PIECES = P_BYTES / 1024 / NW;     // 1-KiB DMA pieces per wave
+    static constexpr int P_CHUNKS = P_RB / 16, P_RPP = 1024 / P_RB;
+    static constexpr int Q_BYTES = T9_QROWS * 128;
+    static constexpr int ZERO = P_BYTES + Q_BYTES;           // 64 zero bytes at the end of EACH stage
+    static constexpr int STAGE = ZERO + 64;                  // two stages; stage-relative offsets + an immediate
+    static constexpr int EP = CIF * 16 * 4 + 16;             // epilogue staging pitch (bytes)
+    static constexpr int EPI_BYTES = NW * COF * 16 * EP;
+    static constexpr int LDS = (2 * STAGE > EPI_BYTES) ? 2 * STAGE : EPI_BYTES;
+    static_assert(2 * STAGE <= 65536 + STAGE && STAGE < 65536, "stage base must fit the 16-bit DS offset field");
+};
+
+template <int WCO, int WCI, int COF, int CIF>
+__global__ __launch_bounds__(64 * WCO * WCI, (WCO * WCI > 4 ? 1 : 2))
+void tn_taps9_kernel(TnGeom g, const void* __restrict__ p_ptr, const void* __restrict__ q_ptr, float* __restrict__ out,
+                     int co_tiles, int ci_tiles) {
     typedef bf16_t T;
+    typedef T9Cfg<WCO, WCI, COF, CIF> Cfg;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = lane_id(), wave = wave_id();
     const uint32_t lin = xcd_remap(blockIdx.x, gridDim.x);
     const int ci_tile = (int)(lin % (uint32_t)ci_tiles), co_tile = (int)(lin / (uint32_t)ci_tiles);
     const int ks_begin = blockIdx.y * g.ksteps_per_split;
     const int ks_end = min(g.ksteps, ks_begin + g.ksteps_per_split);
-    const int wco = wave >> 1, wci = wave & 1;
-    const int co0 = co_tile * 64, ci0 = ci_tile * 64;
+    const int wco = wave / WCI, wci = wave % WCI;
+    const int co0 = co_tile * Cfg::CO_T, ci0 = ci_tile * 64;
     const int qrows = TN_KP + 2 * g.W + 2, qpieces = (qrows + 7) >> 3;
+    const int qpw = (qpieces + Cfg::NW - 1) / Cfg::NW;      // window pieces per wave
 
-    f32x4_t acc[9][2][2];
+    f32x4_t acc[9][COF][CIF];
 #pragma unroll
     for (int t = 0; t < 9; ++t)
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
+        for (int a = 0; a < COF; ++a)
 #pragma unroll
-            for (int b = 0; b < 2; ++b) acc[t][a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    if (threadIdx.x == 0) *reinterpret_cast<f32x4_t*>(smem + TH_ZERO) = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            for (int b = 0; b < CIF; ++b) acc[t][a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    if (threadIdx.x < 8)
+        *reinterpret_cast<f32x4_t*>(smem + (threadIdx.x >> 2) * Cfg::STAGE + Cfg::ZERO + (threadIdx.x & 3) * 16) = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
     const __amdgpu_buffer_rsrc_t rp = make_rsrc(p_ptr, g.p_bytes);
     const __amdgpu_buffer_rsrc_t rq = make_rsrc(q_ptr, g.q_bytes);
 
-    // ---- loader: pieces of 8 rows x 128 B.  P: 8 pieces (2 per wave); Q window: up to 23 pieces (6 per wave).
-    const int sub = lane >> 3, phys = lane & 7;
-    uint32_t offp[2], offq[6];
-    bool okq[6];
+    // ---- loader: 1-KiB pieces.  dy: P_RPP rows of P_RB bytes per piece; window: 8 rows of 128 B per piece.
+    uint32_t offp[Cfg::P_PIECES], offq[Cfg::QPW_MAX];
+    bool okp[Cfg::P_PIECES], okq[Cfg::QPW_MAX];
     const uint32_t incp = (uint32_t)(TN_KP * g.ldp) * 2u, incq = (uint32_t)(TN_KP * g.C) * 2u;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int row = (wave * 2 + j) * 8 + sub;
-        const int ce = (phys ^ tn_swz<TH_RB>(row)) * 8;
-        offp[j] = (co0 + ce < g.ldp) ? (uint32_t)(((ks_begin * TN_KP + row) * g.ldp + co0 + ce) * 2) : OOB_OFFSET;
+    for (int j = 0; j < Cfg::P_PIECES; ++j) {
+        const int row = (wave * Cfg::P_PIECES + j) * Cfg::P_RPP + lane / Cfg::P_CHUNKS;
+        const int ce = ((lane % Cfg::P_CHUNKS) ^ tn_swz<Cfg::P_RB>(row)) * 8;
+        okp[j] = co0 + ce < g.ldp;
+        offp[j] = (uint32_t)(((ks_begin * TN_KP + row) * g.ldp + co0 + ce) * 2);     // rows past M lie beyond p_bytes -> zero fill
     }
-    const bool p_col_ok0 = offp[0] != OOB_OFFSET, p_col_ok1 = offp[1] != OOB_OFFSET;
 #pragma unroll
-    for (int j = 0; j < 6; ++j) {
-        const int piece = wave + 4 * j;
-        const int row = piece * 8 + sub;
-        const int ce = (phys ^ tn_swz<TH_RB>(row)) * 8;
-        okq[j] = piece < qpieces && ci0 + ce < g.C;
+    for (int j = 0; j < Cfg::QPW_MAX; ++j) {
+        const int row = (wave + Cfg::NW * j) * 8 + (lane >> 3);
+        const int ce = ((lane & 7) ^ tn_swz<128>(row)) * 8;
+        okq[j] = ci0 + ce < g.C;
         offq[j] = (uint32_t)(((ks_begin * TN_KP - g.W - 1 + row) * g.C + ci0 + ce) * 2);   // negative pixel -> out of range
     }
     auto stage = [&](int buf) {
-        char* sp = smem + buf * TH_STAGE;
-        char* sq = sp + TH_P_BYTES;
-        glds16(rp, sp + (wave * 2 + 0) * 1024, p_col_ok0 ? offp[0] : OOB_OFFSET);
-        glds16(rp, sp + (wave * 2 + 1) * 1024, p_col_ok1 ? offp[1] : OOB_OFFSET);
-        offp[0] += incp; offp[1] += incp;
+        char* sp = smem + buf * Cfg::STAGE;
+        char* sq = sp + Cfg::P_BYTES;
 #pragma unroll
-        for (int j = 0; j < 6; ++j) {
-            if (wave + 4 * j < qpieces) glds16(rq, sq + (wave + 4 * j) * 1024, okq[j] ? offq[j] : OOB_OFFSET);
+        for (int j = 0; j < Cfg::P_PIECES; ++j) {
+            glds16(rp, sp + (wave * Cfg::P_PIECES + j) * 1024, okp[j] ? offp[j] : OOB_OFFSET);
+            offp[j] += incp;
+        }
+#pragma unroll
+        for (int j = 0; j < Cfg::QPW_MAX; ++j) {
+            if (j < qpw) glds16(rq, sq + (wave + Cfg::NW * j) * 1024, okq[j] ? offq[j] : OOB_OFFSET);
             offq[j] += incq;
         }
     };
 
-    // ---- consumer: the four pixel rows (of the 64) this lane addresses in the transposed reads
+    // ---- consumer: the four pixel rows (of the 64) this lane addresses in the transposed reads.  All offsets are
+    //      stage-relative; the stage base is a compile-time constant of the unrolled K loop and lands in the DS
+    //      instruction's immediate, so a read costs one select (padding -> zero block) and nothing else.
     const int fg = lane >> 4, fj = lane & 15, fq = fj >> 2, fp = fj & 3;
-    int pho[4], pwo[4], pm[4];
-    int pa[4];             // P slot of row i, channel tile 0 (tile 1 = ^32)
-    int qa[9][4];          // Q slot of row i at tap t, channel tile 0 (tile 1 = ^32)
+    const uint32_t lds0 = (uint32_t)(uintptr_t)LDS_ADDR(smem);      // LDS byte address of stage 0
+    const uint32_t zero_a = lds0 + (uint32_t)Cfg::ZERO;
+    int pho[4], pwo[4];
+    uint32_t pa[4];        // dy slot of row i, channel tile 0 (tile t = ^ (t << 5))
+    uint32_t qa[9][4];     // window slot of row i at tap t
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int prow = (i >> 1) * 32 + 8 * fg + fq + 4 * (i & 1);          // i = 2*kk + half
@@ -454,109 +489,140 @@ __global__ __launch_bounds__(TN_THREADS, 1) void tn_taps9_kernel(TnGeom g, const
         const uint32_t n = fdiv(m, g.d_howo);
         const uint32_t rem = m - n * (uint32_t)(g.Ho * g.Wo);
         const uint32_t ho = fdiv(rem, g.d_wo);
-        pm[i] = (int)m; pho[i] = (int)ho; pwo[i] = (int)(rem - ho * (uint32_t)g.Wo);
-        const int cp = ((wco * 32) >> 3) + (fp >> 1), cq = ((wci * 32) >> 3) + (fp >> 1);
-        pa[i] = prow * TH_RB + ((cp ^ tn_swz<TH_RB>(prow)) << 4) + 8 * (fp & 1);
+        pho[i] = (int)ho; pwo[i] = (int)(rem - ho * (uint32_t)g.Wo);
+        const int cp = wco * COF * 2 + (fp >> 1), cq = wci * CIF * 2 + (fp >> 1);
+        pa[i] = lds0 + (uint32_t)(prow * Cfg::P_RB + ((cp ^ tn_swz<Cfg::P_RB>(prow)) << 4) + 8 * (fp & 1));
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
             const int qrow = prow + g.W + 1 + (t / 3 - 1) * g.W + (t % 3 - 1);
-            qa[t][i] = TH_P_BYTES + qrow * TH_RB + ((cq ^ tn_swz<TH_RB>(qrow)) << 4) + 8 * (fp & 1);
+            qa[t][i] = lds0 + (uint32_t)(Cfg::P_BYTES + qrow * 128 + ((cq ^ tn_swz<128>(qrow)) << 4) + 8 * (fp & 1));
         }
     }
     typedef __attribute__((ext_vector_type(8))) short i16x8_t;
-    auto tr8 = [&](const char* lo_p, const char* hi_p) {
-        i16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4_t*)LDS_ADDR(lo_p));
-        i16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4_t*)LDS_ADDR(hi_p));
-        return __builtin_bit_cast(bf16x8_t, (i16x8_t)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+    // lo_a / hi_a: LDS byte addresses in stage 0; OFF (compile time) selects the stage through the DS immediate
+    auto tr8 = [&](auto off_c, uint32_t lo_a, uint32_t hi_a) {
+        constexpr int OFF = decltype(off_c)::value;
+        typedef __attribute__((address_space(3))) i16x4_t* lds_p;
+        if constexpr (FRHIP_ABL & 4) {
+            bf16x8_t f; asm volatile("" : "=v"(f) : "v"(lo_a), "v"(hi_a)); return f;
+        } else {
+            i16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)((__attribute__((address_space(3))) char*)(uintptr_t)lo_a + OFF));
+            i16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)((__attribute__((address_space(3))) char*)(uintptr_t)hi_a + OFF));
+            return __builtin_bit_cast(bf16x8_t, (i16x8_t)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+        }
     };
 
-    auto compute = [&](int buf) {
-        const char* base = smem + buf * TH_STAGE;
-        const char* zero = smem + TH_ZERO;
-        bool up[4], dn[4], lf[4], rt[4], live[4];
+    auto compute = [&](auto buf_c) {
+        typedef std::integral_constant<int, decltype(buf_c)::value * Cfg::STAGE> Off;
+        // rows past M need no mask: their dy rows were zero-filled and every window row read is finite data or zero
+        bool up[4], dn[4], lf[4], rt[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            live[i] = pm[i] < g.M;
-            up[i] = pho[i] > 0; dn[i] = pho[i] < g.H - 1; lf[i] = pwo[i] > 0; rt[i] = pwo[i] < g.W - 1;
-        }
-        // software pipeline over the 18 (kk, tap) groups: the transposed reads of group n+1 are issued before the
-        // four MFMAs of group n, so LDS latency hides behind the matrix pipe (two register sets, qa / qb)
-        bf16x8_t pf[2][2];
+        for (int i = 0; i < 4; ++i) { up[i] = pho[i] > 0; dn[i] = pho[i] < g.H - 1; lf[i] = pwo[i] > 0; rt[i] = pwo[i] < g.W - 1; }
+        // software pipeline over the 18 (kk, tap) groups: the transposed reads of group n+1 (and the dy fragments of
+        // the second K half) are issued before the MFMAs of group n, so LDS latency hides behind the matrix pipe
+        bf16x8_t pf[2][COF];
+        auto loadp = [&](int kk) {
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            pf[kk][0] = tr8(base + pa[2 * kk], base + pa[2 * kk + 1]);
-            pf[kk][1] = tr8(base + (pa[2 * kk] ^ 32), base + (pa[2 * kk + 1] ^ 32));
-        }
-        auto loadq = [&](int n, bf16x8_t& q0, bf16x8_t& q1) {
+            for (int a = 0; a < COF; ++a)
+                pf[kk][a] = tr8(Off{}, pa[2 * kk] ^ (uint32_t)(a << 5), pa[2 * kk + 1] ^ (uint32_t)(a << 5));
+        };
+        auto loadq = [&](int n, bf16x8_t (&q)[CIF]) {
             const int kk = n / 9, t = n - kk * 9;
             const int i0 = 2 * kk, i1 = 2 * kk + 1;
             const int dy = t / 3 - 1, dx = t % 3 - 1;
-            const bool v0 = live[i0] && (dy < 0 ? up[i0] : (dy > 0 ? dn[i0] : true)) && (dx < 0 ? lf[i0] : (dx > 0 ? rt[i0] : true));
-            const bool v1 = live[i1] && (dy < 0 ? up[i1] : (dy > 0 ? dn[i1] : true)) && (dx < 0 ? lf[i1] : (dx > 0 ? rt[i1] : true));
-            q0 = tr8(v0 ? base + qa[t][i0] : zero, v1 ? base + qa[t][i1] : zero);
-            q1 = tr8(v0 ? base + (qa[t][i0] ^ 32) : zero, v1 ? base + (qa[t][i1] ^ 32) : zero);
-        };
-        auto mma4 = [&](int n, const bf16x8_t& q0, const bf16x8_t& q1) {
-            const int kk = n / 9, t = n - kk * 9;
-            Mma<T>::run(pf[kk][0], q0, acc[t][0][0]);
-            Mma<T>::run(pf[kk][0], q1, acc[t][0][1]);
-            Mma<T>::run(pf[kk][1], q0, acc[t][1][0]);
-            Mma<T>::run(pf[kk][1], q1, acc[t][1][1]);
-        };
-        bf16x8_t qa0, qa1, qb0, qb1;
-        loadq(0, qa0, qa1);
+            const bool v0 = (dy < 0 ? up[i0] : (dy > 0 ? dn[i0] : true)) && (dx < 0 ? lf[i0] : (dx > 0 ? rt[i0] : true));
+            const bool v1 = (dy < 0 ? up[i1] : (dy > 0 ? dn[i1] : true)) && (dx < 0 ? lf[i1] : (dx > 0 ? rt[i1] : true));
+            const uint32_t o0 = v0 ? qa[t][i0] : zero_a, o1 = v1 ? qa[t][i1] : zero_a;
 #pragma unroll
-        for (int n = 0; n < 18; n += 2) {
-            loadq(n + 1, qb0, qb1);
-            mma4(n, qa0, qa1);
-            if (n + 2 < 18) loadq(n + 2, qa0, qa1);
-            mma4(n + 1, qb0, qb1);
+            for (int b = 0; b < CIF; ++b)       // the zero block is 64 bytes, so ^32 stays inside it
+                q[b] = tr8(Off{}, o0 ^ (uint32_t)(b << 5), o1 ^ (uint32_t)(b << 5));
+        };
+        auto mma = [&](int n, const bf16x8_t (&q)[CIF]) {
+            const int kk = n / 9, t = n - kk * 9;
+#pragma unroll
+            for (int a = 0; a < COF; ++a)
+#pragma unroll
+                for (int b = 0; b < CIF; ++b) {
+                    if constexpr (FRHIP_ABL & 2) { bf16x8_t fa = pf[kk][a], fb = q[b]; asm volatile("" :: "v"(fa), "v"(fb)); }
+                    else Mma<T>::run(pf[kk][a], q[b], acc[t][a][b]);
+                }
+        };
+        // ring of DEPTH window-fragment sets: group n + DEPTH - 1 is read while group n multiplies (a group is only
+        // COF*CIF MFMAs = 64 matrix-pipe cycles, LDS latency under load is several times that)
+        constexpr int DEPTH = T9_DEPTH;
+        bf16x8_t qr[DEPTH][CIF];
+        loadp(0);
+#pragma unroll
+        for (int n = 0; n < DEPTH - 1; ++n) loadq(n, qr[n]);
+#pragma unroll
+        for (int n = 0; n < 18; ++n) {
+            if (n + DEPTH - 1 < 18) loadq(n + DEPTH - 1, qr[(n + DEPTH - 1) % DEPTH]);
+            if (n == 3) loadp(1);
+            mma(n, qr[n % DEPTH]);
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             int wo = pwo[i] + g.adv_wo, ho = pho[i] + g.adv_ho;
             if (wo >= g.Wo) { wo -= g.Wo; ++ho; }
             if (ho >= g.Ho) ho -= g.Ho;
-            pwo[i] = wo; pho[i] = ho; pm[i] += TN_KP;
+            pwo[i] = wo; pho[i] = ho;
         }
     };
 
+    // ---- K loop: two LDS stages (unrolled by two so the stage is a compile-time constant), DMA one step ahead
     if (ks_begin < ks_end) {
+        const int nks = ks_end - ks_begin;
         stage(0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        int cur = 0;
-        for (int ks = ks_begin; ks < ks_end - 1; ++ks) {
-            stage(cur ^ 1);
-            compute(cur);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            cur ^= 1;
+        auto step = [&](auto buf_c, int it) {
+            constexpr int BUF = decltype(buf_c)::value;
+            if (it + 1 < nks && !(FRHIP_ABL & 8)) stage(BUF ^ 1);
+            compute(buf_c);
+            if (it + 1 < nks) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if constexpr (!(FRHIP_ABL & 1)) __builtin_amdgcn_s_barrier();
+            }
+        };
+        for (int it = 0; it < nks; it += 2) {
+            step(std::integral_constant<int, 0>{}, it);
+            if (it + 1 < nks) step(std::integral_constant<int, 1>{}, it + 1);
         }
-        compute(cur);
     }
-    // ---- epilogue, tap by tap: 32x32 per wave -> LDS -> row-wise fp32 atomic adds into dw[co][tap][ci]
-    constexpr int P = 32 * 4 + 16;
-    char* mine = smem + wave * 32 * P;
+    // ---- epilogue, tap by tap: (COF*16 x CIF*16) per wave -> LDS -> row-wise fp32 stores / atomic adds into dw[co][tap][ci]
+    constexpr int EP = Cfg::EP, WCOT = COF * 16, WCIT = CIF * 16;
+    char* mine = smem + wave * WCOT * EP;
     const int fi = lane & 15;
-    const int col = lane & 31, rsub = lane >> 5;
+    constexpr int RPI = 64 / WCIT;                    // rows per wave instruction
+    const int col = lane % WCIT, rsub = lane / WCIT;
+    if constexpr (FRHIP_ABL & 16) {
+        if (g.M >= 0) {
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+#pragma unroll
+                for (int a = 0; a < COF; ++a)
+#pragma unroll
+                    for (int b = 0; b < CIF; ++b) asm volatile("" :: "v"(acc[t][a][b]));
+            return;
+        }
+    }
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
         __syncthreads();
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
+        for (int a = 0; a < COF; ++a)
 #pragma unroll
-            for (int b = 0; b < 2; ++b)
+            for (int b = 0; b < CIF; ++b)
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
-                    *reinterpret_cast<float*>(mine + (a * 16 + 4 * fg + e) * P + (b * 16 + fi) * 4) = acc[t][a][b][e];
+                    *reinterpret_cast<float*>(mine + (a * 16 + 4 * fg + e) * EP + (b * 16 + fi) * 4) = acc[t][a][b][e];
         __syncthreads();
-        const int ci = ci0 + wci * 32 + col;
-        for (int it = 0; it < 16; ++it) {
-            const int row = it * 2 + rsub;
-            const int co = co0 + wco * 32 + row;
+        const int ci = ci0 + wci * WCIT + col;
+        for (int it = 0; it < WCOT / RPI; ++it) {
+            const int row = it * RPI + rsub;
+            const int co = co0 + wco * WCOT + row;
             if (co < g.Kc && ci < g.C) {
-                const float v = *reinterpret_cast<const float*>(mine + row * P + col * 4);
+                const float v = *reinterpret_cast<const float*>(mine + row * EP + col * 4);
                 const size_t idx = ((size_t)co * 9 + t) * g.C + ci;
                 if (g.slab_stride) out[(size_t)blockIdx.y * g.slab_stride + idx] = v;
                 else atomicAdd(out + idx, v);
@@ -567,31 +633,47 @@ __global__ __launch_bounds__(TN_THREADS, 1) void tn_taps9_kernel(TnGeom g, const
 
 static int g_tn_taps9 = 1;
 
+template <int WCO, int WCI, int COF, int CIF>
 static int tn_taps9_launch(const TnGeom& g, const void* p, const void* q, float* out, int splits, hipStream_t stream) {
-    const int co_tiles = (g.Kc + 63) / 64, ci_tiles = (g.C + 63) / 64;
+    typedef T9Cfg<WCO, WCI, COF, CIF> Cfg;
+    const int co_tiles = (g.Kc + Cfg::CO_T - 1) / Cfg::CO_T, ci_tiles = (g.C + 63) / 64;
+    auto kern = tn_taps9_kernel<WCO, WCI, COF, CIF>;
     static bool attr_done = false;
     if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(tn_taps9_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, TH_LDS) != hipSuccess) {
-            set_error("igemm_tn(taps9): cannot raise dynamic LDS to %d bytes", TH_LDS);
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS) != hipSuccess) {
+            set_error("igemm_tn(taps9): cannot raise dynamic LDS to %d bytes", Cfg::LDS);
             return FRHIP_ELAUNCH;
         }
         attr_done = true;
     }
-    hipLaunchKernelGGL(tn_taps9_kernel, dim3(co_tiles * ci_tiles, splits), dim3(TN_THREADS), TH_LDS, stream, g, p, q, out,
-                       co_tiles, ci_tiles);
+    hipLaunchKernelGGL(kern, dim3(co_tiles * ci_tiles, splits), dim3(64 * Cfg::NW), Cfg::LDS, stream, g, p, q, out, co_tiles, ci_tiles);
     return check_launch("igemm_tn(taps9)");
 }
 
-// out[i] += sum_s slabs[s][i]   (float4 per thread; the slabs were written by plain stores, so this is deterministic)
-__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slabs, int splits, size_t stride,
-                                                          float* __restrict__ out, size_t n4) {
+// Sum of K-split slabs, float4 per thread, no atomics (deterministic).  blockIdx.y = g owns slabs g*per_group ..:
+//   final == 0: their sum overwrites the group's first slab (first level of a two-level tree)
+//   final == 1: out[i] += sum (gridDim.y must be 1)
+__global__ __launch_bounds__(256) void slab_reduce_kernel(float* __restrict__ slabs, int count, int per_group,
+                                                          size_t step, float* __restrict__ out, size_t n4, int final) {
+    const int s0 = blockIdx.y * per_group, s1 = min(count, s0 + per_group);
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
-        f32x4_t acc = reinterpret_cast<const f32x4_t*>(out)[i];
-        for (int sp = 0; sp < splits; ++sp) {
-            const f32x4_t v = *reinterpret_cast<const f32x4_t*>(slabs + (size_t)sp * stride + i * 4);
-            acc[0] += v[0]; acc[1] += v[1]; acc[2] += v[2]; acc[3] += v[3];
+        f32x4_t a0 = f32x4_t{0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
+        int sp = s0;
+        for (; sp + 4 <= s1; sp += 4) {
+            const f32x4_t v0 = *reinterpret_cast<const f32x4_t*>(slabs + (size_t)(sp + 0) * step + i * 4);
+            const f32x4_t v1 = *reinterpret_cast<const f32x4_t*>(slabs + (size_t)(sp + 1) * step + i * 4);
+            const f32x4_t v2 = *reinterpret_cast<const f32x4_t*>(slabs + (size_t)(sp + 2) * step + i * 4);
+            const f32x4_t v3 = *reinterpret_cast<const f32x4_t*>(slabs + (size_t)(sp + 3) * step + i * 4);
+            a0 += v0; a1 += v1; a2 += v2; a3 += v3;
         }
-        reinterpret_cast<f32x4_t*>(out)[i] = acc;
+        for (; sp < s1; ++sp) a0 += *reinterpret_cast<const f32x4_t*>(slabs + (size_t)sp * step + i * 4);
+        f32x4_t acc = (a0 + a1) + (a2 + a3);
+        if (final) {
+            acc += reinterpret_cast<const f32x4_t*>(out)[i];
+            reinterpret_cast<f32x4_t*>(out)[i] = acc;
+        } else {
+            *reinterpret_cast<f32x4_t*>(slabs + (size_t)s0 * step + i * 4) = acc;
+        }
     }
 }
 
@@ -638,9 +720,9 @@ static int tn_launch(const TnGeom& g, const void* p, const void* q, float* out, 
 // deterministic reduce pass) when it is large enough, else fp32 atomics straight into `out`.
 static float* tn_pick_dst(TnGeom& g, float* out, int splits, size_t out_elems, float* ws, size_t ws_bytes) {
     g.slab_stride = 0;
-    // measured: slabs win up to a few dozen splits (163 vs 176 us at 14 splits); with hundreds of splits of a tiny
-    // output the serial slab walk of the reduce pass loses to atomics (372 vs 286 us at 512 splits)
-    if (splits > 1 && splits <= 48 && ws && (out_elems % 4) == 0 && out_elems >= 65536 &&
+    // same-address fp32 atomics from hundreds of K splits serialise in L2 (75 us for 500 splits of a 147 KB tile);
+    // slabs + a grouped reduce pass cost two streaming passes over splits * out bytes instead
+    if (splits > 1 && ws && (out_elems % 4) == 0 && out_elems >= 16384 &&
         (size_t)splits * out_elems * sizeof(float) <= ws_bytes) {
         g.slab_stride = (int)out_elems;
         return ws;
@@ -648,11 +730,23 @@ static float* tn_pick_dst(TnGeom& g, float* out, int splits, size_t out_elems, f
     return out;
 }
 
-static int tn_finish(const TnGeom& g, float* out, int splits, size_t out_elems, const float* ws, hipStream_t stream) {
+static int tn_finish(const TnGeom& g, float* out, int splits, size_t out_elems, float* ws, hipStream_t stream) {
     if (!g.slab_stride) return FRHIP_OK;
     const size_t n4 = out_elems / 4;
     int blocks = (int)((n4 + 255) / 256); if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks), dim3(256), 0, stream, ws, splits, out_elems, out, n4);
+    // one pass while it has enough blocks to stream (or few slabs); else a two-level tree: groups of slabs first
+    int groups = 1;
+    while (splits > 32 * groups && blocks * groups < 512) groups *= 2;
+    if (groups > 1) {
+        const int per_group = (splits + groups - 1) / groups;
+        groups = (splits + per_group - 1) / per_group;
+        hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks, groups), dim3(256), 0, stream, ws, splits, per_group,
+                           out_elems, (float*)nullptr, n4, 0);
+        hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks, 1), dim3(256), 0, stream, ws, groups, groups,
+                           (size_t)per_group * out_elems, out, n4, 1);
+    } else {
+        hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks, 1), dim3(256), 0, stream, ws, splits, splits, out_elems, out, n4, 1);
+    }
     return check_launch("igemm_tn(slab reduce)");
 }
 
@@ -684,19 +778,18 @@ static int tn_run(int dtype, const void* p, const void* q, float* out, int n, in
     const size_t out_elems = (size_t)kc * taps * c;
     if (out_elems > 0x7fffffffULL) { set_error("%s: output too large", who); return FRHIP_EINVAL; }
     int rc;
-    // measured (tools/bench_kernels.py wgrad, B=512): the nine-tap kernel wins where the per-tap tile is DMA-starved
-    // (64 channels: 293 vs 455 us) and loses to the 128x128-per-tap kernel from 128 channels up (LDS-read latency
-    // of its 32x32 wave tiles); g_tn_taps9 == 2 forces it everywhere (tests).
-    if (g_tn_taps9 && (g_tn_taps9 == 2 || (c <= 64 && kc <= 64)) && dtype == FRHIP_DT_BF16 && r == 3 && s == 3 &&
-        stride == 1 && pad == 1 && w <= TH_MAXW &&
+    // The nine-tap kernel covers every 3x3/s1/p1 bf16 layer (g_tn_taps9: 0 off, 1/2 on); wide = 128-co tiles.
+    if (g_tn_taps9 && dtype == FRHIP_DT_BF16 && r == 3 && s == 3 && stride == 1 && pad == 1 && w <= T9_MAXW &&
         1LL * (M + 64 + 2LL * w + 2) * (ldp > c ? ldp : c) * es < 0x7fffffffLL) {
-        const long long tiles = 1LL * ((kc + 63) / 64) * ((c + 63) / 64);
-        const int slots = 256 * 2;
+        const bool wide = kc > 64;
+        const int co_t = wide ? 128 : 64;
+        const long long tiles = 1LL * ((kc + co_t - 1) / co_t) * ((c + 63) / 64);
+        const int slots = 256 * (wide ? 1 : 2);
         int best = 1; double best_t = 1e30;
         const int max_splits = g.ksteps / 8 > 0 ? g.ksteps / 8 : 1;
         for (int sp = 1; sp <= max_splits && sp <= 1024; ++sp) {
             const long long rounds = (tiles * sp + slots - 1) / slots;
-            const double t = (double)rounds * ((double)g.ksteps / sp + 12.0);       // epilogue ~ 12 K steps (nine atomic passes)
+            const double t = (double)rounds * ((double)g.ksteps / sp + 8.0);       // epilogue ~ 8 K steps (nine store passes)
             if (t < best_t * 0.98) { best_t = t; best = sp; }
         }
         if (splits <= 0) splits = best;
@@ -704,7 +797,8 @@ static int tn_run(int dtype, const void* p, const void* q, float* out, int n, in
         g.ksteps_per_split = (g.ksteps + splits - 1) / splits;
         splits = (g.ksteps + g.ksteps_per_split - 1) / g.ksteps_per_split;
         float* dst = tn_pick_dst(g, out, splits, out_elems, ws, ws_bytes);
-        rc = tn_taps9_launch(g, p, q, dst, splits, stream);
+        rc = wide ? tn_taps9_launch<2, 4, 4, 1>(g, p, q, dst, splits, stream)
+                  : tn_taps9_launch<1, 4, 4, 1>(g, p, q, dst, splits, stream);
         return rc ? rc : tn_finish(g, out, splits, out_elems, ws, stream);
     }
     const bool big = (c * es >= 256) && (kc * es >= 256);

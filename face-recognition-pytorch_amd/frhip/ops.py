@@ -52,14 +52,27 @@ def conv_fwd(x, w, stride, pad, want_stats=True):
     return y, part
 
 
-def conv_dgrad(dy, wt, x_shape, r, s, stride, pad, residual=None, out=None):
-    """dy [N,Ho,Wo,K], wt [C,R,S,K] -> dx [N,H,W,C] (+ residual)"""
+def conv_dgrad(dy, wt, x_shape, r, s, stride, pad, residual=None, out=None, bnred=None):
+    """dy [N,Ho,Wo,K], wt [C,R,S,K] -> dx [N,H,W,C] (+ residual).
+
+    bnred=(y_bn, st, relu_mask): dx is the upstream gradient of a BatchNorm with saved input y_bn and batch state st;
+    the BN-backward partial sums come out of the epilogue and (dx, partial) is returned -- pass partial to bn_backward."""
     n, h, wd, c = x_shape
     k = dy.shape[3]
     dx = out if out is not None else torch.empty(x_shape, dtype=dy.dtype, device=dy.device)
-    check(lib().frhip_conv_dgrad(dt_of(dy), _p(dy), _p(wt), _p(dx), _p(residual), n, h, wd, c, k, r, s, stride, pad, _s()),
-          "frhip_conv_dgrad")
-    return dx
+    if bnred is None:
+        check(lib().frhip_conv_dgrad(dt_of(dy), _p(dy), _p(wt), _p(dx), _p(residual), n, h, wd, c, k, r, s, stride, pad, _s()),
+              "frhip_conv_dgrad")
+        return dx
+    y_bn, st, relu_mask = bnred
+    if tuple(y_bn.shape) != tuple(x_shape) or y_bn.dtype != dy.dtype:
+        raise ValueError("conv_dgrad(bnred): y_bn must have the shape and dtype of dx")
+    rows = lib().frhip_dgrad_stat_rows(dt_of(dy), n, h, wd, c, k, r, s, stride, pad)
+    part = torch.empty((rows, 2, c), dtype=torch.float32, device=dy.device)
+    check(lib().frhip_conv_dgrad_bnred(dt_of(dy), _p(dy), _p(wt), _p(dx), _p(residual), _p(y_bn), _p(st.mean), _p(st.invstd),
+                                       _p(st.scale) if relu_mask else None, _p(st.shift) if relu_mask else None, _p(part),
+                                       n, h, wd, c, k, r, s, stride, pad, _s()), "frhip_conv_dgrad_bnred")
+    return dx, part
 
 
 _WORKSPACES = {}
@@ -158,17 +171,20 @@ def bn_apply(y, st, relu=False, res=None, res_st=None, out=None):
     return out
 
 
-def bn_backward(dout, y, st, gamma, dgamma, dbeta, relu_mask=False, out=None, scratch=None):
-    """dy of BN (optionally through the ReLU that follows it); accumulates dgamma/dbeta (fp32, caller-zeroed)."""
+def bn_backward(dout, y, st, gamma, dgamma, dbeta, relu_mask=False, out=None, scratch=None, part=None):
+    """dy of BN (optionally through the ReLU that follows it); accumulates dgamma/dbeta (fp32, caller-zeroed).
+    part: BN-backward partial sums already produced by conv_dgrad(bnred=...) for this (dout, y) pair."""
     c = y.shape[-1]
     rows = y.numel() // c
     dev = y.device
-    nb = lib().frhip_colreduce_blocks(rows, c, dt_of(y))
-    part = torch.empty((nb, 2, c), dtype=torch.float32, device=dev)
     ms = _p(st.scale) if relu_mask else None
     mb = _p(st.shift) if relu_mask else None
-    check(lib().frhip_bn_bwd_reduce(dt_of(y), _p(dout), _p(y), _p(st.mean), _p(st.invstd), ms, mb, rows, c, _p(part), _s()),
-          "frhip_bn_bwd_reduce")
+    if part is None:
+        nb = lib().frhip_colreduce_blocks(rows, c, dt_of(y))
+        part = torch.empty((nb, 2, c), dtype=torch.float32, device=dev)
+        check(lib().frhip_bn_bwd_reduce(dt_of(y), _p(dout), _p(y), _p(st.mean), _p(st.invstd), ms, mb, rows, c, _p(part), _s()),
+              "frhip_bn_bwd_reduce")
+    nb = part.shape[0]
     coef = torch.empty((3, c), dtype=torch.float32, device=dev)
     if scratch is None:
         scratch = torch.empty((64 * 2 * c,), dtype=torch.float32, device=dev)

@@ -224,11 +224,17 @@ class AlterNet(nn.Module):
         dt = self.dtype
         bc = BackwardCtx(params, d_emb.device)
         dout = tail_backward(self, sv, d_emb, bc)
-        for mod, s in zip(reversed(list(self._layers())), reversed(sv.layers)):
+        layers = list(self._layers())
+        part = None
+        for i in range(len(layers) - 1, -1, -1):
+            mod, s = layers[i], sv.layers[i]
             if isinstance(mod, BasicBlock):
-                dout = basic_block_backward(mod, s, dout, dt, bc)
+                prev_is_block = i > 0 and isinstance(layers[i - 1], BasicBlock)
+                nxt = (sv.layers[i - 1].y2, sv.layers[i - 1].st2) if prev_is_block else None
+                res = basic_block_backward(mod, s, dout, dt, bc, part2=part, next_bn=nxt)
+                dout, part = res if nxt is not None else (res, None)
             else:
-                dout = attn_block_backward(mod, s, dout, dt, bc)
+                dout, part = attn_block_backward(mod, s, dout, dt, bc), None
         stem_backward(self, sv, dout, bc)
         return bc.join()
 

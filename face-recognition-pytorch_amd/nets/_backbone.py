@@ -215,9 +215,12 @@ def basic_block_forward(blk, xin, dt, training, save):
     return out, s
 
 
-def basic_block_backward(blk, s, dout, dt, bc):
+def basic_block_backward(blk, s, dout, dt, bc, part2=None, next_bn=None):
+    """part2: BN-backward partial sums of (dout, s.y2) when the kernel that produced dout already reduced them.
+    next_bn=(y, st): the BatchNorm (no ReLU in between) that consumes the returned dx; its reduction is then fused into
+    the epilogue of conv1's data-gradient and (dx, partial) is returned instead of dx."""
     G = bc.G
-    dy2 = ops.bn_backward(dout, s.y2, s.st2, blk.bn2.weight.data, G(blk.bn2.weight), G(blk.bn2.bias))
+    dy2 = ops.bn_backward(dout, s.y2, s.st2, blk.bn2.weight.data, G(blk.bn2.weight), G(blk.bn2.bias), part=part2)
     shortcut = dout
     if blk.downsample is not None:
         dconv, dbn = blk.downsample[0], blk.downsample[1]
@@ -226,11 +229,16 @@ def basic_block_backward(blk, s, dout, dt, bc):
         shortcut = ops.conv_dgrad(dyd, wdt, s.x.shape, 1, 1, dconv.stride, 0)
         bc.wgrad(dyd, s.x, phys_grad(G(dconv.weight)), 1, 1, dconv.stride, 0)
     w2t = ops.pack_wt(blk.conv2.physical(), dt)
-    da1 = ops.conv_dgrad(dy2, w2t, s.a1.shape, 3, 3, blk.stride, 1)
+    # the BN1 (+ReLU) backward reduction over (da1, y1) rides in the epilogue of conv2's data-gradient
+    da1, part1 = ops.conv_dgrad(dy2, w2t, s.a1.shape, 3, 3, blk.stride, 1, bnred=(s.y1, s.st1, True))
     bc.wgrad(dy2, s.a1, phys_grad(G(blk.conv2.weight)), 3, 3, blk.stride, 1)
-    dy1 = ops.bn_backward(da1, s.y1, s.st1, blk.bn1.weight.data, G(blk.bn1.weight), G(blk.bn1.bias), relu_mask=True)
+    dy1 = ops.bn_backward(da1, s.y1, s.st1, blk.bn1.weight.data, G(blk.bn1.weight), G(blk.bn1.bias), relu_mask=True,
+                          part=part1)
     w1t = ops.pack_wt(blk.conv1.physical(), dt)
-    dx = ops.conv_dgrad(dy1, w1t, s.x.shape, 3, 3, 1, 1, residual=shortcut)
+    if next_bn is not None:
+        dx = ops.conv_dgrad(dy1, w1t, s.x.shape, 3, 3, 1, 1, residual=shortcut, bnred=(next_bn[0], next_bn[1], False))
+    else:
+        dx = ops.conv_dgrad(dy1, w1t, s.x.shape, 3, 3, 1, 1, residual=shortcut)
     bc.wgrad(dy1, s.x, phys_grad(G(blk.conv1.weight)), 3, 3, 1, 1)
     return dx
 

@@ -80,8 +80,13 @@ class ResNet(nn.Module):
     def _backward_impl(self, sv, d_emb, params):
         bc = BackwardCtx(params, d_emb.device)
         dout = tail_backward(self, sv, d_emb, bc)
-        for blk, s in zip(reversed(list(self._blocks())), reversed(sv.blocks)):
-            dout = basic_block_backward(blk, s, dout, self.dtype, bc)
+        blocks = list(self._blocks())
+        part = None
+        for i in range(len(blocks) - 1, -1, -1):
+            # the gradient leaving block i enters bn2 of block i-1: its reduction rides in block i's last kernel
+            nxt = (sv.blocks[i - 1].y2, sv.blocks[i - 1].st2) if i > 0 else None
+            res = basic_block_backward(blocks[i], sv.blocks[i], dout, self.dtype, bc, part2=part, next_bn=nxt)
+            dout, part = res if nxt is not None else (res, None)
         stem_backward(self, sv, dout, bc)
         return bc.join()
 

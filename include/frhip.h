@@ -63,6 +63,16 @@ int frhip_conv_fwd(int dtype, const void* x, const void* w, void* y, float* stat
  * autograd of nn.Conv2d w.r.t. input; the residual add is the gradient fan-in of `out += residual` (nets/resnet.py:101). */
 int frhip_conv_dgrad(int dtype, const void* dy, const void* wt, void* dx, const void* residual,
                      int n, int h, int wd, int c, int k, int r, int s, int stride, int pad, frhip_stream_t stream);
+/* frhip_conv_dgrad with the NEXT BatchNorm-backward reduction fused into its epilogue: dx is the upstream gradient of a
+ * BatchNorm (nets/resnet.py:91, :98) whose saved input is y_bn [n,h,w,c]; stats_partial[frhip_dgrad_stat_rows(...)][2][c]
+ * receives per-row-tile { sum d, sum d*(y_bn-mean)*invstd } with d = dx * (y_bn*mask_scale + mask_shift > 0) (mask_scale may
+ * be NULL: no ReLU between the BN and this gradient) -- what frhip_bn_bwd_reduce would compute in a second pass over dx
+ * and y_bn; feed it to frhip_bn_bwd_finalize. */
+int frhip_dgrad_stat_rows(int dtype, int n, int h, int wd, int c, int k, int r, int s, int stride, int pad);
+int frhip_conv_dgrad_bnred(int dtype, const void* dy, const void* wt, void* dx, const void* residual,
+                           const void* y_bn, const float* mean, const float* invstd, const float* mask_scale,
+                           const float* mask_shift, float* stats_partial, int n, int h, int wd, int c, int k,
+                           int r, int s, int stride, int pad, frhip_stream_t stream);
 /* dw[k,r,s,c] (fp32, caller-zeroed) += sum over output pixels dy * x.  autograd of nn.Conv2d w.r.t. weight.
  * splits <= 0: library picks the split-K factor.  workspace (may be NULL): caller-owned scratch used by THIS call only
  * (one per stream); when splits * sizeof(dw) fits, each K split stores a private slab with plain stores and one reduce

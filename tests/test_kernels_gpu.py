@@ -120,16 +120,48 @@ def test_halo_kernel_equals_generic_kernel():
         wt = ops.pack_wt(w.float(), torch.bfloat16)
         dy = rnd(43, (n, h, h, k)).bfloat16().cuda()
         outs = []
-        for halo in (1, 0):
+        for halo in (2, 3, 0):       # 4-wave tile (two workgroups per CU) / 8-wave tile with double-buffered halo / generic
             old = lib().frhip_set_conv_halo(halo)
             y, part = ops.conv_fwd(x, w, 1, 1)
             dx = ops.conv_dgrad(dy, wt, (n, h, h, c), 3, 3, 1, 1, residual=res)
             lib().frhip_set_conv_halo(old)
             outs.append((y.float().cpu(), part.sum(0).cpu(), dx.float().cpu()))
-        scale = outs[1][0].abs().max().item()
-        np.testing.assert_allclose(outs[0][0].numpy(), outs[1][0].numpy(), rtol=0, atol=scale * 2 ** -7)   # one bf16 ulp of the largest value
-        np.testing.assert_allclose(outs[0][1].numpy(), outs[1][1].numpy(), rtol=2e-3, atol=0.5)
-        np.testing.assert_allclose(outs[0][2].numpy(), outs[1][2].numpy(), rtol=0, atol=outs[1][2].abs().max().item() * 2 ** -7)
+        ref = outs[2]
+        scale = ref[0].abs().max().item()
+        for o in outs[:2]:
+            np.testing.assert_allclose(o[0].numpy(), ref[0].numpy(), rtol=0, atol=scale * 2 ** -7)   # one bf16 ulp of the largest value
+            np.testing.assert_allclose(o[1].numpy(), ref[1].numpy(), rtol=2e-3, atol=0.5)
+            np.testing.assert_allclose(o[2].numpy(), ref[2].numpy(), rtol=0, atol=ref[2].abs().max().item() * 2 ** -7)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", [(3, 14, 64, 128, 1, True), (2, 28, 128, 128, 1, False), (2, 16, 64, 64, 2, True),
+                                  (5, 7, 256, 256, 1, True), (1, 9, 64, 64, 1, False)])
+def test_dgrad_epilogue_bn_backward_reduction(dtype, case):
+    """conv_dgrad(bnred=...) = conv_dgrad followed by the stand-alone BN-backward reduction over (dx, y_bn)"""
+    ops = _ops()
+    from frhip._abi import lib
+    n, h, c, k, stride, mask = case
+    ho = (h + 2 - 3) // stride + 1
+    dy = rnd(60, (n, ho, ho, k)).to(dtype).cuda()
+    w = (rnd(61, (k, 3, 3, c)) * 0.05)
+    wt = ops.pack_wt(w.cuda(), dtype)
+    res = rnd(62, (n, h, h, c)).to(dtype).cuda()
+    y_bn = rnd(63, (n, h, h, c)).to(dtype).cuda()
+    rows = n * h * h
+    st = ops.bn_finalize(ops.colstats(y_bn.view(rows, c)), rows, (1 + 0.1 * rnd(64, (c,))).cuda(), (0.1 * rnd(65, (c,))).cuda(),
+                         None, None)
+    dx_ref = ops.conv_dgrad(dy, wt, (n, h, h, c), 3, 3, stride, 1, residual=res)
+    nb = lib().frhip_colreduce_blocks(rows, c, ops.dt_of(y_bn))
+    pref = torch.empty((nb, 2, c), dtype=torch.float32, device="cuda")
+    P = ops._p
+    ops.check(lib().frhip_bn_bwd_reduce(ops.dt_of(y_bn), P(dx_ref), P(y_bn), P(st.mean), P(st.invstd),
+                                        P(st.scale) if mask else None, P(st.shift) if mask else None, rows, c, P(pref), ops._s()),
+              "frhip_bn_bwd_reduce")
+    dx, part = ops.conv_dgrad(dy, wt, (n, h, h, c), 3, 3, stride, 1, residual=res, bnred=(y_bn, st, mask))
+    assert torch.equal(dx, dx_ref)
+    a, b = part.sum(0).cpu().numpy(), pref.sum(0).cpu().numpy()
+    np.testing.assert_allclose(a, b, rtol=2e-4, atol=2e-4 * max(1.0, np.abs(b).max()))
 
 
 def test_linear_shift_wgrad_equals_generic_wgrad():
@@ -137,7 +169,7 @@ def test_linear_shift_wgrad_equals_generic_wgrad():
     ops = _ops()
     from frhip._abi import lib
     for (n, h, c, k, r) in [(3, 56, 64, 64, 3), (5, 28, 128, 128, 3), (7, 14, 256, 256, 3), (11, 7, 512, 512, 3),
-                            (4, 9, 64, 128, 1)]:
+                            (4, 9, 64, 128, 1), (2, 10, 96, 192, 3), (2, 56, 64, 128, 3), (1, 5, 72, 40, 3)]:
         pad = (r - 1) // 2
         x = rnd(50, (n, h, h, c)).bfloat16().cuda()
         dy = rnd(51, (n, h, h, k)).bfloat16().cuda()

@@ -73,15 +73,17 @@ for (h, c, k, r, stride) in SHAPES:
             us = timeit(lambda: ops.conv_fwd(x, w, stride, pad))
             line += " t%d %6.1fus %5.0fTF e=%.0e |" % (tile, us, flops / us / 1e6, err)
         lib().frhip_set_nt_tile(0)
+        for hm in (1, 2):
+            lib().frhip_set_conv_halo(hm)
+            y, _ = ops.conv_fwd(x, w, stride, pad)
+            err = (y.float() - ref).abs().max().item()
+            us = timeit(lambda: ops.conv_fwd(x, w, stride, pad))
+            line += " halo%d %6.1fus %5.0fTF e=%.0e |" % (hm, us, flops / us / 1e6, err)
         lib().frhip_set_conv_halo(1)
-        y, _ = ops.conv_fwd(x, w, stride, pad)
-        err = (y.float() - ref).abs().max().item()
-        us = timeit(lambda: ops.conv_fwd(x, w, stride, pad))
-        line += " halo %6.1fus %5.0fTF e=%.0e |" % (us, flops / us / 1e6, err)
     elif what == "wgrad":
         dy = torch.randn(B, ho, ho, k, device="cuda").bfloat16()
         dw = torch.zeros(k, r, r, c, device="cuda")
-        for mode in (2, 4):      # 2 = automatic kernel choice, 4 = nine-tap kernel forced where it applies
+        for mode in (0, 2):      # 0 = per-tap gather kernel, 2 = nine-tap kernel where it applies
             lib().frhip_set_tn_linear(mode)
             us = timeit(lambda: ops.conv_wgrad(dy, x, dw, r, r, stride, pad, 0))
             line += " wgrad[m%d] %6.1fus %5.0fTF |" % (mode, us, flops / us / 1e6)
