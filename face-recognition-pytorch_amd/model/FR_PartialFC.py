@@ -87,8 +87,11 @@ class Model(nn.Module):
         self.loss.train()
         loss = self.loss(feat, id_, self.opt)
         loss.backward()
-        torch.nn.utils.clip_grad_norm_(self.encoder.parameters(), 5)
-        self.opt.step()
+        if hasattr(self.opt, "last_grad_norm"):          # frhip.optim.SGD: the clip rides inside the fused update
+            self.opt.step(clip=(self.encoder.parameters(), 5))
+        else:
+            torch.nn.utils.clip_grad_norm_(self.encoder.parameters(), 5)
+            self.opt.step()
         return loss.detach()
 
     def training_step(self, batch):
@@ -180,7 +183,8 @@ class Model(nn.Module):
         if c.optimizer == "AdamW":
             opt = torch.optim.AdamW(groups, lr=self.lr, weight_decay=c.wd, eps=c.eps, betas=c.betas)
         elif c.optimizer == "SGD":
-            opt = torch.optim.SGD(groups, lr=self.lr, momentum=c.mom, weight_decay=c.wd)
+            # torch.optim.SGD subclass whose step() runs as three libfrhip kernels (same state / param_groups)
+            opt = importlib.import_module("frhip.optim").SGD(groups, lr=self.lr, momentum=c.mom, weight_decay=c.wd)
         sch = None
         name = getattr(c, "lr_scheduler", None)
         if name == "CosineAnnealingWarmupRestarts":

@@ -198,6 +198,22 @@ int frhip_gelu_bwd(int dtype, const void* da, const void* h, void* dh, size_t n,
 int frhip_pair_score(const float* e1, const float* e2, const int64_t* labels, int n, int d, double* scores,
                      int* hist_idx, int* hist_genuine, int* hist_imposter, frhip_stream_t stream);
 
+/* ---- optimizer: torch.optim.SGD(momentum, weight_decay).step() + torch.nn.utils.clip_grad_norm_ of the training step
+ * (model/FR_PartialFC.py:153-160, :181-190) as multi-tensor kernels.  A chunk is a run of at most
+ * FRHIP_SGD_CHUNK consecutive fp32 elements of one parameter (p), its gradient (g) and its momentum buffer (m, may be
+ * NULL when momentum == 0); the chunk table lives in device memory, the (<= 8) parameter groups are passed by value.
+ * d = g*coef + weight_decay*p;  m = momentum*m + d;  p -= lr*m   with coef = *clip_coef for groups with clip != 0. */
+#define FRHIP_SGD_CHUNK 65536
+#define FRHIP_SGD_MAX_GROUPS 8
+typedef struct { float lr, weight_decay, momentum, clip; } frhip_sgd_group;
+typedef struct { float* p; const float* g; float* m; uint32_t n; uint32_t group; } frhip_sgd_chunk;
+/* coef_out[0] = min(1, max_norm / (||g|| + 1e-6)) over the gradients of every group with clip != 0, coef_out[1] = ||g||;
+ * partial: nchunks floats of scratch */
+int frhip_sgd_clip_coef(const frhip_sgd_chunk* chunks, int nchunks, const frhip_sgd_group* groups_host, int ngroups,
+                        float max_norm, float* partial, float* coef_out, frhip_stream_t stream);
+int frhip_sgd_multi(const frhip_sgd_chunk* chunks, int nchunks, const frhip_sgd_group* groups_host, int ngroups,
+                    const float* clip_coef, frhip_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,89 @@
+"""frhip.optim.SGD: torch.optim.SGD semantics + clip_grad_norm_ as multi-tensor HIP kernels.
+Reference call sites: /root/reference/model/FR_PartialFC.py:153-160 (optimizer), :181-190 (clip + step)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [p for p in (ROOT, os.path.join(ROOT, "face-recognition-pytorch_amd")) if p not in sys.path]
+
+
+def _make(device, seed):
+    g = torch.Generator().manual_seed(seed)
+    shapes = [(64, 3, 3, 3), (64,), (128, 64, 3, 3), (7,), (513, 129), (1,), (300000,)]
+    ps = []
+    for i, s in enumerate(shapes):
+        t = torch.randn(s, generator=g)
+        if len(s) == 4 and i % 2 == 0:
+            t = t.contiguous(memory_format=torch.channels_last)
+        ps.append(torch.nn.Parameter(t.to(device)))
+    head = torch.nn.Parameter(torch.randn((1000, 512), generator=g).to(device))
+    return ps, head
+
+
+def _grads(ps, head, seed, scale):
+    g = torch.Generator().manual_seed(seed)
+    for p in ps + [head]:
+        gr = (torch.randn(p.shape, generator=g) * scale).to(p.device)
+        if p.dim() == 4 and not p.data.is_contiguous():
+            gr = gr.contiguous(memory_format=torch.channels_last)
+        p.grad = gr
+
+
+def _run(opt_cls, device, clip, steps=3, fused_clip=False):
+    ps, head = _make(device, 1)
+    opt = opt_cls([{"params": ps}, {"params": [head], "weight_decay": 0.0}], lr=0.1, momentum=0.9, weight_decay=5e-4)
+    norms = []
+    for k in range(steps):
+        _grads(ps, head, 10 + k, 3.0 if k == 0 else 0.01)      # step 0 clips, later steps do not
+        if k == 2:
+            opt.param_groups[0]["lr"] = 0.03                    # schedulers edit lr in place
+        if fused_clip:
+            opt.step(clip=(ps, clip))
+            norms.append(float(opt.last_grad_norm()))
+        else:
+            norms.append(float(torch.nn.utils.clip_grad_norm_(ps, clip)))
+            opt.step()
+    return [p.detach().cpu() for p in ps + [head]], [opt.state[p]["momentum_buffer"].cpu() for p in ps + [head]], norms
+
+
+def test_sgd_falls_back_to_torch_on_cpu_tensors():
+    from frhip.optim import SGD
+    a = _run(torch.optim.SGD, "cpu", 5.0)
+    b = _run(SGD, "cpu", 5.0, fused_clip=True)
+    for x, y in zip(a[0] + a[1], b[0] + b[1]):
+        assert torch.equal(x, y)
+
+
+@pytest.mark.gpu
+def test_sgd_matches_torch_sgd_and_clip_grad_norm():
+    from frhip.optim import SGD
+    ref = _run(torch.optim.SGD, "cuda", 5.0)
+    got = _run(SGD, "cuda", 5.0, fused_clip=True)
+    np.testing.assert_allclose(got[2], ref[2], rtol=1e-5)
+    for x, y in zip(got[0] + got[1], ref[0] + ref[1]):
+        assert x.stride() == y.stride()
+        np.testing.assert_allclose(x.numpy(), y.numpy(), rtol=2e-6, atol=2e-6)
+
+
+@pytest.mark.gpu
+def test_sgd_honours_swapped_parameter_and_momentum_buffer():
+    """PartialFC swaps the sampled centre rows and their momentum into the last group every step
+    (/root/reference/nets/PartialFC.py:120-143)"""
+    from frhip.optim import SGD
+    outs = []
+    for cls in (torch.optim.SGD, SGD):
+        w = torch.nn.Parameter(torch.ones(8, 4, device="cuda"))
+        opt = cls([{"params": [w]}], lr=0.5, momentum=0.9, weight_decay=0.1)
+        sub = torch.nn.Parameter(torch.full((3, 4), 2.0, device="cuda"))
+        mom = torch.full((3, 4), 0.25, device="cuda")
+        opt.state.pop(opt.param_groups[-1]["params"][0], None)
+        opt.param_groups[-1]["params"][0] = sub
+        opt.state[sub]["momentum_buffer"] = mom
+        sub.grad = torch.full((3, 4), 0.5, device="cuda")
+        opt.step()
+        outs.append((sub.detach().cpu(), mom.cpu()))
+    assert torch.allclose(outs[0][0], outs[1][0]) and torch.allclose(outs[0][1], outs[1][1])

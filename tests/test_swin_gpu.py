@@ -107,7 +107,7 @@ def test_swin18_fp32_eval_and_train_match_reference_fixture(golden):
     # test_swin_block_fp32_matches_reference_fixture and test_window_attention_kernel
     for k, p in net.named_parameters():
         want = g["gsum." + k]
-        if k.endswith(NOISE) or k == "fc.bias":
+        if k.endswith(NOISE) or k in ("fc.bias", "bn2.bias"):     # tail: a constant shift in front of train-mode bn3 -> zero gradient
             continue
         got = recipe.summary(p.grad.cpu())
         np.testing.assert_allclose(got[1], want[1], rtol=6e-2, atol=1e-4, err_msg=k)      # atol: analytically-zero grads
