@@ -23,15 +23,16 @@ class _Group(ctypes.Structure):
 
 
 def _dense_same_layout(*ts):
-    st = ts[0].stride()
-    if any(t.stride() != st or t.shape != ts[0].shape for t in ts[1:]):
-        return False
-    t = ts[0]
-    # dense in SOME dimension order (contiguous or channels_last ...): sorted strides multiply up to numel
+    """same shape, same strides on every dimension that has more than one element, and dense in SOME dimension
+    order (contiguous, channels_last, ...): the kernels then walk the storages element by element"""
+    shape = ts[0].shape
+    dims = [d for d in range(len(shape)) if shape[d] > 1]
+    st = [ts[0].stride(d) for d in dims]
+    for t in ts[1:]:
+        if t.shape != shape or [t.stride(d) for d in dims] != st:
+            return False
     expect = 1
-    for size, stride in sorted(zip(t.shape, st), key=lambda x: x[1]):
-        if size == 1:
-            continue
+    for size, stride in sorted(((shape[d], ts[0].stride(d)) for d in dims), key=lambda x: x[1]):
         if stride != expect:
             return False
         expect *= size
@@ -42,26 +43,30 @@ class SGD(torch.optim.SGD):
     def __init__(self, params, lr=1e-3, momentum=0.0, dampening=0.0, weight_decay=0.0, nesterov=False, **kw):
         super().__init__(params, lr=lr, momentum=momentum, dampening=dampening, weight_decay=weight_decay,
                          nesterov=nesterov, **kw)
-        self._table_key, self._table, self._keep = None, None, None
-        self._partial = self._coef = self._norm = None
+        self._tables = {}            # pointer signature -> (device chunk table, chunk count, per-group clip flags, scratch)
+        self._keep = None
+        self._coef = self._norm = None
 
     # ------------------------------------------------------------------------------------------------
-    def _fusable(self):
+    def _options_ok(self):
         if len(self.param_groups) > 8:
             return False
         for g in self.param_groups:
             if g.get("nesterov") or g.get("dampening", 0) != 0 or g.get("maximize") or g.get("differentiable"):
                 return False
-            for p in g["params"]:
-                if p.grad is None:
-                    continue
-                if not (p.is_cuda and p.dtype == torch.float32 and p.grad.dtype == torch.float32 and not p.grad.is_sparse):
-                    return False
-                if not _dense_same_layout(p.data, p.grad):
-                    return False
         return True
 
-    def _build_table(self, entries, device):
+    @staticmethod
+    def _tensors_ok(entries):
+        for p, g, m, _ in entries:
+            if not (p.is_cuda and p.dtype == torch.float32 and g.dtype == torch.float32 and not g.is_sparse):
+                return False
+            if not _dense_same_layout(p.data, g) or (m is not None and not _dense_same_layout(p.data, m)):
+                return False
+        return True
+
+    @staticmethod
+    def _build_table(entries, device):
         """entries: [(p, g, m or None, group index)] -> device chunk table"""
         parts = []
         for p, g, m, gi in entries:
@@ -78,6 +83,10 @@ class SGD(torch.optim.SGD):
         buf = torch.from_numpy(host.view(np.uint8).copy()).to(device)
         return buf, len(host)
 
+    def _fallback(self, clip):
+        self._norm = torch.nn.utils.clip_grad_norm_(list(clip[0]), float(clip[1])) if clip is not None else None
+        super().step()
+
     @torch.no_grad()
     def step(self, closure=None, clip=None):
         """clip=(iterable of parameters, max_norm): scale the gradients of those parameters by
@@ -86,56 +95,65 @@ class SGD(torch.optim.SGD):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
-        clip_ids, max_norm = (None, None)
         if clip is not None:
-            clip_ids, max_norm = {id(p) for p in clip[0]}, float(clip[1])
-        group_clip = []
-        ok = self._fusable()
-        for g in self.param_groups:
-            ps = [p for p in g["params"] if p.grad is not None]
-            inside = [clip_ids is not None and id(p) in clip_ids for p in ps]
-            if any(inside) and not all(inside):
-                ok = False                                # a clip set that cuts through a group: not expressible per group
-            group_clip.append(bool(inside) and all(inside))
-        if not ok:
-            self._norm = torch.nn.utils.clip_grad_norm_(list(clip[0]), max_norm) if clip is not None else None
-            super().step()
+            clip = (list(clip[0]), float(clip[1]))
+        if not self._options_ok():
+            self._fallback(clip)
             return loss
-
-        entries, device = [], None
+        # (parameter, gradient, momentum buffer, group) of everything that has a gradient.  The pointer signature
+        # of this list keys the cached chunk table, so a steady-state step costs one pass over the parameters.
+        entries = []
         for gi, g in enumerate(self.param_groups):
+            mom = g["momentum"] != 0
             for p in g["params"]:
-                if p.grad is None:
+                gr = p.grad
+                if gr is None:
                     continue
-                device = p.device
-                m = None
-                if g["momentum"] != 0:
-                    st = self.state[p]
-                    m = st.get("momentum_buffer")
-                    if m is None or not _dense_same_layout(p.data, m):
-                        m = st["momentum_buffer"] = torch.zeros_like(p.data, memory_format=torch.preserve_format)
-                entries.append((p.data, p.grad, m, gi))
+                entries.append((p, gr, self.state[p].get("momentum_buffer") if mom else None, gi))
         if not entries:
             return loss
-        key = tuple((p.data_ptr(), g.data_ptr(), 0 if m is None else m.data_ptr(), p.numel(), gi) for p, g, m, gi in entries)
-        if key != self._table_key:
-            self._table, self._n = self._build_table(entries, device)
-            self._table_key = key
-            self._partial = torch.empty(self._n, dtype=torch.float32, device=device)
-            self._coef = torch.ones(2, dtype=torch.float32, device=device)
+        key = tuple((p.data_ptr(), gr.data_ptr(), 0 if m is None else m.data_ptr(), gi) for p, gr, m, gi in entries)
+        clip_sig = None if clip is None else (id(clip[0][0]) if clip[0] else 0, len(clip[0]))
+        hit = self._tables.get((key, clip_sig))
+        if hit is None:
+            # slow path: create missing momentum buffers, validate layouts, build the table
+            fixed = []
+            for p, gr, m, gi in entries:
+                if self.param_groups[gi]["momentum"] != 0 and (m is None or not _dense_same_layout(p.data, m)):
+                    m = self.state[p]["momentum_buffer"] = torch.zeros_like(p.data, memory_format=torch.preserve_format)
+                fixed.append((p, gr, m, gi))
+            entries = fixed
+            clip_ids = set() if clip is None else {id(p) for p in clip[0]}
+            group_clip, ok = [], self._tensors_ok(entries)
+            for gi in range(len(self.param_groups)):
+                inside = [id(p) in clip_ids for p, _, _, g2 in entries if g2 == gi]
+                if any(inside) and not all(inside):
+                    ok = False                            # a clip set that cuts through a group: not expressible per group
+                group_clip.append(bool(inside) and all(inside))
+            if not ok:
+                self._fallback(clip)
+                return loss
+            device = entries[0][0].device
+            table, n = self._build_table(entries, device)
+            hit = (table, n, group_clip, torch.empty(n, dtype=torch.float32, device=device))
+            if len(self._tables) >= 8:
+                self._tables.clear()
+            key = tuple((p.data_ptr(), gr.data_ptr(), 0 if m is None else m.data_ptr(), gi) for p, gr, m, gi in entries)
+            self._tables[(key, clip_sig)] = hit
+            if self._coef is None or self._coef.device != device:
+                self._coef = torch.ones(2, dtype=torch.float32, device=device)
+        table, n, group_clip, partial = hit
         self._keep = entries                               # the table holds raw pointers: keep their owners alive
         groups = (_Group * len(self.param_groups))()
         for gi, g in enumerate(self.param_groups):
             groups[gi] = _Group(float(g["lr"]), float(g["weight_decay"]), float(g["momentum"]), 1.0 if group_clip[gi] else 0.0)
-        tbl = ctypes.c_void_p(self._table.data_ptr())
-        coef = None
+        tbl, gptr, coef = ctypes.c_void_p(table.data_ptr()), ctypes.cast(groups, ctypes.c_void_p), None
         if any(group_clip):
-            check(lib().frhip_sgd_clip_coef(tbl, self._n, ctypes.cast(groups, ctypes.c_void_p), len(groups), max_norm,
-                                            ops._p(self._partial), ops._p(self._coef), ops._s()), "frhip_sgd_clip_coef")
+            check(lib().frhip_sgd_clip_coef(tbl, n, gptr, len(groups), clip[1], ops._p(partial), ops._p(self._coef), ops._s()),
+                  "frhip_sgd_clip_coef")
             coef = ops._p(self._coef)
             self._norm = self._coef[1]
-        check(lib().frhip_sgd_multi(tbl, self._n, ctypes.cast(groups, ctypes.c_void_p), len(groups), coef, ops._s()),
-              "frhip_sgd_multi")
+        check(lib().frhip_sgd_multi(tbl, n, gptr, len(groups), coef, ops._s()), "frhip_sgd_multi")
         return loss
 
     def last_grad_norm(self):

