@@ -45,7 +45,8 @@ class SGD(torch.optim.SGD):
                          nesterov=nesterov, **kw)
         self._tables = {}            # pointer signature -> (device chunk table, chunk count, per-group clip flags, scratch)
         self._keep = None
-        self._coef = self._norm = None
+        self._coef = self._norm = self._pin = None
+        self._pin_next = 0
 
     # ------------------------------------------------------------------------------------------------
     def _options_ok(self):
@@ -65,8 +66,7 @@ class SGD(torch.optim.SGD):
                 return False
         return True
 
-    @staticmethod
-    def _build_table(entries, device):
+    def _build_table(self, entries, device):
         """entries: [(p, g, m or None, group index)] -> device chunk table"""
         parts = []
         for p, g, m, gi in entries:
@@ -80,7 +80,18 @@ class SGD(torch.optim.SGD):
             t["group"] = gi
             parts.append(t)
         host = np.concatenate(parts)
-        buf = torch.from_numpy(host.view(np.uint8).copy()).to(device)
+        raw = torch.from_numpy(host.view(np.uint8).copy())
+        # staged through a pre-allocated pinned slot with an async copy, so a table built while a HIP graph is being
+        # captured (the gradient arena lives at other addresses there) becomes a memcpy node instead of an illegal
+        # synchronous copy; the slot stays untouched for as long as the cache entry lives
+        if self._pin is None or self._pin.shape[1] < raw.numel():
+            self._pin = torch.empty((8, raw.numel()), dtype=torch.uint8, pin_memory=True)
+            self._pin_next = 0
+        slot = self._pin[self._pin_next % 8, :raw.numel()]
+        self._pin_next += 1
+        slot.copy_(raw)
+        buf = torch.empty(raw.numel(), dtype=torch.uint8, device=device)
+        buf.copy_(slot, non_blocking=True)
         return buf, len(host)
 
     def _fallback(self, clip):
