@@ -388,6 +388,9 @@ __global__ __launch_bounds__(TN_THREADS, 2) void tn_lin_kernel(TnGeom g, const v
 #ifndef T9_DEPTH
 #define T9_DEPTH 4
 #endif
+#ifndef T9_PIN
+#define T9_PIN 0
+#endif
 constexpr int T9_MAXW = 56;
 constexpr int T9_QROWS = 192;                               // 24 pieces of 8 rows >= 64 + 2*56 + 2
 
@@ -559,6 +562,20 @@ void tn_taps9_kernel(TnGeom g, const void* __restrict__ p_ptr, const void* __res
             if (n + DEPTH - 1 < 18) loadq(n + DEPTH - 1, qr[(n + DEPTH - 1) % DEPTH]);
             if (n == 3) loadp(1);
             mma(n, qr[n % DEPTH]);
+#if T9_PIN == 1
+            // issue-slot packing: the address selects and the transposed reads of the look-ahead group go BETWEEN this
+            // group's MFMAs (an MFMA keeps the matrix pipe busy for 16 cycles; what is issued in its shadow is free)
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+#elif T9_PIN == 2
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+#endif
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {

@@ -41,6 +41,45 @@ __global__ void pack_wt_kernel(const float* __restrict__ w, T* __restrict__ wt, 
     }
 }
 
+// Every conv weight of a backbone in ONE launch: w[K][RS][C] fp32 -> wc[K][RS][C] T (forward operand) and
+// wt[C][RS][K] T (data-gradient operand).  Block -> (tensor, rs, 32x32 tile) by binary search over the tensors'
+// cumulative tile counts (the table has one entry per tensor).
+template <typename T>
+__global__ void prep_weights_kernel(const frhip_wprep* __restrict__ tab, int ntensors) {
+    __shared__ float tile[32][33];
+    int lo = 0, hi = ntensors - 1;
+    while (lo < hi) {                                   // last tensor whose tile_begin <= blockIdx.x
+        const int mid = (lo + hi + 1) >> 1;
+        if (tab[mid].tile_begin <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const frhip_wprep e = tab[lo];
+    const int K = e.k, RS = e.rs, C = e.c;
+    const int ct = (C + 31) >> 5, kt = (K + 31) >> 5;
+    int t = (int)blockIdx.x - e.tile_begin;
+    const int cti = t % ct; t /= ct;
+    const int kti = t % kt; const int rs = t / kt;
+    const int c0 = cti * 32, k0 = kti * 32;
+    const float* __restrict__ w = e.w;
+    T* __restrict__ wc = reinterpret_cast<T*>(e.wc);
+    T* __restrict__ wt = reinterpret_cast<T*>(e.wt);
+    for (int j = threadIdx.y; j < 32; j += blockDim.y) {
+        const int k = k0 + j, c = c0 + threadIdx.x;
+        float v = 0.f;
+        if (k < K && c < C) {
+            const size_t idx = ((size_t)k * RS + rs) * C + c;
+            v = w[idx];
+            if (wc) wc[idx] = from_f32<T>(v);
+        }
+        tile[j][threadIdx.x] = v;
+    }
+    __syncthreads();
+    if (wt)
+        for (int j = threadIdx.y; j < 32; j += blockDim.y) {
+            const int c = c0 + j, k = k0 + threadIdx.x;
+            if (c < C && k < K) wt[((size_t)c * RS + rs) * K + k] = from_f32<T>(tile[threadIdx.x][j]);
+        }
+}
+
 // generic 2-D transpose in[rows][cols] -> out[cols][rows]
 template <typename TI, typename TO>
 __global__ void transpose2d_kernel(const TI* __restrict__ in, TO* __restrict__ out, int rows, int cols, int ld_out) {
@@ -133,6 +172,15 @@ extern "C" int frhip_pack_wt(int dtype, const float* w, void* wt, int k, int rs,
     else if (dtype == FRHIP_DT_F32) hipLaunchKernelGGL(pack_wt_kernel<float>, grid, block, 0, stream, w, (float*)wt, k, rs, c);
     else { set_error("frhip_pack_wt: bad dtype %d", dtype); return FRHIP_EINVAL; }
     return check_launch("frhip_pack_wt");
+}
+
+extern "C" int frhip_prep_conv_weights(int dtype, const frhip_wprep* table, int ntensors, int ntiles, hipStream_t stream) {
+    if (!table || ntensors < 1 || ntiles < 1) { set_error("frhip_prep_conv_weights: empty table"); return FRHIP_EINVAL; }
+    dim3 block(32, 8);
+    if (dtype == FRHIP_DT_BF16) hipLaunchKernelGGL(prep_weights_kernel<bf16_t>, dim3(ntiles), block, 0, stream, table, ntensors);
+    else if (dtype == FRHIP_DT_F32) hipLaunchKernelGGL(prep_weights_kernel<float>, dim3(ntiles), block, 0, stream, table, ntensors);
+    else { set_error("frhip_prep_conv_weights: bad dtype %d", dtype); return FRHIP_EINVAL; }
+    return check_launch("frhip_prep_conv_weights");
 }
 
 extern "C" int frhip_transpose2d(int dtype_in, int dtype_out, const void* in, void* out, int rows, int cols, int ld_out, hipStream_t stream) {

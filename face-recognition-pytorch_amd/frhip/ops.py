@@ -258,6 +258,43 @@ def pack_wt(w_f32, dtype, out=None):
     return out
 
 
+_WPREP = {}
+
+
+def prep_conv_weights(weights, dtype):
+    """weights: list of fp32 [K,R,S,C] (physical) conv weights -> ([K,R,S,C] dtype, [C,R,S,K] dtype) per tensor, all
+    produced by ONE kernel launch into one arena that is reused from step to step (the pointer table is cached)."""
+    import numpy as np
+    key = (tuple(w.data_ptr() for w in weights), dtype)
+    hit = _WPREP.get(key)
+    if hit is None:
+        dev = weights[0].device
+        total = sum(w.numel() for w in weights)
+        arena = torch.empty(2 * total, dtype=dtype, device=dev)
+        es = arena.element_size()
+        dt = np.dtype([("w", "<u8"), ("wc", "<u8"), ("wt", "<u8"), ("k", "<i4"), ("rs", "<i4"), ("c", "<i4"), ("tile_begin", "<i4")])
+        tab = np.empty(len(weights), dtype=dt)
+        outs, off, tiles = [], 0, 0
+        for i, w in enumerate(weights):
+            assert w.is_cuda and w.dtype == torch.float32 and w.is_contiguous()
+            k, r, s, c = w.shape
+            n = w.numel()
+            wc = arena[off:off + n].view(k, r, s, c)
+            wt = arena[off + n:off + 2 * n].view(c, r, s, k)
+            tab[i] = (w.data_ptr(), wc.data_ptr(), wt.data_ptr(), k, r * s, c, tiles)
+            tiles += ((k + 31) // 32) * ((c + 31) // 32) * r * s
+            off += 2 * n
+            outs.append((wc, wt))
+        assert off * es == arena.numel() * es
+        table = torch.from_numpy(tab.view(np.uint8).copy()).to(dev)
+        if len(_WPREP) >= 8:
+            _WPREP.clear()
+        hit = _WPREP[key] = (table, len(weights), tiles, outs, arena, list(weights))
+    table, n, tiles, outs, _, _ = hit
+    check(lib().frhip_prep_conv_weights(_DT[dtype], _p(table), n, tiles, _s()), "frhip_prep_conv_weights")
+    return outs
+
+
 def transpose2d(x, out_dtype=None, out=None, pad_to=1):
     """x [rows][cols] -> [cols][ld] with ld = rows rounded up to pad_to (pad columns are zero)"""
     rows, cols = x.shape

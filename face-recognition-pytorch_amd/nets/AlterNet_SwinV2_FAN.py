@@ -22,7 +22,8 @@ from frhip import ops
 
 from . import SwinV2 as _S
 from ._backbone import (BackwardCtx, BasicBlock, Saved, _BN, _Conv, _Linear, basic_block_backward,  # noqa: F401
-                        basic_block_forward, bn_forward_state, compute_dtype, encoder_call, stem_backward,
+                        basic_block_forward, bn_forward_state, compute_dtype, encoder_call, prepare_conv_weights,
+                        stem_backward,
                         stem_forward, tail_backward, tail_forward)
 
 conv1x1 = lambda cin, cout, stride=1: _Conv(cin, cout, 1, stride)  # noqa: E731
@@ -203,9 +204,13 @@ class AlterNet(nn.Module):
         sv = Saved() if save else None
         cur = stem_forward(self, x, training, sv)
         saved = []
-        for mod in self._layers():
+        layers = list(self._layers())
+        convs = [c for b in layers if isinstance(b, BasicBlock)
+                 for c in ((b.conv1, b.conv2) + ((b.downsample[0],) if b.downsample is not None else ()))]
+        wprep = prepare_conv_weights(convs, dt) if convs else None
+        for mod in layers:
             if isinstance(mod, BasicBlock):
-                cur, s = basic_block_forward(mod, cur, dt, training, save)
+                cur, s = basic_block_forward(mod, cur, dt, training, save, wprep)
             else:
                 cur, s = attn_block_forward(mod, cur, dt, training, save)
             saved.append(s)

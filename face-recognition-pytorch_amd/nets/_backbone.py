@@ -156,11 +156,17 @@ class BackwardCtx:
 
 
 # ------------------------------------------------------------------------------------------------- forward pieces
+_NBT_PENDING = None      # inside encoder_call: the num_batches_tracked counters to bump, in one multi-tensor add at the end
+
+
 def bn_forward_state(bn, part, count, training):
     if training:
         st = ops.bn_finalize(part, count, bn.weight.data, bn.bias.data, bn.running_mean, bn.running_var,
                              bn.momentum, bn.eps)
-        bn.num_batches_tracked += 1
+        if _NBT_PENDING is not None:
+            _NBT_PENDING.append(bn.num_batches_tracked)
+        else:
+            bn.num_batches_tracked += 1
         return st
     return ops.bn_eval_affine(bn.weight.data, bn.bias.data, bn.running_mean, bn.running_var, bn.eps)
 
@@ -191,18 +197,32 @@ def stem_backward(net, sv, dout, bc):
     ops.unpack_stem_grad(dwp0, phys_grad(bc.G(net.conv1.weight)).view(64, 27))
 
 
-def basic_block_forward(blk, xin, dt, training, save):
-    w1 = ops.cast_from_f32(blk.conv1.physical(), dt)
+def prepare_conv_weights(convs, dt):
+    """{conv module: (bf16/fp32 [K,R,S,C], transposed [C,R,S,K])} for a list of _Conv modules, one kernel launch"""
+    convs = list(convs)
+    outs = ops.prep_conv_weights([c.physical() for c in convs], dt)
+    return dict(zip(convs, outs))
+
+
+def _operands(conv, dt, wprep):
+    """(forward operand, data-gradient operand or None) of a conv: from the batched preparation when there is one"""
+    if wprep is not None and conv in wprep:
+        return wprep[conv]
+    return ops.cast_from_f32(conv.physical(), dt), None
+
+
+def basic_block_forward(blk, xin, dt, training, save, wprep=None):
+    w1, w1t = _operands(blk.conv1, dt, wprep)
     y1, p1 = ops.conv_fwd(xin, w1, 1, 1, want_stats=training)
     st1 = bn_forward_state(blk.bn1, p1, y1.numel() // y1.shape[3], training)
     a1 = ops.bn_apply(y1, st1, relu=True)
-    w2 = ops.cast_from_f32(blk.conv2.physical(), dt)
+    w2, w2t = _operands(blk.conv2, dt, wprep)
     y2, p2 = ops.conv_fwd(a1, w2, blk.stride, 1, want_stats=training)
     st2 = bn_forward_state(blk.bn2, p2, y2.numel() // y2.shape[3], training)
-    yd = std = None
+    yd = std = wdt = None
     if blk.downsample is not None:
         dconv, dbn = blk.downsample[0], blk.downsample[1]
-        wd = ops.cast_from_f32(dconv.physical(), dt)
+        wd, wdt = _operands(dconv, dt, wprep)
         yd, pd = ops.conv_fwd(xin, wd, dconv.stride, 0, want_stats=training)
         std = bn_forward_state(dbn, pd, yd.numel() // yd.shape[3], training)
         out = ops.bn_apply(y2, st2, res=yd, res_st=std)
@@ -212,6 +232,7 @@ def basic_block_forward(blk, xin, dt, training, save):
     if save:
         s = Saved()
         s.x, s.y1, s.st1, s.a1, s.y2, s.st2, s.yd, s.std = xin, y1, st1, a1, y2, st2, yd, std
+        s.w1t, s.w2t, s.wdt = w1t, w2t, wdt
     return out, s
 
 
@@ -225,16 +246,16 @@ def basic_block_backward(blk, s, dout, dt, bc, part2=None, next_bn=None):
     if blk.downsample is not None:
         dconv, dbn = blk.downsample[0], blk.downsample[1]
         dyd = ops.bn_backward(dout, s.yd, s.std, dbn.weight.data, G(dbn.weight), G(dbn.bias))
-        wdt = ops.pack_wt(dconv.physical(), dt)
+        wdt = s.wdt if getattr(s, "wdt", None) is not None else ops.pack_wt(dconv.physical(), dt)
         shortcut = ops.conv_dgrad(dyd, wdt, s.x.shape, 1, 1, dconv.stride, 0)
         bc.wgrad(dyd, s.x, phys_grad(G(dconv.weight)), 1, 1, dconv.stride, 0)
-    w2t = ops.pack_wt(blk.conv2.physical(), dt)
+    w2t = s.w2t if getattr(s, "w2t", None) is not None else ops.pack_wt(blk.conv2.physical(), dt)
     # the BN1 (+ReLU) backward reduction over (da1, y1) rides in the epilogue of conv2's data-gradient
     da1, part1 = ops.conv_dgrad(dy2, w2t, s.a1.shape, 3, 3, blk.stride, 1, bnred=(s.y1, s.st1, True))
     bc.wgrad(dy2, s.a1, phys_grad(G(blk.conv2.weight)), 3, 3, blk.stride, 1)
     dy1 = ops.bn_backward(da1, s.y1, s.st1, blk.bn1.weight.data, G(blk.bn1.weight), G(blk.bn1.bias), relu_mask=True,
                           part=part1)
-    w1t = ops.pack_wt(blk.conv1.physical(), dt)
+    w1t = s.w1t if getattr(s, "w1t", None) is not None else ops.pack_wt(blk.conv1.physical(), dt)
     if next_bn is not None:
         dx = ops.conv_dgrad(dy1, w1t, s.x.shape, 3, 3, 1, 1, residual=shortcut, bnred=(next_bn[0], next_bn[1], False))
     else:
@@ -307,7 +328,15 @@ def encoder_call(net, x):
         raise RuntimeError("frhip backbone: input must live on the MI355X; there is no CPU path "
                            "(the CPU restatement lives in oracle/ and is test-only)")
     x = x.contiguous().float()
-    if net.training and torch.is_grad_enabled():
-        return EncoderFn.apply(net, x, *[p for p in net.parameters()])
-    out, _ = net._forward_impl(x, net.training, False)
+    global _NBT_PENDING
+    _NBT_PENDING = []
+    try:
+        if net.training and torch.is_grad_enabled():
+            out = EncoderFn.apply(net, x, *[p for p in net.parameters()])
+        else:
+            out, _ = net._forward_impl(x, net.training, False)
+        if _NBT_PENDING:
+            torch._foreach_add_(_NBT_PENDING, 1)        # ~60 one-element increments as one launch
+    finally:
+        _NBT_PENDING = None
     return out

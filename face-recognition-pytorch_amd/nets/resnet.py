@@ -18,7 +18,8 @@ There is no CPU / eager fallback: without libfrhip.so or without a GPU tensor, f
 import torch.nn as nn
 
 from ._backbone import (BackwardCtx, BasicBlock, Saved, _BN, _Conv, _Linear, basic_block_backward,
-                        basic_block_forward, compute_dtype, encoder_call, stem_backward, stem_forward,
+                        basic_block_forward, compute_dtype, encoder_call, prepare_conv_weights, stem_backward,
+                        stem_forward,
                         tail_backward, tail_forward)
 
 _BLOCKS = {18: (2, 2, 2, 2), 34: (3, 4, 6, 4), 50: (3, 4, 14, 4), 100: (3, 13, 30, 4), 200: (3, 43, 50, 4)}
@@ -69,8 +70,11 @@ class ResNet(nn.Module):
         sv = Saved() if save else None
         cur = stem_forward(self, x, training, sv)
         saved_blocks = []
-        for blk in self._blocks():
-            cur, s = basic_block_forward(blk, cur, self.dtype, training, save)
+        blocks = list(self._blocks())
+        convs = [c for b in blocks for c in ((b.conv1, b.conv2) + ((b.downsample[0],) if b.downsample is not None else ()))]
+        wprep = prepare_conv_weights(convs, self.dtype)          # every conv operand of the step in one launch
+        for blk in blocks:
+            cur, s = basic_block_forward(blk, cur, self.dtype, training, save, wprep)
             saved_blocks.append(s)
         emb = tail_forward(self, cur, training, sv)
         if save:

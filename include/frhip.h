@@ -198,6 +198,13 @@ int frhip_gelu_bwd(int dtype, const void* da, const void* h, void* dh, size_t n,
 int frhip_pair_score(const float* e1, const float* e2, const int64_t* labels, int n, int d, double* scores,
                      int* hist_idx, int* hist_genuine, int* hist_imposter, frhip_stream_t stream);
 
+/* ---- per-step operand preparation of ALL conv weights in one launch (the reference casts them implicitly under autocast,
+ * nets/resnet.py:23-46 + model/FR_PartialFC.py:166-170).  Per tensor w[k][rs][c] fp32: wc[k][rs][c] (forward operand) and
+ * wt[c][rs][k] (data-gradient operand) in `dtype`; either destination may be NULL.  tile_begin = number of 32x32 tiles
+ * (ceil(k/32)*ceil(c/32)*rs per tensor) of the tensors before this one; ntiles = the total.  Table in device memory. */
+typedef struct { const float* w; void* wc; void* wt; int32_t k, rs, c, tile_begin; } frhip_wprep;
+int frhip_prep_conv_weights(int dtype, const frhip_wprep* table, int ntensors, int ntiles, frhip_stream_t stream);
+
 /* ---- optimizer: torch.optim.SGD(momentum, weight_decay).step() + torch.nn.utils.clip_grad_norm_ of the training step
  * (model/FR_PartialFC.py:153-160, :181-190) as multi-tensor kernels.  A chunk is a run of at most
  * FRHIP_SGD_CHUNK consecutive fp32 elements of one parameter (p), its gradient (g) and its momentum buffer (m, may be
