@@ -77,29 +77,40 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
     if (pl == 0 && t < 2 * C) out[(size_t)blockIdx.y * 2 * C + t] = red[0][tl] + red[1][tl] + red[2][tl] + red[3][tl];
 }
 
-// sum of partial[p][st][c] over p, by 4 lanes per channel (block = 64 channels x 4 lanes); result valid on lane 0
-__device__ __forceinline__ void sum_parts_4(const float* __restrict__ parts, int nparts, int C, int c, int pl,
-                                            float (*red)[2][64], float& s1, float& s2) {
+// sum of partial[p][st][c] over p, by PL = blockDim.x / 64 lanes per channel (block = 64 channels x PL lanes, PL <= 16);
+// result valid on lane 0
+constexpr int FIN_MAX_PL = 16;
+__device__ __forceinline__ void sum_parts(const float* __restrict__ parts, int nparts, int C, int c, int pl,
+                                          float (*red)[2][64], float& s1, float& s2) {
+    const int PL = blockDim.x >> 6;
     float a1 = 0.f, a2 = 0.f;
-    if (c < C)
-        for (int p = pl; p < nparts; p += 4) { a1 += parts[(size_t)p * 2 * C + c]; a2 += parts[(size_t)p * 2 * C + C + c]; }
+    if (c < C) {
+        int p = pl;
+        for (; p + 3 * PL < nparts; p += 4 * PL) {        // four independent row pairs in flight
+            const float* r0 = parts + (size_t)p * 2 * C, *r1 = r0 + (size_t)PL * 2 * C, *r2 = r1 + (size_t)PL * 2 * C,
+                        *r3 = r2 + (size_t)PL * 2 * C;
+            const float x0 = r0[c], y0 = r0[C + c], x1 = r1[c], y1 = r1[C + c], x2 = r2[c], y2 = r2[C + c], x3 = r3[c], y3 = r3[C + c];
+            a1 += (x0 + x1) + (x2 + x3); a2 += (y0 + y1) + (y2 + y3);
+        }
+        for (; p < nparts; p += PL) { a1 += parts[(size_t)p * 2 * C + c]; a2 += parts[(size_t)p * 2 * C + C + c]; }
+    }
     red[pl][0][threadIdx.x & 63] = a1; red[pl][1][threadIdx.x & 63] = a2;
     __syncthreads();
     const int cl = threadIdx.x & 63;
-    s1 = red[0][0][cl] + red[1][0][cl] + red[2][0][cl] + red[3][0][cl];
-    s2 = red[0][1][cl] + red[1][1][cl] + red[2][1][cl] + red[3][1][cl];
+    s1 = 0.f; s2 = 0.f;
+    for (int l = 0; l < PL; ++l) { s1 += red[l][0][cl]; s2 += red[l][1][cl]; }
 }
 
 // Finalise forward batch statistics.
-__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ parts, int nparts, int C, float count,
+__global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restrict__ parts, int nparts, int C, float count,
                                    const float* __restrict__ gamma, const float* __restrict__ beta,
                                    float* __restrict__ running_mean, float* __restrict__ running_var,
                                    float momentum, float eps, float* __restrict__ mean_out,
                                    float* __restrict__ invstd_out, float* __restrict__ scale, float* __restrict__ shift) {
-    __shared__ float red[4][2][64];
+    __shared__ float red[FIN_MAX_PL][2][64];
     const int c = blockIdx.x * 64 + (threadIdx.x & 63), pl = threadIdx.x >> 6;
     float s1, s2;
-    sum_parts_4(parts, nparts, C, c, pl, red, s1, s2);
+    sum_parts(parts, nparts, C, c, pl, red, s1, s2);
     if (pl != 0 || c >= C) return;
     const float mu = s1 / count;
     float var = s2 / count - mu * mu;
@@ -126,15 +137,15 @@ __global__ void bn_eval_kernel(int C, const float* __restrict__ gamma, const flo
 }
 
 // Finalise backward sums: dgamma, dbeta and the per-channel affine of  dy = ca*d_eff + cb*y + cc.
-__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ parts, int nparts, int C, float count,
+__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __restrict__ parts, int nparts, int C, float count,
                                        const float* __restrict__ gamma, const float* __restrict__ mean,
                                        const float* __restrict__ invstd, float* __restrict__ dgamma,
                                        float* __restrict__ dbeta, float* __restrict__ ca, float* __restrict__ cb,
                                        float* __restrict__ cc) {
-    __shared__ float red[4][2][64];
+    __shared__ float red[FIN_MAX_PL][2][64];
     const int c = blockIdx.x * 64 + (threadIdx.x & 63), pl = threadIdx.x >> 6;
     float s1, s2;
-    sum_parts_4(parts, nparts, C, c, pl, red, s1, s2);
+    sum_parts(parts, nparts, C, c, pl, red, s1, s2);
     if (pl != 0 || c >= C) return;
     dgamma[c] += s2; dbeta[c] += s1;                 // accumulate into (caller-zeroed) .grad
     const float gi = gamma[c] * invstd[c], m2 = s2 / count, m1 = s1 / count;
@@ -303,21 +314,27 @@ extern "C" int frhip_bn_bwd_reduce(int dtype, const void* dout, const void* y, c
     return check_launch("frhip_bn_bwd_reduce");
 }
 
+// Up to FOLD_LIMIT partial rows go straight into the finalize kernel (16 lanes per channel, 4 rows in flight per lane);
+// beyond that a first pass folds them to RED_GROUPS rows.
+constexpr int FOLD_LIMIT = 512;
 static const float* fold_partials(const float* partial, int& nparts, int c, float* scratch, hipStream_t stream) {
-    if (nparts <= RED_GROUPS) return partial;
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3((2 * c + 63) / 64, RED_GROUPS), dim3(256), 0, stream,
+    if (nparts <= FOLD_LIMIT) return partial;
+    // scratch holds 64 rows of [2][c]: fold to 64 rows (enough blocks to stream thousands of partial rows of a narrow layer)
+    const int groups = nparts > 4 * FOLD_LIMIT ? 64 : RED_GROUPS;
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((2 * c + 63) / 64, groups), dim3(256), 0, stream,
                        partial, scratch, nparts, c);
-    nparts = RED_GROUPS;
+    nparts = groups;
     return scratch;
 }
+static int fin_threads(int nparts) { return nparts > 64 ? 1024 : 256; }
 
 extern "C" int frhip_bn_finalize(const float* partial, int nparts, float* scratch, int c, float count,
                                  const float* gamma, const float* beta, float* running_mean, float* running_var,
                                  float momentum, float eps, float* mean, float* invstd, float* scale, float* shift,
                                  hipStream_t stream) {
-    // scratch: RED_GROUPS*2*c floats
+    // scratch: 64*2*c floats
     const float* p = fold_partials(partial, nparts, c, scratch, stream);
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((c + 63) / 64), dim3(256), 0, stream, p, nparts, c, count, gamma, beta,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((c + 63) / 64), dim3(fin_threads(nparts)), 0, stream, p, nparts, c, count, gamma, beta,
                        running_mean, running_var, momentum, eps, mean, invstd, scale, shift);
     return check_launch("frhip_bn_finalize");
 }
@@ -333,7 +350,7 @@ extern "C" int frhip_bn_bwd_finalize(const float* partial, int nparts, float* sc
                                      const float* gamma, const float* mean, const float* invstd, float* dgamma,
                                      float* dbeta, float* ca, float* cb, float* cc, hipStream_t stream) {
     const float* p = fold_partials(partial, nparts, c, scratch, stream);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((c + 63) / 64), dim3(256), 0, stream, p, nparts, c, count, gamma,
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((c + 63) / 64), dim3(fin_threads(nparts)), 0, stream, p, nparts, c, count, gamma,
                        mean, invstd, dgamma, dbeta, ca, cb, cc);
     return check_launch("frhip_bn_bwd_finalize");
 }

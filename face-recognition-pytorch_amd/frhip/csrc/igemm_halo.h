@@ -28,6 +28,8 @@ struct HaloGeom {
     int H, W, C;            // activation tensor (same spatial size in and out)
     int M, Nout, Ktot;      // N*H*W, output channels, 9*C
     int sign;               // +1 forward (offset = (r-1, s-1)), -1 data-gradient (offset = (1-r, 1-s))
+    int m_origin;           // first output pixel of m-tile 0 of THIS launch (tail launches start behind the full tiles)
+    int stat_row0;          // row of the BN-partial buffer that m-tile 0 of this launch writes
     uint32_t a_bytes, b_bytes;
 };
 
@@ -73,7 +75,7 @@ struct HaloMainloop {
 
         const __amdgpu_buffer_rsrc_t ra = make_rsrc(a_ptr, g.a_bytes);
         const __amdgpu_buffer_rsrc_t rb = make_rsrc(b_ptr, g.b_bytes);
-        const int m0 = mtile * BM;
+        const int m0 = g.m_origin + mtile * BM;
         const int hrows = BM + 2 * g.W + 2;                 // rows actually needed
         const int npieces = (hrows + 7) >> 3;
         const int p_lo = m0 - g.W - 1;                      // linear pixel of halo row 0
@@ -117,8 +119,8 @@ struct HaloMainloop {
         //      neighbour lies outside the image.  The K loop then only adds compile-time constants to them.
         const int fi = lane & 15, fg = lane >> 4;
         // two 16-bit offsets per register (a halo buffer is < 64 KiB): low half = even mt, high half = odd mt
-        static_assert(Tile::HALO_BYTES < 65536 && MT % 2 == 0, "packed fragment offsets");
-        uint32_t xa[9][MT / 2];
+        static_assert(Tile::HALO_BYTES < 65536, "packed fragment offsets");
+        uint32_t xa[9][(MT + 1) / 2];
         {
             const int HW = g.H * g.W;
 #pragma unroll

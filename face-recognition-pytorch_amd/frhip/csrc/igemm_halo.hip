@@ -27,19 +27,46 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void halo_kernel(HaloG
     }
     const int wave = wave_id();
     const int wm = wave / WN, wn = wave % WN;
-    const int m0 = mtile * Tile::BM + wm * Tile::WROWS, n0 = ntile * Tile::BN + wn * 64;
+    const int m0 = g.m_origin + mtile * Tile::BM + wm * Tile::WROWS, n0 = ntile * Tile::BN + wn * 64;
     EpiOperands<T, Tile::WROWS> eo;
     eo.fetch(res, stats ? br.y : nullptr, g.M, g.Nout, m0, n0);
     const char* mine = ml.template stage_out<T>(smem);
     nt_epilogue_store<T, WM, WN, Tile::WROWS, Tile::THREADS, Tile::BN>(mine, Tile::template stage_pitch<T>(), smem, g.M, g.Nout,
-                                                                       out, res != nullptr, stats, br, eo, mtile, ntile, m0, n0);
+                                                                       out, res != nullptr, stats, br, eo, g.stat_row0 + mtile, ntile, m0, n0);
+}
+
+// Tail balancing.  A launch of T = mtiles x ntiles equal tiles on `slots` resident workgroups takes ceil(T / slots) rounds;
+// with T = 3.06 x slots (256-channel layers at B = 512) the fourth round is 94 % empty.  Plan: run only the FULL rounds
+// with 256-row tiles, then cover the remaining rows of every column with at most slots / ntiles smaller tiles
+// (h x 64 rows, h = 1..3, a second launch of the same kernel instantiated with MT = h): the tail then costs ~h/4 of a round.
+struct HaloPlan {
+    int nb;        // 256-row m-tiles per column in the first launch
+    int h;         // tail tile height in 64-row units (0 = no tail launch)
+    int ns;        // tail m-tiles per column
+    int rows() const { return nb + ns; }
+};
+
+static HaloPlan halo_plan(int M, int ntiles, int slots, bool allow_tail) {
+    const int mtiles = (M + 255) / 256;
+    HaloPlan p = {mtiles, 0, 0};
+    const long long T = 1LL * mtiles * ntiles;
+    if (!allow_tail || ntiles > slots || (slots % ntiles) != 0 || T <= slots) return p;
+    const long long full = (T / slots) * slots;
+    if (full == T) return p;
+    const int nb = (int)(full / ntiles);                  // slots % ntiles == 0 -> exact
+    const int units = (M - nb * 256 + 63) / 64;           // 64-row units left per column
+    const int per_col = slots / ntiles;
+    const int h = (units + per_col - 1) / per_col;        // <= 4 because fewer than `slots` full tiles are left
+    if (h >= 4) return p;                                 // the tail would be (almost) a whole round anyway
+    p.nb = nb; p.h = h; p.ns = (units + h - 1) / h;
+    return p;
 }
 
 template <typename T, int WM, int WN, int MT, int HBUFS>
-static int halo_launch(const HaloGeom& g, const void* a, const void* b, void* out, const void* res, float* stats,
-                       const EpiBnRed& br, hipStream_t stream) {
+static int halo_launch_one(HaloGeom g, const void* a, const void* b, void* out, const void* res, float* stats,
+                           const EpiBnRed& br, int mtiles, int m_origin, int stat_row0, hipStream_t stream) {
     typedef HaloTile<T, WM, WN, MT, HBUFS> Tile;
-    const int mtiles = (g.M + Tile::BM - 1) / Tile::BM, ntiles = (g.Nout + Tile::BN - 1) / Tile::BN;
+    const int ntiles = (g.Nout + Tile::BN - 1) / Tile::BN;
     const int lds = Tile::template lds_bytes<T>();
     auto kern = halo_kernel<T, WM, WN, MT, HBUFS>;
     static bool attr_done = false;
@@ -50,8 +77,27 @@ static int halo_launch(const HaloGeom& g, const void* a, const void* b, void* ou
         }
         attr_done = true;
     }
+    g.m_origin = m_origin; g.stat_row0 = stat_row0;
     hipLaunchKernelGGL(kern, dim3(mtiles * ntiles), dim3(Tile::THREADS), lds, stream, g, a, b, out, res, stats, br, mtiles, ntiles);
     return check_launch("igemm_halo");
+}
+
+static int g_halo_tail = 1;      // test hook (frhip_set_conv_halo bit 4 clears it)
+
+// WGPC = workgroups of this configuration one CU holds (LDS / register limited): 2 for the 4-wave tile, 1 for the 8-wave one
+template <typename T, int WM, int WN, int HBUFS, int WGPC>
+static int halo_launch(const HaloGeom& g, const void* a, const void* b, void* out, const void* res, float* stats,
+                       const EpiBnRed& br, hipStream_t stream) {
+    static_assert(WM == 4, "256-row tiles");
+    const int ntiles = (g.Nout + WN * 64 - 1) / (WN * 64);
+    const HaloPlan p = halo_plan(g.M, ntiles, 256 * WGPC, g_halo_tail != 0);
+    int rc = halo_launch_one<T, WM, WN, 4, HBUFS>(g, a, b, out, res, stats, br, p.nb, 0, 0, stream);
+    if (rc || !p.h) return rc;
+    switch (p.h) {
+        case 1: return halo_launch_one<T, WM, WN, 1, HBUFS>(g, a, b, out, res, stats, br, p.ns, p.nb * 256, p.nb, stream);
+        case 2: return halo_launch_one<T, WM, WN, 2, HBUFS>(g, a, b, out, res, stats, br, p.ns, p.nb * 256, p.nb, stream);
+        default: return halo_launch_one<T, WM, WN, 3, HBUFS>(g, a, b, out, res, stats, br, p.ns, p.nb * 256, p.nb, stream);
+    }
 }
 
 static int g_halo_enabled = 1;
@@ -62,7 +108,32 @@ bool halo_applicable(int dtype, int h, int w, int c, int k, int r, int s, int st
            (dtype == FRHIP_DT_BF16 || dtype == FRHIP_DT_F32);
 }
 
-int halo_block_m() { return 256; }
+// which kernel configuration a problem gets: 0 = <4,1,4,1> (4 waves, 256x64, two workgroups per CU), 1 = <8,1,2,2>,
+// 2 = <4,2,4,2> (8 waves, 256x128, double-buffered halo)
+static int halo_config(int dtype, int c, int k) {
+    const int es = dtype == FRHIP_DT_BF16 ? 2 : 4;
+    const int nchunks = c / (NT_ROWB / es);
+    const bool narrow = (k % 128) != 0;
+    if (dtype == FRHIP_DT_BF16) {
+        // measured (tools/bench_kernels.py fwd, B=512): up to 256 input channels the 4-wave 256x64 tile with TWO
+        // workgroups per CU wins (117 vs 144 us at 128 ch, 106 vs 124 us at 256 ch): the second workgroup's MFMAs cover
+        // the first one's prologue, halo reloads, barriers and store epilogue.  From 512 channels the 8-wave 256x128
+        // tile with the double-buffered halo is level or ahead.  g_halo_enabled: 2 forces the former, 3 the latter.
+        const int mode = g_halo_enabled & 3;
+        const bool two_per_cu = mode == 2 || (mode != 3 && nchunks <= 4);
+        if (two_per_cu || narrow) return (nchunks == 1 || two_per_cu) ? 0 : 1;
+        return 2;
+    }
+    return narrow ? 1 : 2;
+}
+
+// rows of the BN-partial buffer a halo launch writes for an output of m pixels
+int halo_stat_rows(int dtype, int m, int c, int k) {
+    const int cfg = halo_config(dtype, c, k);
+    if (cfg == 1) return (m + 255) / 256;
+    const int bn = cfg == 0 ? 64 : 128;
+    return halo_plan(m, (k + bn - 1) / bn, cfg == 0 ? 512 : 256, g_halo_tail != 0).rows();
+}
 
 // a: activations [n,h,w,c] (forward: x, data-gradient: dy), b: [k][3][3][c] K-contiguous pack, out [n,h,w,k]
 int halo_run(int dtype, const void* a, const void* b, void* out, const void* res, float* stats, const EpiBnRed& br,
@@ -72,25 +143,23 @@ int halo_run(int dtype, const void* a, const void* b, void* out, const void* res
     if (ab > 0x7fffffffLL || bb > 0x7fffffffLL) { set_error("igemm_halo: tensor exceeds the 2 GiB buffer window"); return FRHIP_EINVAL; }
     HaloGeom g;
     g.H = h; g.W = w; g.C = c; g.M = n * h * w; g.Nout = k; g.Ktot = 9 * c; g.sign = sign;
+    g.m_origin = 0; g.stat_row0 = 0;
     g.a_bytes = (uint32_t)ab; g.b_bytes = (uint32_t)bb;
-    const int nchunks = c / (NT_ROWB / es);
-    const bool narrow = (k % 128) != 0;
+    const int cfg = halo_config(dtype, c, k);
     if (dtype == FRHIP_DT_BF16) {
-        // measured (tools/bench_kernels.py fwd, B=512): up to 256 input channels the 4-wave 256x64 tile with TWO
-        // workgroups per CU wins (117 vs 144 us at 128 ch, 106 vs 124 us at 256 ch): the second workgroup's MFMAs cover
-        // the first one's prologue, halo reloads, barriers and store epilogue.  From 512 channels the 8-wave 256x128
-        // tile with the double-buffered halo is level or ahead.  g_halo_enabled: 2 forces the former, 3 the latter.
-        const bool two_per_cu = g_halo_enabled == 2 || (g_halo_enabled != 3 && nchunks <= 4);
-        if (two_per_cu || narrow) {
-            if (nchunks == 1 || two_per_cu) return halo_launch<bf16_t, 4, 1, 4, 1>(g, a, b, out, res, stats, br, stream);
-            return halo_launch<bf16_t, 8, 1, 2, 2>(g, a, b, out, res, stats, br, stream);
-        }
-        return halo_launch<bf16_t, 4, 2, 4, 2>(g, a, b, out, res, stats, br, stream);
+        if (cfg == 0) return halo_launch<bf16_t, 4, 1, 1, 2>(g, a, b, out, res, stats, br, stream);
+        if (cfg == 1) return halo_launch_one<bf16_t, 8, 1, 2, 2>(g, a, b, out, res, stats, br, (g.M + 255) / 256, 0, 0, stream);
+        return halo_launch<bf16_t, 4, 2, 2, 1>(g, a, b, out, res, stats, br, stream);
     }
-    if (narrow) return halo_launch<float, 8, 1, 2, 2>(g, a, b, out, res, stats, br, stream);
-    return halo_launch<float, 4, 2, 4, 2>(g, a, b, out, res, stats, br, stream);
+    if (cfg == 1) return halo_launch_one<float, 8, 1, 2, 2>(g, a, b, out, res, stats, br, (g.M + 255) / 256, 0, 0, stream);
+    return halo_launch_one<float, 4, 2, 4, 2>(g, a, b, out, res, stats, br, (g.M + 255) / 256, 0, 0, stream);
 }
 
 }  // namespace frhip
 
-extern "C" int frhip_set_conv_halo(int enabled) { const int old = frhip::g_halo_enabled; frhip::g_halo_enabled = enabled; return old; }
+extern "C" int frhip_set_conv_halo(int enabled) {
+    // bits 0-1: 0 off, 1 auto, 2 force the 4-wave tile, 3 force the 8-wave tile; bit 4 set: no tail-balancing launch
+    const int old = frhip::g_halo_enabled | (frhip::g_halo_tail ? 0 : 16);
+    frhip::g_halo_enabled = enabled & 3; frhip::g_halo_tail = (enabled & 16) ? 0 : 1;
+    return old;
+}

@@ -134,6 +134,35 @@ def test_halo_kernel_equals_generic_kernel():
             np.testing.assert_allclose(o[2].numpy(), ref[2].numpy(), rtol=0, atol=ref[2].abs().max().item() * 2 ** -7)
 
 
+@pytest.mark.parametrize("case", [(48, 56, 64, 64, 1), (400, 7, 512, 512, 3), (200, 14, 256, 256, 1)])
+def test_halo_tail_balancing_equals_single_launch(case):
+    """more tiles than resident workgroups: the full rounds run 256-row tiles and a second launch covers the rest with
+    smaller tiles -- same outputs, same BN partial sums (fewer / more partial rows, equal column sums)"""
+    ops = _ops()
+    from frhip._abi import lib
+    n, h, c, k, mode = case
+    x = rnd(70, (n, h, h, c)).bfloat16().cuda()
+    w = (rnd(71, (k, 3, 3, c)) * 0.05).bfloat16().cuda()
+    dy = rnd(72, (n, h, h, k)).bfloat16().cuda()
+    wt = ops.pack_wt(w.float(), torch.bfloat16)
+    res = rnd(73, (n, h, h, c)).bfloat16().cuda()
+    y_bn = rnd(74, (n, h, h, c)).bfloat16().cuda()
+    rows = n * h * h
+    st = ops.bn_finalize(ops.colstats(y_bn.view(rows, c)), rows, torch.ones(c).cuda(), torch.zeros(c).cuda(), None, None)
+    outs = []
+    for tail in (0, 16):
+        old = lib().frhip_set_conv_halo(mode | tail)
+        y, part = ops.conv_fwd(x, w, 1, 1)
+        dx, bpart = ops.conv_dgrad(dy, wt, (n, h, h, c), 3, 3, 1, 1, residual=res, bnred=(y_bn, st, True))
+        lib().frhip_set_conv_halo(old)
+        outs.append((y, part, dx, bpart))
+    a, b = outs
+    assert a[1].shape[0] != b[1].shape[0], "the case must be large enough for a tail launch"
+    assert torch.equal(a[0], b[0]) and torch.equal(a[2], b[2])
+    for i in (1, 3):
+        np.testing.assert_allclose(a[i].sum(0).cpu().numpy(), b[i].sum(0).cpu().numpy(), rtol=1e-4, atol=1e-2)
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("case", [(3, 14, 64, 128, 1, True), (2, 28, 128, 128, 1, False), (2, 16, 64, 64, 2, True),
                                   (5, 7, 256, 256, 1, True), (1, 9, 64, 64, 1, False)])
