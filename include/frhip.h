@@ -53,7 +53,9 @@ int frhip_conv_stat_rows(int dtype, int m, int k, int h, int w, int c, int r, in
 /* test hook: bit 0 enables the linear-shift (stride-1) weight-gradient kernel; bits 1-2 select the all-nine-taps 3x3
  * kernel (0 off, 1 = automatic: 64-channel layers only, 2 = always).  Default 2 (= auto, linear off).  Returns the old value */
 int frhip_set_tn_linear(int enabled);
-/* test hook: 0 disables the LDS-halo 3x3/s1 kernel (generic NT kernel is used instead); returns the old value */
+/* test hook.  bits 0-1: 0 disables the LDS-halo 3x3/s1 kernel (generic NT kernel is used instead), 1 automatic tile choice,
+ * 2 forces the 4-wave 256x64 tile (two workgroups per CU), 3 the 8-wave 256x128 tile; bit 5 (32) enables the tail-balancing
+ * second launch of smaller tiles.  Returns the old value */
 int frhip_set_conv_halo(int enabled);
 /* test / micro-benchmark hook: force the NT tile (0 auto, 1 128x128, 2 256x64, 3 256x128, 4 256x256); returns the old value */
 int frhip_set_nt_tile(int tile);

@@ -150,7 +150,7 @@ def test_halo_tail_balancing_equals_single_launch(case):
     rows = n * h * h
     st = ops.bn_finalize(ops.colstats(y_bn.view(rows, c)), rows, torch.ones(c).cuda(), torch.zeros(c).cuda(), None, None)
     outs = []
-    for tail in (0, 16):
+    for tail in (32, 0):
         old = lib().frhip_set_conv_halo(mode | tail)
         y, part = ops.conv_fwd(x, w, 1, 1)
         dx, bpart = ops.conv_dgrad(dy, wt, (n, h, h, c), 3, 3, 1, 1, residual=res, bnred=(y_bn, st, True))
