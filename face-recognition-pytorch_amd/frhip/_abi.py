@@ -7,7 +7,7 @@ import re
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 HEADER = os.path.join(ROOT, "include", "frhip.h")
-LIB_PATH = os.path.join(HERE, "libfrhip.so")
+LIB_PATH = os.environ.get("FRHIP_LIB_PATH") or os.path.join(HERE, "libfrhip.so")   # override: kernel-variant experiments
 
 DT_BF16, DT_F32 = 0, 1
 

@@ -9,6 +9,12 @@
 namespace frhip {
 
 constexpr int EW_THREADS = 256;
+#ifndef EW_UNROLL
+#define EW_UNROLL 2
+#endif
+#ifndef EW_ROWS
+#define EW_ROWS 16
+#endif
 constexpr int RED_GROUPS = 16;      // second-level partial count
 
 template <typename T> struct EW {
@@ -169,7 +175,7 @@ __global__ __launch_bounds__(EW_THREADS) void bn_apply_kernel(const T* __restric
         sc[e] = scale[cg * EPV + e]; sh[e] = shift[cg * EPV + e];
         rs[e] = rscale ? rscale[cg * EPV + e] : 1.f; rb[e] = rscale ? rshift[cg * EPV + e] : 0.f;
     }
-#pragma unroll 2
+#pragma unroll EW_UNROLL
     for (int r = blockIdx.x * rlanes + rl; r < rows; r += gridDim.x * rlanes) {
         const size_t idx = (size_t)r * C + cg * EPV;
         Vec16<T> a = *reinterpret_cast<const Vec16<T>*>(y + idx);
@@ -207,7 +213,7 @@ __global__ __launch_bounds__(EW_THREADS) void bn_bwd_apply_kernel(const T* __res
         a_[e] = ca[cg * EPV + e]; b_[e] = cb[cg * EPV + e]; c_[e] = cc[cg * EPV + e];
         ms[e] = mscale ? mscale[cg * EPV + e] : 0.f; mb[e] = mscale ? mshift[cg * EPV + e] : 1.f;
     }
-#pragma unroll 2
+#pragma unroll EW_UNROLL
     for (int r = blockIdx.x * rlanes + rl; r < rows; r += gridDim.x * rlanes) {
         const size_t idx = (size_t)r * C + cg * EPV;
         const Vec16<T> d = *reinterpret_cast<const Vec16<T>*>(dout + idx);
@@ -260,7 +266,7 @@ static int ew_row_blocks(int rows, int c, int dtype) {
     const int epv = dtype == FRHIP_DT_BF16 ? 8 : 4;
     const int rlanes = EW_THREADS / (c / epv);
     // >= 8 rows per thread so the per-channel vectors (up to 40 floats per thread) are amortised
-    int b = (rows + rlanes * 8 - 1) / (rlanes * 8);
+    int b = (rows + rlanes * EW_ROWS - 1) / (rlanes * EW_ROWS);
     if (b > 2048) b = 2048;
     return b < 1 ? 1 : b;
 }
