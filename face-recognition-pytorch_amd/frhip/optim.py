@@ -170,3 +170,157 @@ class SGD(torch.optim.SGD):
     def last_grad_norm(self):
         """total gradient norm of the clipped groups at the last step (device scalar), as clip_grad_norm_ returns it"""
         return self._norm
+
+
+# ----------------------------------------------------------------------------------------------------- AdamW
+_ACHUNK_DT = np.dtype([("p", "<u8"), ("g", "<u8"), ("m", "<u8"), ("v", "<u8"), ("n", "<u4"), ("group", "<u4")])
+
+
+class _AGroup(ctypes.Structure):
+    _fields_ = [(k, ctypes.c_float) for k in ("lr", "beta1", "beta2", "eps", "weight_decay", "bc1", "bc2", "clip")]
+
+
+def _step_value(st):
+    v = st.get("step", 0)
+    return int(v.item()) if torch.is_tensor(v) else int(v)
+
+
+class AdamW(torch.optim.AdamW):
+    """torch.optim.AdamW whose step (and an optional clip_grad_norm_) runs as libfrhip multi-tensor kernels.  Same
+    state keys (`step`, `exp_avg`, `exp_avg_sq`) as torch, so PartialFCAdamW can keep moving the rows of its sampled
+    parameter in and out (/root/reference/nets/PartialFC.py:235-342).  The step counter must be uniform inside a
+    parameter group (it is: torch bumps every parameter together, PartialFCAdamW owns a group of its own);
+    anything else (amsgrad, maximize, mixed steps, non-fp32 / non-dense tensors) falls back to torch's step."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, **kw):
+        super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, **kw)
+        self._tables = {}
+        self._keep = None
+        self._coef = self._norm = self._pin = None
+        self._pin_next = 0
+
+    def _options_ok(self):
+        if len(self.param_groups) > 8:
+            return False
+        return not any(g.get("amsgrad") or g.get("maximize") or g.get("differentiable") or g.get("capturable")
+                       for g in self.param_groups)
+
+    def _table(self, entries, device):
+        parts = []
+        for p, g, m, v, gi in entries:
+            n = p.numel()
+            offs = np.arange(0, n, CHUNK, dtype=np.uint64)
+            t = np.empty(len(offs), dtype=_ACHUNK_DT)
+            t["p"], t["g"] = p.data_ptr() + 4 * offs, g.data_ptr() + 4 * offs
+            t["m"], t["v"] = m.data_ptr() + 4 * offs, v.data_ptr() + 4 * offs
+            t["n"] = np.minimum(n - offs, CHUNK).astype(np.uint32)
+            t["group"] = gi
+            parts.append(t)
+        host = np.concatenate(parts)
+        raw = torch.from_numpy(host.view(np.uint8).copy())
+        if self._pin is None or self._pin.shape[1] < raw.numel():
+            self._pin = torch.empty((8, raw.numel()), dtype=torch.uint8, pin_memory=True)
+            self._pin_next = 0
+        slot = self._pin[self._pin_next % 8, :raw.numel()]
+        self._pin_next += 1
+        slot.copy_(raw)
+        buf = torch.empty(raw.numel(), dtype=torch.uint8, device=device)
+        buf.copy_(slot, non_blocking=True)
+        return buf, len(host)
+
+    def _fallback(self, clip):
+        self._norm = torch.nn.utils.clip_grad_norm_(list(clip[0]), float(clip[1])) if clip is not None else None
+        super().step()
+
+    @torch.no_grad()
+    def step(self, closure=None, clip=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        if clip is not None:
+            clip = (list(clip[0]), float(clip[1]))
+        if not self._options_ok():
+            self._fallback(clip)
+            return loss
+        entries, steps = [], []
+        for gi, g in enumerate(self.param_groups):
+            gstep = None
+            for p in g["params"]:
+                gr = p.grad
+                if gr is None:
+                    continue
+                st = self.state[p]
+                sv = _step_value(st)
+                if gstep is None:
+                    gstep = sv
+                elif gstep != sv:
+                    self._fallback(clip)               # mixed step counters inside one group
+                    return loss
+                entries.append((p, gr, st.get("exp_avg"), st.get("exp_avg_sq"), gi))
+            steps.append(gstep)
+        if not entries:
+            return loss
+        key = tuple((p.data_ptr(), gr.data_ptr(), 0 if m is None else m.data_ptr(), 0 if v is None else v.data_ptr(), gi)
+                    for p, gr, m, v, gi in entries)
+        clip_sig = None if clip is None else (id(clip[0][0]) if clip[0] else 0, len(clip[0]))
+        hit = self._tables.get((key, clip_sig))
+        if hit is None:
+            ok = all(p.is_cuda and p.dtype == torch.float32 and gr.dtype == torch.float32 and not gr.is_sparse and
+                     _dense_same_layout(p.data, gr) for p, gr, _, _, _ in entries)
+            clip_ids = set() if clip is None else {id(p) for p in clip[0]}
+            group_clip = []
+            for gi in range(len(self.param_groups)):
+                inside = [id(p) in clip_ids for p, _, _, _, g2 in entries if g2 == gi]
+                if any(inside) and not all(inside):
+                    ok = False
+                group_clip.append(bool(inside) and all(inside))
+            if not ok:
+                self._fallback(clip)                   # before any state is created: torch initialises empty states itself
+                return loss
+            fixed = []
+            for p, gr, m, v, gi in entries:
+                st = self.state[p]
+                if "step" not in st:
+                    st["step"] = torch.tensor(0.0, dtype=torch.float32)
+                if m is None or not _dense_same_layout(p.data, m):
+                    m = st["exp_avg"] = torch.zeros_like(p.data, memory_format=torch.preserve_format)
+                if v is None or not _dense_same_layout(p.data, v):
+                    v = st["exp_avg_sq"] = torch.zeros_like(p.data, memory_format=torch.preserve_format)
+                fixed.append((p, gr, m, v, gi))
+            entries = fixed
+            device = entries[0][0].device
+            table, n = self._table(entries, device)
+            hit = (table, n, group_clip, torch.empty(n, dtype=torch.float32, device=device))
+            if len(self._tables) >= 8:
+                self._tables.clear()
+            key = tuple((p.data_ptr(), gr.data_ptr(), m.data_ptr(), v.data_ptr(), gi) for p, gr, m, v, gi in entries)
+            self._tables[(key, clip_sig)] = hit
+            if self._coef is None or self._coef.device != device:
+                self._coef = torch.ones(2, dtype=torch.float32, device=device)
+        table, n, group_clip, partial = hit
+        self._keep = entries
+        # bump the step counters the way torch does (tensor or python int, whatever the state holds)
+        for p, _, _, _, _ in entries:
+            st = self.state[p]
+            if torch.is_tensor(st.get("step")):
+                st["step"] += 1
+            else:
+                st["step"] = _step_value(st) + 1
+        groups = (_AGroup * len(self.param_groups))()
+        for gi, g in enumerate(self.param_groups):
+            t = (steps[gi] or 0) + 1
+            b1, b2 = g["betas"]
+            groups[gi] = _AGroup(float(g["lr"]), float(b1), float(b2), float(g["eps"]), float(g["weight_decay"]),
+                                 1.0 - float(b1) ** t, 1.0 - float(b2) ** t, 1.0 if group_clip[gi] else 0.0)
+        tbl, gptr, coef = ctypes.c_void_p(table.data_ptr()), ctypes.cast(groups, ctypes.c_void_p), None
+        if any(group_clip):
+            check(lib().frhip_adamw_clip_coef(tbl, n, gptr, len(groups), clip[1], ops._p(partial), ops._p(self._coef), ops._s()),
+                  "frhip_adamw_clip_coef")
+            coef = ops._p(self._coef)
+            self._norm = self._coef[1]
+        check(lib().frhip_adamw_multi(tbl, n, gptr, len(groups), coef, ops._s()), "frhip_adamw_multi")
+        return loss
+
+    def last_grad_norm(self):
+        return self._norm

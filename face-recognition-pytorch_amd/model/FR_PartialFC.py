@@ -181,7 +181,7 @@ class Model(nn.Module):
         c = self.conf
         groups = [{"params": self.encoder.parameters()}, {"params": self.loss.parameters()}]
         if c.optimizer == "AdamW":
-            opt = torch.optim.AdamW(groups, lr=self.lr, weight_decay=c.wd, eps=c.eps, betas=c.betas)
+            opt = importlib.import_module("frhip.optim").AdamW(groups, lr=self.lr, weight_decay=c.wd, eps=c.eps, betas=c.betas)
         elif c.optimizer == "SGD":
             # torch.optim.SGD subclass whose step() runs as three libfrhip kernels (same state / param_groups)
             opt = importlib.import_module("frhip.optim").SGD(groups, lr=self.lr, momentum=c.mom, weight_decay=c.wd)

@@ -223,6 +223,17 @@ int frhip_sgd_clip_coef(const frhip_sgd_chunk* chunks, int nchunks, const frhip_
 int frhip_sgd_multi(const frhip_sgd_chunk* chunks, int nchunks, const frhip_sgd_group* groups_host, int ngroups,
                     const float* clip_coef, frhip_stream_t stream);
 
+/* torch.optim.AdamW(betas, eps, weight_decay) (amsgrad off), same table scheme (model/FR_PartialFC.py:153-160 'AdamW' branch;
+ * nets/PartialFC.py:235-342 swaps exp_avg / exp_avg_sq rows in and out): bc1 = 1 - beta1^step, bc2 = 1 - beta2^step of the
+ * step being taken, computed by the caller per group.
+ * p *= 1 - lr*wd; m = b1*m + (1-b1)*g; v = b2*v + (1-b2)*g*g; p -= (lr/bc1) * m / (sqrt(v)/sqrt(bc2) + eps) */
+typedef struct { float lr, beta1, beta2, eps, weight_decay, bc1, bc2, clip; } frhip_adamw_group;
+typedef struct { float* p; const float* g; float* m; float* v; uint32_t n; uint32_t group; } frhip_adamw_chunk;
+int frhip_adamw_clip_coef(const frhip_adamw_chunk* chunks, int nchunks, const frhip_adamw_group* groups_host, int ngroups,
+                          float max_norm, float* partial, float* coef_out, frhip_stream_t stream);
+int frhip_adamw_multi(const frhip_adamw_chunk* chunks, int nchunks, const frhip_adamw_group* groups_host, int ngroups,
+                      const float* clip_coef, frhip_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -97,3 +97,43 @@ def test_sgd_honours_swapped_parameter_and_momentum_buffer():
         opt.step()
         outs.append((sub.detach().cpu(), mom.cpu()))
     assert torch.allclose(outs[0][0], outs[1][0]) and torch.allclose(outs[0][1], outs[1][1])
+
+
+def _run_adamw(opt_cls, device, steps=3, fused_clip=False):
+    ps, head = _make(device, 2)
+    opt = opt_cls([{"params": ps}, {"params": [head], "weight_decay": 0.0}], lr=1e-2, betas=(0.9, 0.99), eps=1e-8, weight_decay=0.05)
+    for k in range(steps):
+        _grads(ps, head, 20 + k, 3.0 if k == 0 else 0.01)
+        if fused_clip:
+            opt.step(clip=(ps, 5.0))
+        else:
+            torch.nn.utils.clip_grad_norm_(ps, 5.0)
+            opt.step()
+    st = [opt.state[p] for p in ps + [head]]
+    return ([p.detach().cpu() for p in ps + [head]], [s_["exp_avg"].cpu() for s_ in st], [s_["exp_avg_sq"].cpu() for s_ in st],
+            [int(s_["step"]) for s_ in st])
+
+
+def test_adamw_falls_back_to_torch_on_cpu_tensors():
+    from frhip.optim import AdamW
+    a, b = _run_adamw(torch.optim.AdamW, "cpu"), _run_adamw(AdamW, "cpu", fused_clip=True)
+    for x, y in zip(a[0] + a[1] + a[2], b[0] + b[1] + b[2]):
+        assert torch.equal(x, y)
+    assert a[3] == b[3]
+
+
+@pytest.mark.gpu
+def test_adamw_matches_torch_adamw_and_clip_grad_norm():
+    from frhip.optim import AdamW
+    ref = _run_adamw(torch.optim.AdamW, "cuda")
+    fell_back = []
+    orig = torch.optim.AdamW.step
+    torch.optim.AdamW.step = lambda self, *a, **k: (fell_back.append(1), orig(self, *a, **k))[1]
+    try:
+        got = _run_adamw(AdamW, "cuda", fused_clip=True)
+    finally:
+        torch.optim.AdamW.step = orig
+    assert not fell_back, "the fused kernels must take these parameters (no silent torch fallback)"
+    assert got[3] == ref[3] == [3] * len(ref[3])
+    for x, y in zip(got[0] + got[1] + got[2], ref[0] + ref[1] + ref[2]):
+        np.testing.assert_allclose(x.numpy(), y.numpy(), rtol=1e-5, atol=1e-6)
