@@ -249,6 +249,45 @@ def maxpool_bwd(dpool, arg, in_shape):
     return da
 
 
+# ------------------------------------------------------------------------------------------ recompute-style stem
+def stem_stats(x, wp):
+    """BN-statistic partials [blocks, 2, 64] of conv3x3(x) (x fp32 NCHW, wp = pack_stem(w, dtype, kp=32))"""
+    b, _, h, w = x.shape
+    part = torch.empty((lib().frhip_stem_blocks(b, h, w), 2, 64), dtype=torch.float32, device=x.device)
+    check(lib().frhip_stem_stats(dt_of(wp), _p(x), _p(wp), b, h, w, _p(part), _s()), "frhip_stem_stats")
+    return part
+
+
+def stem_fwd(x, wp, st):
+    """maxpool(relu(bn(conv(x)))) -> (pooled [B,Hp,Wp,64], argmax uint8) without materialising the conv output"""
+    b, _, h, w = x.shape
+    hp, wq = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    out = torch.empty((b, hp, wq, 64), dtype=wp.dtype, device=x.device)
+    arg = torch.empty((b, hp, wq, 64), dtype=torch.uint8, device=x.device)
+    check(lib().frhip_stem_fwd(dt_of(wp), _p(x), _p(wp), _p(st.scale), _p(st.shift), _p(out), _p(arg), b, h, w, _s()),
+          "frhip_stem_fwd")
+    return out, arg
+
+
+def stem_bwd(x, wp, dpool, arg, st, gamma, dgamma, dbeta, dw27, scratch=None):
+    """backward of the stem given the gradient of the pooled map: accumulates dgamma, dbeta and dw27 [64, 27] (fp32)"""
+    b, _, h, w = x.shape
+    dev = x.device
+    nb = lib().frhip_stem_blocks(b, h, w)
+    part = torch.empty((nb, 2, 64), dtype=torch.float32, device=dev)
+    check(lib().frhip_stem_bwd_reduce(dt_of(wp), _p(x), _p(wp), _p(dpool), _p(arg), _p(st.mean), _p(st.invstd), _p(st.scale),
+                                      _p(st.shift), b, h, w, _p(part), _s()), "frhip_stem_bwd_reduce")
+    coef = torch.empty((3, 64), dtype=torch.float32, device=dev)
+    if scratch is None:
+        scratch = torch.empty((64 * 2 * 64,), dtype=torch.float32, device=dev)
+    check(lib().frhip_bn_bwd_finalize(_p(part), nb, _p(scratch), 64, float(b * h * w), _p(gamma), _p(st.mean), _p(st.invstd),
+                                      _p(dgamma), _p(dbeta), _p(coef[0]), _p(coef[1]), _p(coef[2]), _s()),
+          "frhip_bn_bwd_finalize")
+    slabs = torch.empty((nb, 64, 32), dtype=torch.float32, device=dev)
+    check(lib().frhip_stem_bwd_wgrad(dt_of(wp), _p(x), _p(wp), _p(dpool), _p(arg), _p(coef[0]), _p(coef[1]), _p(coef[2]),
+                                     _p(st.scale), _p(st.shift), b, h, w, _p(slabs), _p(dw27), _s()), "frhip_stem_bwd_wgrad")
+
+
 # ------------------------------------------------------------------------------------------ packs
 def pack_wt(w_f32, dtype, out=None):
     """w [K,R,S,C] fp32 (physical) -> [C,R,S,K] dtype"""
@@ -306,9 +345,10 @@ def transpose2d(x, out_dtype=None, out=None, pad_to=1):
     return out
 
 
-def pack_stem(w_f32_k27, dtype):
+def pack_stem(w_f32_k27, dtype, kp=None):
     k = w_f32_k27.shape[0]
-    kp = 64 if dtype == torch.bfloat16 else 32
+    if kp is None:
+        kp = 64 if dtype == torch.bfloat16 else 32
     out = torch.empty((k, 1, 1, kp), dtype=dtype, device=w_f32_k27.device)
     check(lib().frhip_pack_stem(_DT[dtype], _p(w_f32_k27), _p(out), k, 27, kp, _s()), "frhip_pack_stem")
     return out

@@ -171,11 +171,28 @@ def bn_forward_state(bn, part, count, training):
     return ops.bn_eval_affine(bn.weight.data, bn.bias.data, bn.running_mean, bn.running_var, bn.eps)
 
 
+_FUSED_STEM = os.environ.get("FRHIP_FUSED_STEM", "1") == "1"
+
+
 def stem_forward(net, x, training, sv):
-    """conv3x3(3->64) as im2col + GEMM, then fused BN + ReLU + MaxPool(3,2,1) -> NHWC [B, H/2, W/2, 64]"""
+    """conv3x3(3->64) - BN - ReLU - MaxPool(3,2,1) -> NHWC [B, H/2, W/2, 64].
+
+    stride 1 (ResNet, SwinV2): recompute-style kernels -- the 64-channel conv output map (822 MB at B = 512) is never
+    written: one pass computes the BN statistics, a second one recomputes the conv and pools.  stride 2 (AlterNet):
+    im2col + GEMM, then fused BN + ReLU + MaxPool."""
     dt = net.dtype
     b, _, h, w = x.shape
     stride = net.conv1.stride
+    if stride == 1 and _FUSED_STEM:
+        wp0 = ops.pack_stem(net.conv1.physical().reshape(64, 27), dt, kp=32)
+        if training:
+            st0 = bn_forward_state(net.bn1, ops.stem_stats(x, wp0), b * h * w, True)
+        else:
+            st0 = bn_forward_state(net.bn1, None, b * h * w, False)
+        cur, arg0 = ops.stem_fwd(x, wp0, st0)
+        if sv is not None:
+            sv.x0, sv.wp0, sv.st0, sv.arg0, sv.col = x, wp0, st0, arg0, None
+        return cur
     col = ops.stem_im2col(x, dt, stride)
     h, w = (h - 1) // stride + 1, (w - 1) // stride + 1
     wp0 = ops.pack_stem(net.conv1.physical().reshape(64, 27), dt)
@@ -189,6 +206,10 @@ def stem_forward(net, x, training, sv):
 
 
 def stem_backward(net, sv, dout, bc):
+    if sv.col is None:          # recompute-style stem
+        ops.stem_bwd(sv.x0, sv.wp0, dout.contiguous(), sv.arg0, sv.st0, net.bn1.weight.data, bc.G(net.bn1.weight),
+                     bc.G(net.bn1.bias), phys_grad(bc.G(net.conv1.weight)).view(64, 27))
+        return
     da0 = ops.maxpool_bwd(dout, sv.arg0, sv.y0.shape)
     dy0 = ops.bn_backward(da0, sv.y0, sv.st0, net.bn1.weight.data, bc.G(net.bn1.weight), bc.G(net.bn1.bias), relu_mask=True)
     m, kp = sv.col.shape

@@ -200,6 +200,26 @@ int frhip_gelu_bwd(int dtype, const void* da, const void* h, void* dh, size_t n,
 int frhip_pair_score(const float* e1, const float* e2, const int64_t* labels, int n, int d, double* scores,
                      int* hist_idx, int* hist_genuine, int* hist_imposter, frhip_stream_t stream);
 
+/* ---- recompute-style stem (stride 1): conv3x3(3->64) -> BN -> ReLU -> MaxPool(3,2,1) of nets/resnet.py:232-235 without ever
+ * writing the conv output map or an im2col matrix; every pass recomputes the conv from x [b,3,h,w] fp32 NCHW and
+ * wp = frhip_pack_stem(w, 64, 27, 32) ([64][32] in `dtype`).  frhip_stem_blocks(b,h,w) = partial rows / slabs the
+ * grid-stride kernels write.
+ *   stats      : partial[blocks][2][64] = per-workgroup { sum y, sum y^2 }            -> frhip_bn_finalize
+ *   fwd        : pooled [b,hp,wp,64] `dtype`, argmax uint8 [b,hp,wp,64] (first max in row-major window order)
+ *   bwd_reduce : partial[blocks][2][64] = { sum d, sum d*(y-mean)*invstd }, d = maxpool_bwd(dpool) * (y*scale+shift > 0)
+ *                                                                                     -> frhip_bn_bwd_finalize
+ *   bwd_wgrad  : dy = ca*d + cb*y + cc; dw[64][27] (fp32) += sum_pixels dy x im2col; slabs: blocks*64*32 floats of scratch */
+int frhip_stem_blocks(int b, int h, int w);
+int frhip_stem_stats(int dtype, const float* x, const void* wp, int b, int h, int w, float* partial, frhip_stream_t stream);
+int frhip_stem_fwd(int dtype, const float* x, const void* wp, const float* scale, const float* shift, void* pooled,
+                   uint8_t* argmax, int b, int h, int w, frhip_stream_t stream);
+int frhip_stem_bwd_reduce(int dtype, const float* x, const void* wp, const void* dpool, const uint8_t* argmax,
+                          const float* mean, const float* invstd, const float* scale, const float* shift, int b, int h,
+                          int w, float* partial, frhip_stream_t stream);
+int frhip_stem_bwd_wgrad(int dtype, const float* x, const void* wp, const void* dpool, const uint8_t* argmax,
+                         const float* ca, const float* cb, const float* cc, const float* scale, const float* shift, int b,
+                         int h, int w, float* slabs, float* dw, frhip_stream_t stream);
+
 /* ---- per-step operand preparation of ALL conv weights in one launch (the reference casts them implicitly under autocast,
  * nets/resnet.py:23-46 + model/FR_PartialFC.py:166-170).  Per tensor w[k][rs][c] fp32: wc[k][rs][c] (forward operand) and
  * wt[c][rs][k] (data-gradient operand) in `dtype`; either destination may be NULL.  tile_begin = number of 32x32 tiles

@@ -311,6 +311,53 @@ def test_stem_im2col_conv_pool(dtype):
         np.testing.assert_allclose(dg.cpu().numpy(), g_.grad.numpy(), rtol=2e-3, atol=2e-4)
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("shape", [(2, 12, 10), (3, 23, 57), (1, 112, 112)])
+def test_recompute_stem_matches_torch(dtype, shape):
+    """stem_stats / stem_fwd / stem_bwd (conv output never materialised) vs torch autograd of conv - BN - ReLU - MaxPool
+    (reference stem, nets/resnet.py:232-235)"""
+    ops = _ops()
+    b, h, w = shape
+    x = rnd(80, (b, 3, h, w)).clamp(-1, 1)
+    wt = rnd(81, (64, 3, 3, 3), 0.2)
+    gamma, beta = 1 + 0.1 * rnd(82, (64,)), 0.1 * rnd(83, (64,))
+    xq, wq = q(x, dtype), q(wt, dtype)
+    w_ref = wq.clone().requires_grad_(True)
+    g_, b_ = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    y0 = F.conv2d(xq, w_ref, None, 1, 1)
+    a0 = F.relu(F.batch_norm(y0, None, None, g_, b_, True, 0.1, 1e-5))
+    p0 = F.max_pool2d(a0, 3, 2, 1)
+    dp = q(rnd(84, p0.shape), dtype)
+    # device
+    xd = x.cuda()
+    wp = ops.pack_stem(nhwc(wt).reshape(64, 27).contiguous().cuda(), dtype, kp=32)
+    part = ops.stem_stats(xd, wp)
+    st = ops.bn_finalize(part, b * h * w, gamma.cuda(), beta.cuda(), None, None)
+    np.testing.assert_allclose(st.mean.cpu().numpy(), y0.detach().mean((0, 2, 3)).numpy(), rtol=1e-3, atol=1e-4)
+    np.testing.assert_allclose(st.invstd.cpu().numpy(), (y0.detach().var((0, 2, 3), unbiased=False) + 1e-5).rsqrt().numpy(), rtol=1e-3)
+    pooled, arg = ops.stem_fwd(xd, wp, st)
+    np.testing.assert_allclose(nchw(pooled.float().cpu()).numpy(), p0.detach().numpy(), **tol(dtype, 3.0))
+    # reference backward: route the pooled gradient through the DEVICE's arg-max (bf16 rounding of the activations makes
+    # ties that torch's fp32 max-pool breaks differently -- both are valid sub-gradients), then autograd the rest
+    hp, wq_ = p0.shape[2], p0.shape[3]
+    argc = nchw(arg.cpu().long())                                   # [b,64,hp,wq] tap index r*3+s
+    ph = torch.arange(hp).view(1, 1, hp, 1); pw = torch.arange(wq_).view(1, 1, 1, wq_)
+    hh = (2 * ph - 1 + argc // 3).clamp(0, h - 1); ww = (2 * pw - 1 + argc % 3).clamp(0, w - 1)
+    da0 = torch.zeros_like(a0)
+    da0.view(b, 64, -1).scatter_add_(2, (hh * w + ww).view(b, 64, -1), dp.view(b, 64, -1))
+    a0.backward(da0)
+    dg, db = torch.zeros(64, device="cuda"), torch.zeros(64, device="cuda")
+    dw = torch.zeros((64, 27), device="cuda")
+    ops.stem_bwd(xd, wp, nhwc(dp).to(dtype).cuda(), arg, st, gamma.cuda(), dg, db, dw)
+    ref_dw = nhwc(w_ref.grad).reshape(64, 27)
+    t = dict(rtol=2e-3, atol=2e-4 * max(1.0, ref_dw.abs().max().item())) if dtype == torch.float32 else \
+        dict(rtol=5e-2, atol=5e-2 * ref_dw.abs().max().item())
+    np.testing.assert_allclose(dw.cpu().numpy(), ref_dw.numpy(), **t)
+    tg = dict(rtol=2e-3, atol=2e-3) if dtype == torch.float32 else dict(rtol=5e-2, atol=5e-2 * max(1.0, g_.grad.abs().max().item()))
+    np.testing.assert_allclose(dg.cpu().numpy(), g_.grad.numpy(), **tg)
+    np.testing.assert_allclose(db.cpu().numpy(), b_.grad.numpy(), **tg)
+
+
 def test_packs_roundtrip():
     ops = _ops()
     w = rnd(30, (48, 3, 3, 40))

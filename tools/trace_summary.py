@@ -9,7 +9,7 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 for r in rows:
     r["s"], r["e"] = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
 rows.sort(key=lambda r: r["s"])
-starts = [r["s"] for r in rows if "stem_im2col" in r["Kernel_Name"]]
+starts = [r["s"] for r in rows if "stem_im2col" in r["Kernel_Name"] or "stem_stats_kernel" in r["Kernel_Name"]]
 k = int(sys.argv[2]) if len(sys.argv) > 2 else len(starts) - 3
 a, b = starts[k], starts[k + 1]
 step = [r for r in rows if a <= r["s"] < b]
