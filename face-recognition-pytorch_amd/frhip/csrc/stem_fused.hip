@@ -270,8 +270,11 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__
 // receive from in LDS.
 //   WGRAD = false: partial[block] = { sum d, sum d*(y-mean)*invstd }            (p0 = mean, p1 = invstd)
 //   WGRAD = true : dy = p0*d + p1*y + p2;  slab[block][co][k] = sum dy[co]*col[k]
+#ifndef SF_BWD_OCC
+#define SF_BWD_OCC 2
+#endif
 template <typename T, bool WGRAD>
-__global__ __launch_bounds__(256, 2) void stem_bwd_kernel(const float* __restrict__ x, const T* __restrict__ wp,
+__global__ __launch_bounds__(256, SF_BWD_OCC) void stem_bwd_kernel(const float* __restrict__ x, const T* __restrict__ wp,
                                                        const T* __restrict__ dpool, const uint8_t* __restrict__ argmax,
                                                        const float* __restrict__ p0, const float* __restrict__ p1,
                                                        const float* __restrict__ p2, const float* __restrict__ scale,
@@ -477,6 +480,223 @@ __global__ __launch_bounds__(256, 2) void stem_bwd_kernel(const float* __restric
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// backward, bf16, scatter form.  The gather form above asks, for each of the 448 x 64 (pixel, channel) pairs of a tile,
+// "which of my (up to 4) windows chose me?" -- ~200 VALU ops per pixel-lane and 1.5 ms for the two passes.  Here the
+// tile's conv outputs go to LDS once ([448 pixels][64 channels] bf16 in the transposed-read layout) and the 145 x 64
+// pooled elements of the tile scatter instead: 7x fewer elements, one select each.
+//   WGRAD = false: Y tile = y;   pooled loop: d = dpool * (y*ms+mb > 0) -> { sum d, sum d*y }
+//   WGRAD = true : DY tile = cb*y + cc (+ a ReLU mask bit per element); pooled loop in four parity phases (windows of one
+//                  phase are disjoint, so the bf16 read-modify-writes need no atomics): DY[argmax pixel] += ca*dpool;
+//                  then dW += DY^T x im2col on the matrix pipe, DY fragments transposed-read straight from the tile.
+constexpr int SB_THREADS = 512, SB_WAVES = 8;
+constexpr int SB_NPIX = 4 * SF_PH * SF_PW;                     // 448 activation pixels per tile
+constexpr int SB_TH = SF_PH + 1, SB_TW = SF_PW + 1;            // 5 x 29 pooled windows can reach them
+constexpr int SB_DROW = 128 + 16, SB_AROW = 64 + 16;
+constexpr int SB_OFF_ARG = SB_TH * SB_TW * SB_DROW;
+constexpr int SB_OFF_XS = SB_OFF_ARG + SB_TH * SB_TW * SB_AROW;
+constexpr int SB_XR = 2 * SF_PH + 2, SB_XC = 2 * SF_PW + 2;
+constexpr int SB_OFF_CONST = SB_OFF_XS + ((3 * SB_XR * SB_XC * 2 + 15) / 16) * 16;
+constexpr int SB_OFF_TILE = SB_OFF_CONST + 5 * 64 * 4;
+constexpr int SB_OFF_MASK = SB_OFF_TILE + SB_NPIX * 128;
+constexpr int SB_OFF_COL = SB_OFF_MASK + SB_NPIX * 8;
+constexpr int SB_LDS_REDUCE = SB_OFF_MASK > SB_THREADS * 16 * 4 ? SB_OFF_MASK : SB_THREADS * 16 * 4;
+constexpr int SB_LDS_WGRAD = SB_OFF_COL + SB_WAVES * 32 * 128;
+
+// byte address of channel c of pixel row `row` in the [pixel][64 ch] bf16 tile (16-byte chunks swizzled per row)
+__device__ __forceinline__ int sb_addr(int row, int c) { return row * 128 + (((c >> 3) ^ sf_swz<128>(row)) << 4) + (c & 7) * 2; }
+
+template <bool WGRAD>
+__global__ __launch_bounds__(SB_THREADS, 1) void stem_bwd2_kernel(const float* __restrict__ x, const bf16_t* __restrict__ wp,
+                                                                 const bf16_t* __restrict__ dpool, const uint8_t* __restrict__ argmax,
+                                                                 const float* __restrict__ p0, const float* __restrict__ p1,
+                                                                 const float* __restrict__ p2, const float* __restrict__ scale,
+                                                                 const float* __restrict__ shift, float* __restrict__ outbuf,
+                                                                 int B, int H, int W) {
+    typedef bf16_t T;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* s_dp = smem;
+    uint8_t* s_arg = reinterpret_cast<uint8_t*>(smem + SB_OFF_ARG);
+    T* xs = reinterpret_cast<T*>(smem + SB_OFF_XS);
+    float* s_const = reinterpret_cast<float*>(smem + SB_OFF_CONST);     // [0] ms [1] mb [2] ca [3] cb [4] cc
+    char* s_tile = smem + SB_OFF_TILE;
+    uint32_t* s_mask = reinterpret_cast<uint32_t*>(smem + SB_OFF_MASK);  // [pixel][2 words]
+    StemConv<T> sc;
+    sc.init(wp, xs, SB_XR, SB_XC);
+    const int lane = lane_id(), wave = wave_id(), i = lane & 15, g = lane >> 4;
+    char* my_col = smem + SB_OFF_COL + wave * 32 * 128;
+    const int Hp = (H - 1) / 2 + 1, Wp = (W - 1) / 2 + 1;
+    const int tw = (Wp + SF_PW - 1) / SF_PW, th = (Hp + SF_PH - 1) / SF_PH;
+    for (int v = threadIdx.x; v < 64; v += SB_THREADS) {
+        s_const[v] = scale[v]; s_const[64 + v] = shift[v];
+        if (WGRAD) { s_const[128 + v] = p0[v]; s_const[192 + v] = p1[v]; s_const[256 + v] = p2[v]; }
+    }
+    auto cvec = [&](int which, int t) { return *reinterpret_cast<const f32x4_t*>(s_const + which * 64 + t * 16 + 4 * g); };
+    // the pooled loop gives every thread a fixed 8-channel group (cv) of varying windows
+    const int cv = threadIdx.x & 7;
+    float s1[8], s2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
+    f32x4_t dw[4][2];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { dw[t][0] = f32x4_t{0.f, 0.f, 0.f, 0.f}; dw[t][1] = dw[t][0]; }
+    if (WGRAD)
+        for (int v = lane; v < 32 * 128 / 16; v += 64) *reinterpret_cast<f32x4_t*>(my_col + v * 16) = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    for (int tile = blockIdx.x; tile < B * th * tw; tile += gridDim.x) {
+        int rem = tile;
+        const int n = rem / (tw * th); rem -= n * tw * th;
+        const int ph0 = (rem / tw) * SF_PH, pw0 = (rem % tw) * SF_PW;
+        __syncthreads();
+        sc.stage(xs, x + (size_t)n * 3 * H * W, 2 * ph0 - 1, 2 * pw0 - 1, H, W);
+        for (int v = threadIdx.x; v < SB_TH * SB_TW * 8; v += SB_THREADS) {
+            const int pix = v >> 3, part = v & 7;
+            const int ph = ph0 + pix / SB_TW, pw = pw0 + pix % SB_TW;
+            f32x4_t val = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            if (ph < Hp && pw < Wp)
+                val = *reinterpret_cast<const f32x4_t*>(reinterpret_cast<const char*>(dpool) + ((((size_t)n * Hp + ph) * Wp + pw) * 64) * 2 + part * 16);
+            *reinterpret_cast<f32x4_t*>(s_dp + pix * SB_DROW + part * 16) = val;
+        }
+        for (int v = threadIdx.x; v < SB_TH * SB_TW * 4; v += SB_THREADS) {
+            const int pix = v >> 2, part = v & 3;
+            const int ph = ph0 + pix / SB_TW, pw = pw0 + pix % SB_TW;
+            f32x4_t val = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            if (ph < Hp && pw < Wp)
+                val = *reinterpret_cast<const f32x4_t*>(argmax + (((size_t)n * Hp + ph) * Wp + pw) * 64 + part * 16);
+            *reinterpret_cast<f32x4_t*>(s_arg + pix * SB_AROW + part * 16) = val;
+        }
+        if (WGRAD) for (int v = threadIdx.x; v < SB_NPIX * 2; v += SB_THREADS) s_mask[v] = 0u;
+        __syncthreads();
+        // ---- A: conv outputs of the tile's pixels -> LDS tile
+        for (int it = wave; it * 16 < SB_NPIX; it += SB_WAVES) {
+            const int bp = it * 16 + i;
+            const int br = bp / (2 * SF_PW), bc = bp - br * (2 * SF_PW);
+            const bool live = 2 * ph0 + br < H && 2 * pw0 + bc < W;
+            typename StemConv<T>::Frag b[1];
+            f32x4_t acc[4];
+            sc.gather(br, bc, true, b);
+            sc.conv(b, acc);
+            uint32_t mbits[2] = {0u, 0u};
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int ch0 = t * 16 + 4 * g;
+                bf16x4_t q;
+                if (WGRAD) {
+                    const f32x4_t ms = cvec(0, t), mb = cvec(1, t), cb = cvec(3, t), cc = cvec(4, t);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float y = acc[t][r];
+                        q[r] = (bf16_t)(live ? cb[r] * y + cc[r] : 0.f);
+                        if (live && y * ms[r] + mb[r] > 0.f) mbits[ch0 >> 5] |= 1u << ((ch0 & 31) + r);
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) q[r] = (bf16_t)acc[t][r];
+                }
+                *reinterpret_cast<bf16x4_t*>(s_tile + sb_addr(bp, ch0)) = q;
+            }
+            if (WGRAD) {
+                if (mbits[0]) atomicOr(&s_mask[bp * 2 + 0], mbits[0]);
+                if (mbits[1]) atomicOr(&s_mask[bp * 2 + 1], mbits[1]);
+            }
+        }
+        __syncthreads();
+        // ---- B: pooled elements scatter
+        const f32x4_t* cms = reinterpret_cast<const f32x4_t*>(s_const + cv * 8);
+        const f32x4_t* cmb = reinterpret_cast<const f32x4_t*>(s_const + 64 + cv * 8);
+        const f32x4_t* cca = reinterpret_cast<const f32x4_t*>(s_const + 128 + cv * 8);
+        auto element = [&](int pl, int pc) {
+            const int pix = pl * SB_TW + pc;
+            const bf16x8_t dv = *reinterpret_cast<const bf16x8_t*>(s_dp + pix * SB_DROW + cv * 16);
+            const uint64_t a8 = *reinterpret_cast<const uint64_t*>(s_arg + pix * SB_AROW + cv * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int tap = (int)((a8 >> (8 * e)) & 0xffu);
+                const int br = 2 * pl - 1 + tap / 3, bc = 2 * pc - 1 + (tap - (tap / 3) * 3);
+                if ((unsigned)br >= (unsigned)(2 * SF_PH) || (unsigned)bc >= (unsigned)(2 * SF_PW)) continue;   // a neighbour tile's pixel
+                const int bp = br * (2 * SF_PW) + bc, c = cv * 8 + e;
+                bf16_t* slot = reinterpret_cast<bf16_t*>(s_tile + sb_addr(bp, c));
+                const float d = (float)dv[e];
+                if (WGRAD) {
+                    if ((s_mask[bp * 2 + (c >> 5)] >> (c & 31)) & 1u) *slot = (bf16_t)((float)*slot + cca[e >> 2][e & 3] * d);
+                } else {
+                    const float y = (float)*slot;
+                    const float de = (y * cms[e >> 2][e & 3] + cmb[e >> 2][e & 3] > 0.f) ? d : 0.f;
+                    s1[e] += de; s2[e] += de * y;
+                }
+            }
+        };
+        if (WGRAD) {
+            for (int phase = 0; phase < 4; ++phase) {
+                const int a = phase >> 1, b2 = phase & 1;
+                const int nr = (SB_TH - a + 1) / 2, nc = (SB_TW - b2 + 1) / 2;      // windows of this parity
+                for (int task = threadIdx.x; task < nr * nc * 8; task += SB_THREADS) {
+                    const int widx = task >> 3;
+                    element(a + 2 * (widx / nc), b2 + 2 * (widx % nc));
+                }
+                __syncthreads();
+            }
+        } else {
+            for (int task = threadIdx.x; task < SB_TH * SB_TW * 8; task += SB_THREADS) {
+                const int widx = task >> 3;
+                element(widx / SB_TW, widx % SB_TW);
+            }
+        }
+        // ---- C (WGRAD): dW += DY^T x im2col, 32 pixels per MFMA group
+        if (WGRAD) {
+            for (int grp = wave; grp * 32 < SB_NPIX; grp += SB_WAVES) {
+#pragma unroll
+                for (int sub = 0; sub < 2; ++sub) {
+                    const int bp = grp * 32 + sub * 16 + i;
+                    const int br = bp / (2 * SF_PW), bc = bp - br * (2 * SF_PW);
+                    typename StemConv<T>::Frag b[1];
+                    sc.gather(br, bc, true, b);
+                    const int row = sub * 16 + i;
+                    *reinterpret_cast<bf16x8_t*>(my_col + row * 128 + ((g ^ sf_swz<128>(row)) << 4)) = b[0];
+                }
+                bf16x8_t af[4], bf[2];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) af[t] = SfFrag<T, 128>::load(s_tile + grp * 32 * 128, t * 16, lane);
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt) bf[kt] = SfFrag<T, 128>::load(my_col, kt * 16, lane);
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int kt = 0; kt < 2; ++kt) Mma<T>::run(af[t], bf[kt], dw[t][kt]);
+            }
+        }
+    }
+    __syncthreads();
+    if (!WGRAD) {
+        float* red = reinterpret_cast<float*>(smem);              // [thread][16]
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { red[threadIdx.x * 16 + e] = s1[e]; red[threadIdx.x * 16 + 8 + e] = s2[e]; }
+        __syncthreads();
+        if (threadIdx.x < 64) {
+            const int c = threadIdx.x, cvv = c >> 3, e = c & 7;
+            float sd = 0.f, sdy = 0.f;
+            for (int tt = cvv; tt < SB_THREADS; tt += 8) { sd += red[tt * 16 + e]; sdy += red[tt * 16 + 8 + e]; }
+            outbuf[((size_t)blockIdx.x * 2 + 0) * 64 + c] = sd;
+            outbuf[((size_t)blockIdx.x * 2 + 1) * 64 + c] = p1[c] * (sdy - p0[c] * sd);      // p0 = mean, p1 = invstd
+        }
+    } else {
+        float* red = reinterpret_cast<float*>(smem);              // [8 waves][64 co][32 k]
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) red[(wave * 64 + t * 16 + 4 * g + r) * 32 + kt * 16 + i] = dw[t][kt][r];
+        __syncthreads();
+        for (int o = threadIdx.x; o < 64 * 32; o += SB_THREADS) {
+            float a = 0.f;
+#pragma unroll
+            for (int wv = 0; wv < SB_WAVES; ++wv) a += red[wv * 2048 + o];
+            outbuf[(size_t)blockIdx.x * 2048 + o] = a;
+        }
+    }
+}
+
 // dw[co][27] += sum over slabs of slab[co][32] (k < 27)
 __global__ __launch_bounds__(256) void stem_dw_reduce_kernel(const float* __restrict__ slabs, int nslabs, float* __restrict__ dw) {
     __shared__ float red[256];
@@ -580,10 +800,34 @@ static int sf_bwd(const float* x, const void* wp, const void* dpool, const uint8
     return check_launch(who);
 }
 
+template <bool WGRAD>
+static int sf_bwd2(const float* x, const void* wp, const void* dpool, const uint8_t* argmax, const float* p0, const float* p1,
+                   const float* p2, const float* scale, const float* shift, float* outbuf, int b, int h, int w,
+                   hipStream_t stream, const char* who) {
+    const int lds = WGRAD ? SB_LDS_WGRAD : SB_LDS_REDUCE;
+    static_assert(SB_LDS_WGRAD >= SB_WAVES * 64 * 32 * 4 && SB_LDS_WGRAD <= 160 * 1024, "LDS budget");
+    auto kern = stem_bwd2_kernel<WGRAD>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
+            set_error("%s: cannot raise dynamic LDS to %d bytes", who, lds);
+            return FRHIP_ELAUNCH;
+        }
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(frhip_stem_blocks(b, h, w)), dim3(SB_THREADS), lds, stream, x, (const bf16_t*)wp,
+                       (const bf16_t*)dpool, argmax, p0, p1, p2, scale, shift, outbuf, b, h, w);
+    return check_launch(who);
+}
+
+static int g_stem_scatter = 1;       // test hook: 0 = gather-form backward for bf16 too
+
 extern "C" int frhip_stem_bwd_reduce(int dtype, const float* x, const void* wp, const void* dpool, const uint8_t* argmax,
                                      const float* mean, const float* invstd, const float* scale, const float* shift,
                                      int b, int h, int w, float* partial, hipStream_t stream) {
     if (!sf_ok(dtype, b, h, w, "frhip_stem_bwd_reduce")) return FRHIP_EINVAL;
+    if (dtype == FRHIP_DT_BF16 && g_stem_scatter)
+        return sf_bwd2<false>(x, wp, dpool, argmax, mean, invstd, nullptr, scale, shift, partial, b, h, w, stream, "frhip_stem_bwd_reduce");
     return dtype == FRHIP_DT_BF16
         ? sf_bwd<bf16_t, false>(x, wp, dpool, argmax, mean, invstd, nullptr, scale, shift, partial, b, h, w, stream, "frhip_stem_bwd_reduce")
         : sf_bwd<float, false>(x, wp, dpool, argmax, mean, invstd, nullptr, scale, shift, partial, b, h, w, stream, "frhip_stem_bwd_reduce");
@@ -593,10 +837,14 @@ extern "C" int frhip_stem_bwd_wgrad(int dtype, const float* x, const void* wp, c
                                     const float* ca, const float* cb, const float* cc, const float* scale, const float* shift,
                                     int b, int h, int w, float* slabs, float* dw, hipStream_t stream) {
     if (!sf_ok(dtype, b, h, w, "frhip_stem_bwd_wgrad")) return FRHIP_EINVAL;
-    int rc = dtype == FRHIP_DT_BF16
+    int rc = (dtype == FRHIP_DT_BF16 && g_stem_scatter)
+        ? sf_bwd2<true>(x, wp, dpool, argmax, ca, cb, cc, scale, shift, slabs, b, h, w, stream, "frhip_stem_bwd_wgrad")
+        : dtype == FRHIP_DT_BF16
         ? sf_bwd<bf16_t, true>(x, wp, dpool, argmax, ca, cb, cc, scale, shift, slabs, b, h, w, stream, "frhip_stem_bwd_wgrad")
         : sf_bwd<float, true>(x, wp, dpool, argmax, ca, cb, cc, scale, shift, slabs, b, h, w, stream, "frhip_stem_bwd_wgrad");
     if (rc) return rc;
     hipLaunchKernelGGL(stem_dw_reduce_kernel, dim3(64 * 27), dim3(256), 0, stream, slabs, frhip_stem_blocks(b, h, w), dw);
     return check_launch("frhip_stem_bwd_wgrad(reduce)");
 }
+
+extern "C" int frhip_set_stem_scatter(int enabled) { const int old = g_stem_scatter; g_stem_scatter = enabled; return old; }

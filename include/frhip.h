@@ -210,6 +210,8 @@ int frhip_pair_score(const float* e1, const float* e2, const int64_t* labels, in
  *                                                                                     -> frhip_bn_bwd_finalize
  *   bwd_wgrad  : dy = ca*d + cb*y + cc; dw[64][27] (fp32) += sum_pixels dy x im2col; slabs: blocks*64*32 floats of scratch */
 int frhip_stem_blocks(int b, int h, int w);
+/* test hook: 0 = gather-form backward kernels for bf16 as well (fp32 always uses them); returns the old value */
+int frhip_set_stem_scatter(int enabled);
 int frhip_stem_stats(int dtype, const float* x, const void* wp, int b, int h, int w, float* partial, frhip_stream_t stream);
 int frhip_stem_fwd(int dtype, const float* x, const void* wp, const float* scale, const float* shift, void* pooled,
                    uint8_t* argmax, int b, int h, int w, frhip_stream_t stream);

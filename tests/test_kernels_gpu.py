@@ -356,6 +356,16 @@ def test_recompute_stem_matches_torch(dtype, shape):
     tg = dict(rtol=2e-3, atol=2e-3) if dtype == torch.float32 else dict(rtol=5e-2, atol=5e-2 * max(1.0, g_.grad.abs().max().item()))
     np.testing.assert_allclose(dg.cpu().numpy(), g_.grad.numpy(), **tg)
     np.testing.assert_allclose(db.cpu().numpy(), b_.grad.numpy(), **tg)
+    if dtype == torch.bfloat16:
+        # bf16 runs the scatter-form backward by default; the gather-form kernels (the fp32 path) must agree with it
+        from frhip._abi import lib
+        old = lib().frhip_set_stem_scatter(0)
+        dg2, db2, dw2 = torch.zeros(64, device="cuda"), torch.zeros(64, device="cuda"), torch.zeros((64, 27), device="cuda")
+        ops.stem_bwd(xd, wp, nhwc(dp).to(dtype).cuda(), arg, st, gamma.cuda(), dg2, db2, dw2)
+        lib().frhip_set_stem_scatter(old)
+        np.testing.assert_allclose(dg.cpu().numpy(), dg2.cpu().numpy(), rtol=1e-2, atol=1e-2 * max(1.0, dg2.abs().max().item()))
+        np.testing.assert_allclose(db.cpu().numpy(), db2.cpu().numpy(), rtol=1e-2, atol=1e-2 * max(1.0, db2.abs().max().item()))
+        np.testing.assert_allclose(dw.cpu().numpy(), dw2.cpu().numpy(), rtol=2e-2, atol=2e-2 * dw2.abs().max().item())
 
 
 def test_packs_roundtrip():
