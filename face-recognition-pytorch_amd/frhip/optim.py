@@ -111,60 +111,72 @@ class SGD(torch.optim.SGD):
         if not self._options_ok():
             self._fallback(clip)
             return loss
-        # (parameter, gradient, momentum buffer, group) of everything that has a gradient.  The pointer signature
-        # of this list keys the cached chunk table, so a steady-state step costs one pass over the parameters.
-        entries = []
+        clip_sig = None if clip is None else (id(clip[0][0]) if clip[0] else 0, len(clip[0]))
+        clip_ids = None
+        # One chunk table per parameter group, cached by the pointer signature of its (parameter, gradient, momentum)
+        # triples: PartialFC swaps the sampled class-centre parameter of the LAST group every step, which then rebuilds a
+        # ~100-chunk table instead of the whole model's.
+        hits, keep = [], []
         for gi, g in enumerate(self.param_groups):
             mom = g["momentum"] != 0
+            entries = []
             for p in g["params"]:
                 gr = p.grad
-                if gr is None:
-                    continue
-                entries.append((p, gr, self.state[p].get("momentum_buffer") if mom else None, gi))
-        if not entries:
+                if gr is not None:
+                    entries.append((p, gr, self.state[p].get("momentum_buffer") if mom else None, gi))
+            if not entries:
+                hits.append(None)
+                continue
+            key = (gi, clip_sig) + tuple((p.data_ptr(), gr.data_ptr(), 0 if m is None else m.data_ptr()) for p, gr, m, _ in entries)
+            hit = self._tables.get(key)
+            if hit is None:
+                fixed = []
+                for p, gr, m, _ in entries:
+                    if mom and (m is None or not _dense_same_layout(p.data, m)):
+                        m = self.state[p]["momentum_buffer"] = torch.zeros_like(p.data, memory_format=torch.preserve_format)
+                    fixed.append((p, gr, m, gi))
+                entries = fixed
+                if clip_ids is None:
+                    clip_ids = set() if clip is None else {id(p) for p in clip[0]}
+                inside = [id(p) in clip_ids for p, _, _, _ in entries]
+                if not self._tensors_ok(entries) or (any(inside) and not all(inside)):
+                    self._fallback(clip)                  # incl. a clip set that cuts through a group
+                    return loss
+                device = entries[0][0].device
+                table, n = self._build_table(entries, device)
+                hit = (table, n, all(inside), torch.empty(n, dtype=torch.float32, device=device))
+                if len(self._tables) >= 16:
+                    self._tables.clear()
+                key = (gi, clip_sig) + tuple((p.data_ptr(), gr.data_ptr(), 0 if m is None else m.data_ptr()) for p, gr, m, _ in entries)
+                self._tables[key] = hit
+                if self._coef is None or self._coef.device != device:
+                    self._coef = torch.ones(2, dtype=torch.float32, device=device)
+            hits.append(hit)
+            keep.append(entries)
+        if not keep:
             return loss
-        key = tuple((p.data_ptr(), gr.data_ptr(), 0 if m is None else m.data_ptr(), gi) for p, gr, m, gi in entries)
-        clip_sig = None if clip is None else (id(clip[0][0]) if clip[0] else 0, len(clip[0]))
-        hit = self._tables.get((key, clip_sig))
-        if hit is None:
-            # slow path: create missing momentum buffers, validate layouts, build the table
-            fixed = []
-            for p, gr, m, gi in entries:
-                if self.param_groups[gi]["momentum"] != 0 and (m is None or not _dense_same_layout(p.data, m)):
-                    m = self.state[p]["momentum_buffer"] = torch.zeros_like(p.data, memory_format=torch.preserve_format)
-                fixed.append((p, gr, m, gi))
-            entries = fixed
-            clip_ids = set() if clip is None else {id(p) for p in clip[0]}
-            group_clip, ok = [], self._tensors_ok(entries)
-            for gi in range(len(self.param_groups)):
-                inside = [id(p) in clip_ids for p, _, _, g2 in entries if g2 == gi]
-                if any(inside) and not all(inside):
-                    ok = False                            # a clip set that cuts through a group: not expressible per group
-                group_clip.append(bool(inside) and all(inside))
-            if not ok:
-                self._fallback(clip)
-                return loss
-            device = entries[0][0].device
-            table, n = self._build_table(entries, device)
-            hit = (table, n, group_clip, torch.empty(n, dtype=torch.float32, device=device))
-            if len(self._tables) >= 8:
-                self._tables.clear()
-            key = tuple((p.data_ptr(), gr.data_ptr(), 0 if m is None else m.data_ptr(), gi) for p, gr, m, gi in entries)
-            self._tables[(key, clip_sig)] = hit
-            if self._coef is None or self._coef.device != device:
-                self._coef = torch.ones(2, dtype=torch.float32, device=device)
-        table, n, group_clip, partial = hit
-        self._keep = entries                               # the table holds raw pointers: keep their owners alive
+        self._keep = keep                                  # the tables hold raw pointers: keep their owners alive
         groups = (_Group * len(self.param_groups))()
+        clipped = []
         for gi, g in enumerate(self.param_groups):
-            groups[gi] = _Group(float(g["lr"]), float(g["weight_decay"]), float(g["momentum"]), 1.0 if group_clip[gi] else 0.0)
-        tbl, gptr, coef = ctypes.c_void_p(table.data_ptr()), ctypes.cast(groups, ctypes.c_void_p), None
-        if any(group_clip):
-            check(lib().frhip_sgd_clip_coef(tbl, n, gptr, len(groups), clip[1], ops._p(partial), ops._p(self._coef), ops._s()),
-                  "frhip_sgd_clip_coef")
+            c = hits[gi] is not None and hits[gi][2]
+            if c:
+                clipped.append(gi)
+            groups[gi] = _Group(float(g["lr"]), float(g["weight_decay"]), float(g["momentum"]), 1.0 if c else 0.0)
+        gptr, coef = ctypes.cast(groups, ctypes.c_void_p), None
+        if len(clipped) > 1:
+            self._fallback(clip)                           # the norm would span several tables: not built (torch does it)
+            return loss
+        if clipped:
+            table, n, _, partial = hits[clipped[0]]
+            check(lib().frhip_sgd_clip_coef(ctypes.c_void_p(table.data_ptr()), n, gptr, len(groups), clip[1], ops._p(partial),
+                                            ops._p(self._coef), ops._s()), "frhip_sgd_clip_coef")
             coef = ops._p(self._coef)
             self._norm = self._coef[1]
-        check(lib().frhip_sgd_multi(tbl, n, gptr, len(groups), coef, ops._s()), "frhip_sgd_multi")
+        for hit in hits:
+            if hit is not None:
+                check(lib().frhip_sgd_multi(ctypes.c_void_p(hit[0].data_ptr()), hit[1], gptr, len(groups), coef, ops._s()),
+                      "frhip_sgd_multi")
         return loss
 
     def last_grad_norm(self):

@@ -65,7 +65,13 @@ class Model(nn.Module):
             self.encoder.load_state_dict({k[7:]: v for k, v in pre.items()}, strict=True)   # strip 'module.'
         if stage == "train":
             if getattr(conf, "world_size", 1) > 1 or getattr(conf, "force_ddp", False):
-                self.encoder = DDP(self.encoder, broadcast_buffers=False, device_ids=[conf.local_rank])
+                # where the reference has DistributedDataParallel(encoder): same surface ('module.' keys, rank-0 broadcast at
+                # construction), but the backbone averages its flat gradient arena in place with RCCL during backward
+                # (nets._backbone.DataParallel) instead of copying every gradient through DDP's buckets
+                if hasattr(self.encoder, "_backward_impl"):
+                    self.encoder = importlib.import_module("nets._backbone").DataParallel(self.encoder)
+                else:
+                    self.encoder = DDP(self.encoder, broadcast_buffers=False, device_ids=[conf.local_rank])
             head_mod = importlib.import_module("nets.%s" % getattr(conf, "loss", "PartialFC"))
             if conf.optimizer == "SGD":
                 self.loss = head_mod.PartialFC(conf=conf, num_classes=conf.n_classes)
@@ -83,6 +89,8 @@ class Model(nn.Module):
         """the reference's step body (model/FR_PartialFC.py:167-188, non-GradScaler branch)"""
         self.opt.zero_grad()
         self.encoder.train()
+        if hasattr(self.loss, "prepare"):          # label all-gather + the one sync sampling needs, before the GPU gets busy
+            self.loss.prepare(id_)
         feat = normalize(self.forward(img))
         self.loss.train()
         loss = self.loss(feat, id_, self.opt)

@@ -227,7 +227,7 @@ class AlterNet(nn.Module):
 
     def _backward_impl(self, sv, d_emb, params):
         dt = self.dtype
-        bc = BackwardCtx(params, d_emb.device)
+        bc = BackwardCtx(params, d_emb.device, allreduce=getattr(self, "_frhip_allreduce", False))
         dout = tail_backward(self, sv, d_emb, bc)
         layers = list(self._layers())
         part = None

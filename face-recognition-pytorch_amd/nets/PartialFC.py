@@ -241,26 +241,75 @@ class _PartialFCBase(torch.nn.Module):
         return self._kernels
 
     @torch.no_grad()
-    def sample(self, labels, index_positive, optimizer):
+    def sample(self, labels, index_positive, optimizer, n_positive=None):
         """Choose the rows of this shard that take part in the step and re-express labels as positions in
-        that list (reference :92-131 / :309-327).  Mutates `labels` in place like the reference."""
+        that list (reference :92-131 / :309-327).  Mutates `labels` in place like the reference.
+
+        n_positive: number of distinct owned classes in the batch when the caller already knows it (prepare()): the
+        usual branch (num_sample >= n_positive) then runs without a single host synchronisation -- no boolean-mask
+        indexing, no unique() -- and produces the same index set (a set of rows: independent of top-k tie order)."""
         self.step += 1
         dev = labels.device
-        positive = torch.unique(labels[index_positive], sorted=True)
-        if self.num_sample - positive.size(0) >= 0:
-            perm = torch.rand(size=[self.num_local]).to(dev)     # CPU generator, then moved: same draws as the reference
-            perm[positive] = 2.0
-            index = torch.topk(perm, k=self.num_sample)[1]
-            index = index.sort()[0]
+        if n_positive is not None and self.num_sample - n_positive >= 0:
+            lab, mask = labels.view(-1), index_positive.view(-1)
+            perm = self._draw_perm(dev)                          # CPU generator, then moved: same draws as the reference
+            ext = torch.cat([perm, perm.new_zeros(1)])
+            ext.index_fill_(0, torch.where(mask, lab, torch.full_like(lab, self.num_local)), 2.0)    # perm[positive] = 2
+            index = torch.topk(ext[:self.num_local], k=self.num_sample)[1].sort()[0]
+            pos = torch.searchsorted(index, lab.clamp(min=0))
+            labels.copy_(torch.where(mask, pos, lab).view(labels.shape))
         else:
-            index = positive
+            positive = torch.unique(labels[index_positive], sorted=True)
+            if self.num_sample - positive.size(0) >= 0:
+                perm = torch.rand(size=[self.num_local]).to(dev)
+                perm[positive] = 2.0
+                index = torch.topk(perm, k=self.num_sample)[1]
+                index = index.sort()[0]
+            else:
+                index = positive
+            labels[index_positive] = torch.searchsorted(index, labels[index_positive])
         self.weight_index = index
-        labels[index_positive] = torch.searchsorted(index, labels[index_positive])
         k = self.kernels
         self.weight_activated = torch.nn.Parameter(k.gather_rows(self.weight, index))
         for nm in self._state_names:
             setattr(self, "weight_activated_" + nm, k.gather_rows(getattr(self, "weight_" + nm), index))
         self._install_optimizer_state(optimizer)
+
+    def _draw_perm(self, dev):
+        """torch.rand(num_local) from the CPU generator (the reference's draws, :110) delivered to the device through a
+        rotating set of pinned buffers: a pageable host-to-device copy blocks the host until the GPU reaches it, which
+        drains the launch queue in the middle of the step."""
+        if dev.type != "cuda":
+            return torch.rand(size=[self.num_local]).to(dev)
+        pins = getattr(self, "_perm_pins", None)
+        if pins is None:
+            pins = self._perm_pins = [torch.empty(self.num_local, pin_memory=True) for _ in range(4)]
+            self._perm_turn = 0
+        buf = pins[self._perm_turn % len(pins)]
+        self._perm_turn += 1
+        torch.rand(size=[self.num_local], out=buf)
+        return buf.to(dev, non_blocking=True)
+
+    @torch.no_grad()
+    def prepare(self, local_labels):
+        """Optional, call at the START of a step (before the backbone is enqueued): gathers the labels of all ranks and
+        counts this shard's distinct positives.  The one host synchronisation sampling needs (is num_sample >= #positives?,
+        reference :112) then happens while the GPU still has the previous step to chew on, and forward() runs without any
+        -- a mid-step synchronisation drains the launch queue and costs ~3 ms of idle GPU per step at B = 512."""
+        lab = local_labels.view(-1).long()
+        if self.world_size > 1 or _FORCE_COLLECTIVES:
+            glabels = [torch.zeros_like(lab) for _ in range(self.world_size)]
+            distributed.all_gather(glabels, lab)
+            labels = torch.cat(glabels)
+        else:
+            labels = lab.clone()
+        n_pos = None
+        if self.sample_rate < 1:
+            mask = (self.class_start <= labels) & (labels < self.class_start + self.num_local)
+            hits = torch.zeros(self.num_local + 1, dtype=torch.int32, device=labels.device)
+            hits.index_fill_(0, torch.where(mask, labels - self.class_start, torch.full_like(labels, self.num_local)), 1)
+            n_pos = int(hits[:self.num_local].sum().item())
+        self._prep = (local_labels.data_ptr(), labels, n_pos)
 
     @torch.no_grad()
     def update(self):
@@ -284,21 +333,30 @@ class _PartialFCBase(torch.nn.Module):
         assert self.last_batch_size == batch_size, (
             "last batch size do not equal current batch size: {} vs {}".format(self.last_batch_size, batch_size))
         dev = local_embeddings.device
+        prep, self._prep = getattr(self, "_prep", None), None
+        n_pos = None
         if self.world_size > 1 or _FORCE_COLLECTIVES:
             gathered = [torch.zeros((batch_size, self.embedding_size), device=dev) for _ in range(self.world_size)]
-            glabels = [torch.zeros(batch_size, dtype=torch.long, device=dev) for _ in range(self.world_size)]
             embeddings = torch.cat(AllGather(local_embeddings, *gathered))
-            distributed.all_gather(glabels, local_labels)
-            labels = torch.cat(glabels)
+            if prep is not None and prep[1].numel() == batch_size * self.world_size:
+                labels, n_pos = prep[1], prep[2]                      # gathered at the start of the step by prepare()
+            else:
+                glabels = [torch.zeros(batch_size, dtype=torch.long, device=dev) for _ in range(self.world_size)]
+                distributed.all_gather(glabels, local_labels)
+                labels = torch.cat(glabels)
         else:
-            embeddings, labels = local_embeddings, local_labels.clone()
+            embeddings = local_embeddings
+            if prep is not None and prep[1].numel() == batch_size:
+                labels, n_pos = prep[1], prep[2]
+            else:
+                labels = local_labels.clone()
         labels = labels.view(-1, 1)
         index_positive = (self.class_start <= labels) & (labels < self.class_start + self.num_local)
         # shard-relative label, -1 when another rank owns the class (reference :188-193); written with where()
         # so no boolean-mask indexing (= no host sync; the step stays capturable in a HIP graph)
         labels = torch.where(index_positive, labels - self.class_start, torch.full_like(labels, -1))
         if self.sample_rate < 1:
-            self.sample(labels, index_positive, optimizer)
+            self.sample(labels, index_positive, optimizer, n_pos)
         return _MarginSoftmaxFn.apply(embeddings, self.weight_activated, labels.view(-1).to(torch.int32).contiguous(),
                                       self.kernels, float(self.margin_softmax.scale), float(self.margin_softmax.margin),
                                       2 if (_FORCE_COLLECTIVES and self.world_size == 1) else self.world_size)

@@ -258,7 +258,7 @@ class Swin(nn.Module):
 
     def _backward_impl(self, sv, d_emb, params):
         dt = self.dtype
-        bc = BackwardCtx(params, d_emb.device)
+        bc = BackwardCtx(params, d_emb.device, allreduce=getattr(self, "_frhip_allreduce", False))
         dout = tail_backward(self, sv, d_emb, bc)
         for mod, s in zip(reversed(list(self._layers())), reversed(sv.layers)):
             if isinstance(mod, _Conv):

@@ -6,6 +6,7 @@ Only orchestration lives here: every tensor op is a libfrhip kernel (frhip.ops).
 import os
 
 import torch
+import torch.distributed as dist
 import torch.nn as nn
 
 from frhip import ops
@@ -90,13 +91,15 @@ def phys_grad(g):
 
 def flat_grads(params, device):
     """One zeroed fp32 arena for every parameter gradient of the step (a single fill instead of ~160), carved
-    into views that have each parameter's own memory layout (channels_last for conv weights)."""
+    into views that have each parameter's own memory layout (channels_last for conv weights).
+    -> (views {param: tensor}, arena, offsets {param: first element in the arena})"""
     total = sum(p.numel() for p in params)
     flat = torch.zeros(total, dtype=torch.float32, device=device)
-    views, off = {}, 0
+    views, offsets, off = {}, {}, 0
     for p in params:
         n = p.numel()
         chunk = flat[off:off + n]
+        offsets[p] = off
         if p.dim() == 4 and p.data.permute(0, 2, 3, 1).is_contiguous():
             k, c, r, s = p.shape
             views[p] = chunk.view(k, r, s, c).permute(0, 3, 1, 2)
@@ -104,8 +107,9 @@ def flat_grads(params, device):
             views[p] = chunk.view(p.shape)
         else:
             views[p] = grad_like(p)
+            offsets[p] = None                       # not in the arena: reduced on its own at join()
         off += n
-    return views
+    return views, flat, offsets
 
 
 _SIDE_STREAMS = {}
@@ -120,17 +124,28 @@ def side_stream(device):
 
 
 class BackwardCtx:
-    """Gradient arena + the side stream on which weight gradients run.
+    """Gradient arena + the side stream on which weight gradients run + (data parallel) the gradient all-reduce.
 
-    Weight gradients do not feed the rest of the backward chain, so they run on a side HIP stream and fill the gaps
-    (partially filled last rounds, HBM-bound BN passes) of the data-gradient chain on the main stream.  Every tensor a
-    side-stream kernel reads is kept referenced until the streams are joined again."""
+    Weight gradients do not feed the rest of the backward chain, so they run on a side HIP stream.  Every tensor a
+    side-stream kernel reads is kept referenced until the streams are joined again.
 
-    def __init__(self, params, device):
-        self.grads = flat_grads(params, device)
+    Data parallel (`allreduce=True`, set by model.FR_PartialFC.Model on the wrapped encoder): the arena is laid out in
+    parameter order and the backward pass finishes parameters in reverse order, so everything from the first parameter
+    of the block just finished to the end of the arena is final.  `reduce_down_to(param)` averages that tail slice over
+    the ranks IN PLACE with one RCCL all-reduce per >= 32 MB (no bucket copies: the arena is the bucket), issued behind
+    the side stream so it overlaps the rest of the backward pass; join() waits for them.  This replaces torch DDP's
+    reducer (the encoder's DDP wrapper is kept for its constructor broadcast and state_dict prefix, run under no_sync)."""
+
+    MIN_BYTES = 32 << 20
+
+    def __init__(self, params, device, allreduce=False):
+        self.grads, self.flat, self.offsets = flat_grads(params, device)
         self.main = torch.cuda.current_stream()
         self.side = side_stream(device) if _OVERLAP_WGRAD else None
         self.keep = []
+        self.allreduce = bool(allreduce) and dist.is_available() and dist.is_initialized()
+        self.reduced_from = self.flat.numel()          # arena[reduced_from:] has been handed to RCCL
+        self.works = []
 
     def G(self, p):
         return self.grads[p]
@@ -148,11 +163,68 @@ class BackwardCtx:
     def wgrad(self, dy, x, gview, r, s, stride, pad):
         self.on_side(lambda: ops.conv_wgrad(dy, x, gview, r, s, stride, pad), dy, x, gview)
 
+    def _reduce(self, lo, hi):
+        if hi <= lo:
+            return
+        chunk = self.flat[lo:hi]
+        if self.side is not None:                       # behind the weight gradients of this slice AND the main stream
+            self.side.wait_stream(self.main)
+            with torch.cuda.stream(self.side):
+                self.works.append(dist.all_reduce(chunk, op=dist.ReduceOp.AVG, async_op=True))
+        else:
+            self.works.append(dist.all_reduce(chunk, op=dist.ReduceOp.AVG, async_op=True))
+
+    def reduce_down_to(self, param, force=False):
+        """everything from `param` (in parameter order) to the end of the arena is final: hand it to RCCL"""
+        if not self.allreduce:
+            return
+        lo = self.offsets.get(param)
+        if lo is None or lo >= self.reduced_from:
+            return
+        if force or (self.reduced_from - lo) * 4 >= self.MIN_BYTES:
+            self._reduce(lo, self.reduced_from)
+            self.reduced_from = lo
+
     def join(self):
+        if self.allreduce:
+            self._reduce(0, self.reduced_from)
+            self.reduced_from = 0
+            for p, off in self.offsets.items():         # gradients that live outside the arena (unusual layouts)
+                if off is None:
+                    self.works.append(dist.all_reduce(self.grads[p], op=dist.ReduceOp.AVG, async_op=True))
         if self.side is not None:
             self.main.wait_stream(self.side)
-        self.keep = []
+        for w in self.works:
+            w.wait()                                    # current (main) stream waits for the collective
+        self.works, self.keep = [], []
         return self.grads
+
+
+class DataParallel(nn.Module):
+    """Data-parallel wrapper of a frhip backbone with torch DDP's surface (`.module`, 'module.'-prefixed state_dict keys,
+    parameters broadcast from rank 0 at construction) but without its bucketing reducer: the wrapped backbone averages
+    its flat gradient arena in place with RCCL while its backward pass runs (BackwardCtx.reduce_down_to).  Stands where
+    the reference has DistributedDataParallel(encoder, broadcast_buffers=False) (/root/reference/model/FR_PartialFC.py:92-96)."""
+
+    def __init__(self, module, process_group=None):
+        super().__init__()
+        if not hasattr(module, "_backward_impl"):
+            raise TypeError("DataParallel wraps the frhip backbones (nets.resnet / nets.SwinV2 / nets.AlterNet_SwinV2_FAN)")
+        self.module = module
+        module._frhip_allreduce = True
+        if dist.is_available() and dist.is_initialized():
+            with torch.no_grad():
+                flat = torch.cat([p.data.reshape(-1) for p in module.parameters()] +
+                                 [b.data.reshape(-1).float() for b in module.buffers()])
+                dist.broadcast(flat, 0, group=process_group)          # same start on every rank (DDP does the same)
+                off = 0
+                for t in list(module.parameters()) + list(module.buffers()):
+                    n = t.numel()
+                    t.data.copy_(flat[off:off + n].view(t.shape).to(t.dtype))
+                    off += n
+
+    def forward(self, *args, **kwargs):
+        return self.module(*args, **kwargs)
 
 
 # ------------------------------------------------------------------------------------------------- forward pieces

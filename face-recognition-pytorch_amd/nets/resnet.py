@@ -82,7 +82,7 @@ class ResNet(nn.Module):
         return emb, sv
 
     def _backward_impl(self, sv, d_emb, params):
-        bc = BackwardCtx(params, d_emb.device)
+        bc = BackwardCtx(params, d_emb.device, allreduce=getattr(self, "_frhip_allreduce", False))
         dout = tail_backward(self, sv, d_emb, bc)
         blocks = list(self._blocks())
         part = None
@@ -91,6 +91,7 @@ class ResNet(nn.Module):
             nxt = (sv.blocks[i - 1].y2, sv.blocks[i - 1].st2) if i > 0 else None
             res = basic_block_backward(blocks[i], sv.blocks[i], dout, self.dtype, bc, part2=part, next_bn=nxt)
             dout, part = res if nxt is not None else (res, None)
+            bc.reduce_down_to(blocks[i].conv1.weight)      # data parallel: block i and everything behind it is final
         stem_backward(self, sv, dout, bc)
         return bc.join()
 

@@ -87,3 +87,67 @@ def test_cpu_input_is_refused():
     net, _ = _net("ResNet18", "fp32", 1)
     with pytest.raises(RuntimeError):
         net(torch.zeros(1, 3, 112, 112))
+
+
+def test_data_parallel_gradient_allreduce_covers_the_arena_once(monkeypatch, tmp_path):
+    """Data parallel: the backbone hands tail slices of its flat gradient arena to the all-reduce while the backward pass
+    runs (nets._backbone.BackwardCtx).  With a recording stand-in for dist.all_reduce: every arena element is reduced
+    exactly once, slices come in descending order, and p.grad aliases the arena (so the in-place average IS the gradient)."""
+    import torch.distributed as dist
+    import nets._backbone as BB
+    if not dist.is_initialized():
+        dist.init_process_group("gloo", init_method="file://" + str(tmp_path / "pg"), rank=0, world_size=1)
+    calls = []
+
+    class _Work:
+        def wait(self):
+            return True
+
+    def fake_all_reduce(t, op=None, async_op=False):
+        assert op == dist.ReduceOp.AVG and async_op
+        calls.append((t.data_ptr(), t.numel()))
+        t.mul_(0.5)                                    # pretend the other rank contributed zeros
+        return _Work()
+
+    net, _ = _net("ResNet18", "fp32", 4242)
+    net.train()
+    x = recipe.images(4243, 4).cuda()
+    dy = recipe.normal(4244, (4, 512), 0.05).cuda()
+    net(x).backward(dy)
+    ref = {k: p.grad.clone() for k, p in net.named_parameters()}
+    net.zero_grad(set_to_none=True)
+    for b in net.buffers():                            # same BN statistics path: reset what the first pass changed is not needed for grads
+        pass
+    monkeypatch.setattr(BB.dist, "all_reduce", fake_all_reduce)
+    monkeypatch.setattr(BB.BackwardCtx, "MIN_BYTES", 1 << 20)
+    net._frhip_allreduce = True
+    net(x).backward(dy)
+    total = sum(p.numel() for p in net.parameters())
+    assert sum(n for _, n in calls) == total and len(calls) >= 3
+    ends = [ptr + 4 * n for ptr, n in calls]
+    for (ptr, _), prev_start in zip(calls[1:], [c[0] for c in calls[:-1]]):
+        assert ptr + 4 * [n for q, n in calls if q == ptr][0] == prev_start        # contiguous, descending
+    lo = min(ptr for ptr, _ in calls)
+    for k, p in net.named_parameters():
+        assert lo <= p.grad.data_ptr() < lo + 4 * total, k
+        np.testing.assert_allclose(p.grad.cpu().numpy(), 0.5 * ref[k].cpu().numpy(), rtol=1e-3, atol=1e-5 * max(1.0, ref[k].abs().max().item()), err_msg=k)
+
+
+def test_data_parallel_wrapper_has_ddp_surface(tmp_path):
+    """nets._backbone.DataParallel stands where the reference has DistributedDataParallel: `.module`, 'module.'-prefixed
+    state_dict keys (the reference's checkpoints, model/FR_PartialFC.py:76-90), parameters broadcast from rank 0"""
+    import torch.distributed as dist
+    import nets._backbone as BB
+    if not dist.is_initialized():
+        dist.init_process_group("gloo", init_method="file://" + str(tmp_path / "pg"), rank=0, world_size=1)
+    net, sd = _net("ResNet18", "fp32", 4242)
+    dp = BB.DataParallel(net)
+    assert dp.module is net and net._frhip_allreduce
+    assert set(dp.state_dict().keys()) == {"module." + k for k in net.state_dict().keys()}
+    for k, v in net.state_dict().items():
+        assert torch.equal(v.cpu(), sd[k].to(v.dtype)), k          # the broadcast round trip left every value intact
+    dp.eval()
+    with torch.no_grad():
+        assert dp(recipe.images(1, 2).cuda()).shape == (2, 512)
+    with pytest.raises(TypeError):
+        BB.DataParallel(torch.nn.Linear(2, 2))

@@ -16,7 +16,7 @@ import torch.multiprocessing as mp
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, ws, path, name, ret):
+def _worker(rank, ws, path, name, ret, use_prepare=False):
     for p in (ROOT, os.path.join(ROOT, "face-recognition-pytorch_amd"), os.path.join(ROOT, "tests")):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -41,7 +41,10 @@ def _worker(rank, ws, path, name, ret):
         lab[0] = 3
         lab[1] = 3
     torch.manual_seed(1000 + rank)
-    loss = pfc(emb, lab.clone(), opt)
+    lab_in = lab.clone()
+    if use_prepare:                 # the sync-free route: labels gathered and positives counted before the step's forward
+        pfc.prepare(lab_in)
+    loss = pfc(emb, lab_in, opt)
     loss.backward()
     idx = pfc.weight_index if rate < 1 else torch.arange(pfc.num_local)
     ok_opt = opt.param_groups[-1]["params"][0] is pfc.weight_activated
@@ -53,14 +56,15 @@ def _worker(rank, ws, path, name, ret):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("name", ["head_ws2_rate10", "head_ws2_rate03", "head_ws8_rate01"])
-def test_partial_fc_host_logic_multi_rank(golden, name):
+@pytest.mark.parametrize("name,use_prepare", [("head_ws2_rate10", False), ("head_ws2_rate03", False), ("head_ws8_rate01", False),
+                                              ("head_ws2_rate03", True), ("head_ws2_rate10", True)])
+def test_partial_fc_host_logic_multi_rank(golden, name, use_prepare):
     g = golden(name)
     ws = int(g["ws"])
     with tempfile.TemporaryDirectory() as td:
         mgr = mp.Manager()
         ret = mgr.dict()
-        mp.spawn(_worker, args=(ws, os.path.join(td, "pg"), name, ret), nprocs=ws, join=True)
+        mp.spawn(_worker, args=(ws, os.path.join(td, "pg"), name, ret, use_prepare), nprocs=ws, join=True)
         for r in range(ws):
             out = ret[r]
             assert out["class_start"] == int(g["r%d_class_start" % r])
