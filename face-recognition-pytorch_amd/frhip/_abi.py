@@ -57,6 +57,9 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise FrhipError("libfrhip.so is missing (%s): run `python -c 'import __graft_entry__ as g; g.build()'`; "
                              "there is no CPU fallback for the HIP path" % LIB_PATH)
+        # torch first: its wheel bundles the HIP runtime (libamdhip64); loading libfrhip.so before it would bind this
+        # library to the system copy and the process would end up with two runtimes, one of which sees no device
+        import torch  # noqa: F401
         handle = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in parse_header().items():
             fn = getattr(handle, name)          # AttributeError if the library lacks a declared symbol
