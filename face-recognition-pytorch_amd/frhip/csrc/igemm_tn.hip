@@ -606,12 +606,10 @@ void tn_taps9_kernel(TnGeom g, const void* __restrict__ p_ptr, const void* __res
             if (it + 1 < nks) step(std::integral_constant<int, 1>{}, it + 1);
         }
     }
-    // ---- epilogue, tap by tap: (COF*16 x CIF*16) per wave -> LDS -> row-wise fp32 stores / atomic adds into dw[co][tap][ci]
-    constexpr int EP = Cfg::EP, WCOT = COF * 16, WCIT = CIF * 16;
-    char* mine = smem + wave * WCOT * EP;
+    // ---- epilogue: accumulators straight from registers.  D layout: lane holds rows co = a*16 + 4*(lane>>4) + e, column
+    //      ci = b*16 + (lane & 15): 16 lanes write one 64-byte run of dw[co][tap][ci..] -- exactly what staging the wave's
+    //      16-ci-wide tile through LDS produced, minus eighteen barriers per workgroup.
     const int fi = lane & 15;
-    constexpr int RPI = 64 / WCIT;                    // rows per wave instruction
-    const int col = lane % WCIT, rsub = lane / WCIT;
     if constexpr (FRHIP_ABL & 16) {
         if (g.M >= 0) {
 #pragma unroll
@@ -623,29 +621,25 @@ void tn_taps9_kernel(TnGeom g, const void* __restrict__ p_ptr, const void* __res
             return;
         }
     }
+    float* dst = out + (g.slab_stride ? (size_t)blockIdx.y * g.slab_stride : 0);
 #pragma unroll
-    for (int t = 0; t < 9; ++t) {
-        __syncthreads();
+    for (int a = 0; a < COF; ++a)
 #pragma unroll
-        for (int a = 0; a < COF; ++a)
+        for (int e = 0; e < 4; ++e) {
+            const int co = co0 + wco * COF * 16 + a * 16 + 4 * fg + e;
+            if (co >= g.Kc) continue;
 #pragma unroll
-            for (int b = 0; b < CIF; ++b)
+            for (int b = 0; b < CIF; ++b) {
+                const int ci = ci0 + wci * CIF * 16 + b * 16 + fi;
+                if (ci >= g.C) continue;
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    *reinterpret_cast<float*>(mine + (a * 16 + 4 * fg + e) * EP + (b * 16 + fi) * 4) = acc[t][a][b][e];
-        __syncthreads();
-        const int ci = ci0 + wci * WCIT + col;
-        for (int it = 0; it < WCOT / RPI; ++it) {
-            const int row = it * RPI + rsub;
-            const int co = co0 + wco * WCOT + row;
-            if (co < g.Kc && ci < g.C) {
-                const float v = *reinterpret_cast<const float*>(mine + row * EP + col * 4);
-                const size_t idx = ((size_t)co * 9 + t) * g.C + ci;
-                if (g.slab_stride) out[(size_t)blockIdx.y * g.slab_stride + idx] = v;
-                else atomicAdd(out + idx, v);
+                for (int t = 0; t < 9; ++t) {
+                    const size_t idx = ((size_t)co * 9 + t) * g.C + ci;
+                    if (g.slab_stride) dst[idx] = acc[t][a][b][e];
+                    else atomicAdd(dst + idx, acc[t][a][b][e]);
+                }
             }
         }
-    }
 }
 
 static int g_tn_taps9 = 1;
