@@ -229,21 +229,22 @@ def main():
             traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
         achieved = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         line = {
-            "metric": "train imgs/sec IR-50-layout ResNet50 + ArcFace/PartialFC head, 112x112",
+            "metric": "train imgs/sec IR-50-layout ResNet50 + ArcFace/PartialFC head, 112x112" if args.network == "ResNet50"
+                      else "train imgs/sec %s + ArcFace/PartialFC head, 112x112" % args.network,
             "value": round(args.batch * world * args.steps / dt, 1), "unit": "imgs/sec", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "BASELINE cfg %d: %s+%s, %d ids, B=%d/GPU, SGD "
                                    "mom 0.9 wd 5e-4, s=30 m=0.35" % ((2 if world == 1 else 3) if args.network == "ResNet50" else 4,
                                                                      "ResNet50([3,4,14,4] BasicBlock)" if args.network == "ResNet50" else args.network,
-                                                                     "ArcFace (PartialFC rate 1.0)" if world == 1 else "PartialFC rate 0.1",
+                                                                     "ArcFace (PartialFC rate 1.0)" if conf.sample_rate >= 1 else "ArcFace (PartialFC rate %.1f)" % conf.sample_rate,
                                                                      args.classes, args.batch),
                        "global_batch": args.batch * world, "parallelism": "dp%d+class-shard%d" % (world, world),
                        "launch": "hip-graph" if use_graph else "eager"},
             "final_loss": round(loss, 4),
             "roofline": {"bound": "mfma", "achieved": round(achieved, 1), "peak": BF16_DENSE_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(achieved / BF16_DENSE_PEAK_TFLOPS, 4), "traffic": traffic,
-                         "kernel": "frhip::nt_kernel<bf16> (conv forward + data-gradient implicit GEMM)",
+                         "kernel": "frhip::halo_kernel<bf16> + frhip::nt_kernel<bf16> (conv forward + data-gradient implicit GEMM)",
                          "launches": n, "avg_launch_us": round(ms * 1e3 / max(n, 1), 2),
                          "flop_per_launch": round(fl / max(n, 1))},
         }
