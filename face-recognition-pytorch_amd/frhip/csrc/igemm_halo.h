@@ -150,24 +150,38 @@ struct HaloMainloop {
         //      second half of t starts prefetching them, and it orders the last reads of ring slot (t+2)%3 / of the
         //      other halo buffer (first half of t-1 at the latest) before the DMA that overwrites them (top of t+1).
         Frag xf[2][MT], wf[2][4];
+        // LDS byte addresses (not pointers: the stage / buffer base then folds into the DS immediate).  Address arithmetic is
+        // kept off the VALU: it competes with the MFMAs for issue slots (PMC: 2.25 VALU per MFMA before, MFMA pipe 63 %
+        // busy).  Weights: both K-half variants live in registers.  Pixels: the packed offset is unpacked by ONE opaque
+        // instruction when the first K half of a tap is read and kept for the second half (address ^ 64).
+        typedef const __attribute__((address_space(3))) char* lds_cp;
+        typedef const __attribute__((address_space(3))) Frag* lds_fp;
+        // The kernel has no static __shared__ data, so its dynamic LDS starts at byte 0 and offsets ARE addresses (adding the
+        // symbolic base would cost one VALU add per read); checked once.
+        if ((uint32_t)(uintptr_t)LDS_ADDR(smem) != 0u) __builtin_trap();
+        const uint32_t wa0 = (uint32_t)wa, wa1 = (uint32_t)(wa ^ 64);
+        uint32_t xcur[MT];
         auto load_frags = [&](auto set_c, auto h_c, auto hb_c, auto slot_c, auto tap_c) {
             constexpr int SET = decltype(set_c)::value, HH = decltype(h_c)::value, HB = decltype(hb_c)::value,
                           SLOT = decltype(slot_c)::value, TAP = decltype(tap_c)::value;
-            const char* hbase = smem + HB * Tile::HALO_BYTES;
-            const char* wbase = smem + Tile::W_OFF + SLOT * Tile::WBUF_BYTES;
             // second K half = chunk index ^ 4  <=>  byte offset ^ 64 (the zero row is 128 B, so ^64 stays inside it)
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 if constexpr (FRHIP_ABL & 4) asm volatile("" : "=v"(wf[SET][t]));
-                else wf[SET][t] = *reinterpret_cast<const Frag*>(wbase + ((wa + t * 16 * NT_ROWB) ^ (HH << 6)));
+                else wf[SET][t] = *(lds_fp)((lds_cp)(uintptr_t)(HH ? wa1 : wa0) + (Tile::W_OFF + SLOT * Tile::WBUF_BYTES + t * 16 * NT_ROWB));
             }
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 if constexpr (FRHIP_ABL & 4) asm volatile("" : "=v"(xf[SET][mt]));
                 else {
-                    uint32_t pk = xa[TAP][mt >> 1];
-                    asm volatile("" : "+v"(pk));          // keep the unpack inside the loop (hoisting it costs 72 VGPRs)
-                    xf[SET][mt] = *reinterpret_cast<const Frag*>(hbase + (((mt & 1) ? (pk >> 16) : (pk & 0xffffu)) ^ (uint32_t)(HH << 6)));
+                    if constexpr (HH == 0) {
+                        // one instruction, opaque to the optimiser (it would otherwise hoist 72 unpacked copies out of the loop)
+                        if (mt & 1) asm volatile("v_lshrrev_b32 %0, 16, %1" : "=v"(xcur[mt]) : "v"(xa[TAP][mt >> 1]));
+                        else asm volatile("v_and_b32 %0, 0xffff, %1" : "=v"(xcur[mt]) : "v"(xa[TAP][mt >> 1]));
+                        xf[SET][mt] = *(lds_fp)((lds_cp)(uintptr_t)xcur[mt] + HB * Tile::HALO_BYTES);
+                    } else {
+                        xf[SET][mt] = *(lds_fp)((lds_cp)(uintptr_t)(xcur[mt] ^ 64u) + HB * Tile::HALO_BYTES);
+                    }
                 }
             }
         };
