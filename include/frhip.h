@@ -229,6 +229,14 @@ int frhip_stem_bwd_wgrad(int dtype, const float* x, const void* wp, const void* 
 typedef struct { const float* w; void* wc; void* wt; int32_t k, rs, c, tile_begin; } frhip_wprep;
 int frhip_prep_conv_weights(int dtype, const frhip_wprep* table, int ntensors, int ntiles, frhip_stream_t stream);
 
+/* ---- device input pipeline: Resize -> HorizontalFlip -> Normalize(0.5,0.5) -> CoarseDropout -> CHW fp32 of the reference's
+ * albumentations chain (utils/data_partial.py:134-164) in one kernel.  in: uint8 [b,hin,win,3] (HWC, device);
+ * out: fp32 [b,3,size,size]; flip: int32 [b] (may be NULL); holes: int32 [b][nholes][4] = x1,y1,x2,y2 in output
+ * coordinates, exclusive upper bounds, x2 <= x1 marks an unused slot (may be NULL when nholes == 0).  Dropped pixels are 0
+ * (CoarseDropout fill_value 0 after Normalize).  Resize = OpenCV INTER_LINEAR (8-bit fixed point), identity when sizes match. */
+int frhip_augment_u8(const uint8_t* in, float* out, const int32_t* flip, const int32_t* holes, int nholes,
+                     int b, int hin, int win, int size, frhip_stream_t stream);
+
 /* ---- optimizer: torch.optim.SGD(momentum, weight_decay).step() + torch.nn.utils.clip_grad_norm_ of the training step
  * (model/FR_PartialFC.py:153-160, :181-190) as multi-tensor kernels.  A chunk is a run of at most
  * FRHIP_SGD_CHUNK consecutive fp32 elements of one parameter (p), its gradient (g) and its momentum buffer (m, may be

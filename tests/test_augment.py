@@ -1,0 +1,74 @@
+"""Device input pipeline: frhip_augment_u8 / utils.device_transform.DeviceTransform against the
+numpy restatement oracle/augment_ref.py (parity with albumentations / OpenCV is unpinned: neither is installed here)."""
+import os
+import sys
+import types
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [p for p in (ROOT, os.path.join(ROOT, "face-recognition-pytorch_amd")) if p not in sys.path]
+from oracle import augment_ref  # noqa: E402
+
+
+def _conf(size=112, aug=("RandomHorizontalFlip", "RandomErasing")):
+    return types.SimpleNamespace(img_size=size, data_augmentation=list(aug),
+                                 img_augmenation=types.SimpleNamespace(erase_p=0.5, erase_min_holes=1, erase_max_holes=2,
+                                                                       erase_max_h=20, erase_max_w=20))
+
+
+def test_oracle_identity_resize_flip_normalize_dropout():
+    rng = np.random.default_rng(0)
+    img = rng.integers(0, 256, (2, 112, 112, 3), dtype=np.uint8)
+    out = augment_ref.augment(img, 112, flip=[0, 1], holes=np.array([[[3, 5, 10, 9]], [[0, 0, 0, 0]]]))
+    want0 = (img[0].astype(np.float32) - 127.5) / 127.5
+    want0[5:9, 3:10] = 0
+    np.testing.assert_array_equal(out[0], want0.transpose(2, 0, 1))
+    np.testing.assert_array_equal(out[1], ((img[1][:, ::-1].astype(np.float32) - 127.5) / 127.5).transpose(2, 0, 1))
+    assert out.min() >= -1 and out.max() <= 1
+
+
+def test_oracle_resize_properties():
+    """constant images stay constant, integer down-scaling by 2 averages 2x2 blocks (+ rounding), sizes are right"""
+    const = np.full((30, 50, 3), 77, dtype=np.uint8)
+    assert (augment_ref.resize_linear_u8(const, 112) == 77).all()
+    rng = np.random.default_rng(1)
+    img = rng.integers(0, 256, (224, 224, 3), dtype=np.uint8)
+    got = augment_ref.resize_linear_u8(img, 112).astype(np.int64)
+    blk = img.reshape(112, 2, 112, 2, 3).astype(np.int64).sum((1, 3))
+    assert np.abs(got - (blk + 2) // 4).max() <= 1
+
+
+def test_device_transform_draws_follow_the_configuration():
+    from utils.device_transform import DeviceTransform
+    t = DeviceTransform(_conf(), seed=3)
+    flip, holes = t.draw(64)
+    assert flip.shape == (64,) and set(np.unique(flip)) <= {0, 1} and 10 < flip.sum() < 54
+    assert holes.shape == (64, 2, 4)
+    used = holes[..., 2] > holes[..., 0]
+    assert 0 < used.any(1).sum() < 64                                   # erase_p = 0.5
+    assert (holes[used][:, 2] - holes[used][:, 0]).max() <= 20 and (holes[used][:, 3] - holes[used][:, 1]).max() <= 20
+    assert (holes[used][:, 2] <= 112).all() and (holes[used][:, 3] <= 112).all()
+    ev = DeviceTransform(_conf(), train=False)
+    assert ev.draw(4) == (None, None)
+    with pytest.raises(RuntimeError):
+        t.apply(torch.zeros((1, 112, 112, 3), dtype=torch.uint8))       # CPU tensors are refused: no fallback
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(5, 112, 112, 112), (3, 150, 130, 112), (2, 64, 96, 112), (4, 250, 250, 192)])
+def test_augment_kernel_matches_oracle(shape):
+    from utils.device_transform import DeviceTransform
+    b, h, w, size = shape
+    rng = np.random.default_rng(7)
+    img = rng.integers(0, 256, (b, h, w, 3), dtype=np.uint8)
+    t = DeviceTransform(_conf(size), seed=11)
+    flip, holes = t.draw(b)
+    flip[0], holes[0, 0] = 1, (2, 3, 30, 21)                            # make sure both features occur
+    got = t.apply(torch.from_numpy(img).cuda(), flip, holes).cpu().numpy()
+    want = augment_ref.augment(img, size, flip, holes)
+    np.testing.assert_array_equal(got, want)                            # integer resize + one float op: bit-exact
+    plain = DeviceTransform(_conf(size), train=False)
+    np.testing.assert_array_equal(plain(torch.from_numpy(img).cuda()).cpu().numpy(), augment_ref.augment(img, size))
