@@ -62,13 +62,13 @@ class ConvMeter:
                 self.calls.append((self._fwd, (x, w, stride, pad, want_stats), 2.0 * n * ho * wo * k * r * s * c))
             return self._fwd(x, w, stride, pad, want_stats)
 
-        def conv_dgrad(dy, wt, x_shape, r, s, stride, pad, residual=None, out=None, bnred=None):
+        def conv_dgrad(dy, wt, x_shape, r, s, stride, pad, residual=None, out=None, bnred=None, residual_stride=1):
             if self.collect and dy.dtype == torch.bfloat16:
                 n, ho, wo, k = dy.shape
                 # the probe re-issues the launch as the step does (incl. the fused BN-backward reduction in its epilogue)
-                self.calls.append((self._dgrad, (dy, wt, tuple(x_shape), r, s, stride, pad, residual, None, bnred),
+                self.calls.append((self._dgrad, (dy, wt, tuple(x_shape), r, s, stride, pad, residual, None, bnred, residual_stride),
                                    2.0 * n * ho * wo * k * r * s * x_shape[3]))    # algorithmic MACs = forward's
-            return self._dgrad(dy, wt, x_shape, r, s, stride, pad, residual, out, bnred)
+            return self._dgrad(dy, wt, x_shape, r, s, stride, pad, residual, out, bnred, residual_stride)
 
         ops.conv_fwd, ops.conv_dgrad = conv_fwd, conv_dgrad
 

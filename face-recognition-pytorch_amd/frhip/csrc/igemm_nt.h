@@ -41,6 +41,10 @@ struct EpiBnRed {
     const float* invstd;
     const float* mscale;
     const float* mshift;
+    // residual layout: res_w == 0: dense, same shape as the output.  res_w > 0: the output is [n][res_h][res_w][c] and the
+    // residual is the COMPACT gradient of a stride-2 1x1 shortcut, [n][(res_h+1)/2][(res_w+1)/2][c]: it lands on the even
+    // pixels only (everything else receives nothing), so the zero-stuffed full-size tensor is never built.
+    int res_h, res_w;
 };
 
 // WM x WN waves; each wave owns (MT*16) pixel rows x 64 channels (4 MFMA tiles wide).
@@ -227,10 +231,21 @@ struct EpiOperands {
     Vec16<T> rv[PRE ? ITERS : 1], yv[PRE ? ITERS : 1];
     const T* r; const T* y;
     int M, Nout, m0, n, rsub;
+    int res_h, res_w;
+    // element index of residual row for output row m, or -1 when that pixel receives no residual
+    __device__ __forceinline__ long long res_index(int m) const {
+        if (res_w == 0) return (long long)m * Nout + n;
+        const int hw = res_h * res_w;
+        const int img = m / hw, rem = m - img * hw;
+        const int h = rem / res_w, w = rem - h * res_w;
+        if ((h | w) & 1) return -1;
+        const int hc = (res_h + 1) >> 1, wc = (res_w + 1) >> 1;
+        return ((long long)(img * hc + (h >> 1)) * wc + (w >> 1)) * Nout + n;
+    }
     __device__ __forceinline__ void fetch(const void* __restrict__ res, const void* __restrict__ ybn, int M_, int Nout_,
-                                          int m0_, int n0) {
+                                          int m0_, int n0, int res_h_ = 0, int res_w_ = 0) {
         const int lane = lane_id();
-        M = M_; Nout = Nout_; m0 = m0_;
+        M = M_; Nout = Nout_; m0 = m0_; res_h = res_h_; res_w = res_w_;
         n = n0 + (lane % LPR) * EPV; rsub = lane / LPR;
         r = reinterpret_cast<const T*>(res);
         y = reinterpret_cast<const T*>(ybn);
@@ -240,7 +255,14 @@ struct EpiOperands {
                 const int m = m0 + it * RPI + rsub;
                 const bool ok = m < M && n < Nout;
                 const size_t idx = (size_t)m * Nout + n;
-                if (r && ok) rv[it] = *reinterpret_cast<const Vec16<T>*>(r + idx);
+                if (r && ok) {
+                    const long long ri = res_index(m);
+                    if (ri >= 0) rv[it] = *reinterpret_cast<const Vec16<T>*>(r + ri);
+                    else {
+#pragma unroll
+                        for (int e = 0; e < EPV; ++e) rv[it].set(e, 0.f);
+                    }
+                }
                 if (y && ok) yv[it] = *reinterpret_cast<const Vec16<T>*>(y + idx);
             }
         }
@@ -248,7 +270,13 @@ struct EpiOperands {
     // valid for rows inside the tensor only
     __device__ __forceinline__ Vec16<T> res_row(int it) const {
         if constexpr (PRE) return rv[it];
-        else return *reinterpret_cast<const Vec16<T>*>(r + (size_t)(m0 + it * RPI + rsub) * Nout + n);
+        else {
+            const long long ri = res_index(m0 + it * RPI + rsub);
+            Vec16<T> z;
+#pragma unroll
+            for (int e = 0; e < EPV; ++e) z.set(e, 0.f);
+            return ri >= 0 ? *reinterpret_cast<const Vec16<T>*>(r + ri) : z;
+        }
     }
     __device__ __forceinline__ Vec16<T> y_row(int it) const {
         if constexpr (PRE) return yv[it];

@@ -35,7 +35,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void nt_kernel(NtGeom 
 
     if constexpr (EPI == EPI_STORE) {
         EpiOperands<T, WROWS> eo;
-        eo.fetch(res, stats ? br.y : nullptr, g.M, g.Nout, m0, n0);
+        eo.fetch(res, stats ? br.y : nullptr, g.M, g.Nout, m0, n0, br.res_h, br.res_w);
         const char* mine = ml.template stage_out<T>(smem);
         nt_epilogue_store<T, WM, WN, WROWS, THREADS, Tile::BN>(mine, Tile::template stage_pitch<T>(), smem, g.M, g.Nout, out,
                                                                res != nullptr, stats, br, eo, mtile, ntile, m0, n0);
@@ -84,7 +84,7 @@ static int nt_pick_tile(int dtype, const NtGeom& g) {
     return 1;
 }
 
-static const EpiBnRed NO_BNRED = {nullptr, nullptr, nullptr, nullptr, nullptr};
+static const EpiBnRed NO_BNRED = {nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0};
 
 static int nt_dispatch(int dtype, const NtGeom& g, const void* a, const void* b, void* out, const void* res,
                        float* stats, const EpiBnRed& br, int splits, bool atomic, hipStream_t stream) {
@@ -192,6 +192,21 @@ extern "C" int frhip_dgrad_stat_rows(int dtype, int n, int h, int wd, int c, int
     return (m + bm - 1) / bm;
 }
 
+extern "C" int frhip_conv_dgrad_fused(int dtype, const void* dy, const void* wt, void* dx, const void* residual,
+                                      int residual_stride, const void* y_bn, const float* mean, const float* invstd,
+                                      const float* mask_scale, const float* mask_shift, float* stats_partial, int n, int h,
+                                      int wd, int c, int k, int r, int s, int stride, int pad, hipStream_t stream) {
+    if (residual_stride != 1 && residual_stride != 2) { set_error("frhip_conv_dgrad_fused: residual_stride must be 1 or 2"); return FRHIP_EINVAL; }
+    if (y_bn && (!mean || !invstd || !stats_partial || (mask_scale && !mask_shift))) {
+        set_error("frhip_conv_dgrad_fused: y_bn needs mean, invstd and stats_partial");
+        return FRHIP_EINVAL;
+    }
+    EpiBnRed br = {y_bn, mean, invstd, mask_scale, mask_shift, 0, 0};
+    if (residual && residual_stride == 2) { br.res_h = h; br.res_w = wd; }
+    return dgrad_run(dtype, dy, wt, dx, residual, y_bn ? stats_partial : nullptr, br, n, h, wd, c, k, r, s, stride, pad, stream,
+                     "frhip_conv_dgrad_fused");
+}
+
 extern "C" int frhip_conv_dgrad_bnred(int dtype, const void* dy, const void* wt, void* dx, const void* residual,
                                       const void* y_bn, const float* mean, const float* invstd, const float* mask_scale,
                                       const float* mask_shift, float* stats_partial, int n, int h, int wd, int c, int k,
@@ -200,9 +215,8 @@ extern "C" int frhip_conv_dgrad_bnred(int dtype, const void* dy, const void* wt,
         set_error("frhip_conv_dgrad_bnred: y_bn, mean, invstd and stats_partial are required");
         return FRHIP_EINVAL;
     }
-    const EpiBnRed br = {y_bn, mean, invstd, mask_scale, mask_shift};
-    return dgrad_run(dtype, dy, wt, dx, residual, stats_partial, br, n, h, wd, c, k, r, s, stride, pad, stream,
-                     "frhip_conv_dgrad_bnred");
+    return frhip_conv_dgrad_fused(dtype, dy, wt, dx, residual, 1, y_bn, mean, invstd, mask_scale, mask_shift, stats_partial,
+                                  n, h, wd, c, k, r, s, stride, pad, stream);
 }
 
 extern "C" int frhip_gemm_nt(int dtype, const void* a, const void* b, void* out, int m, int n, int k,

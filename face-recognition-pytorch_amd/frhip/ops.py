@@ -52,27 +52,37 @@ def conv_fwd(x, w, stride, pad, want_stats=True):
     return y, part
 
 
-def conv_dgrad(dy, wt, x_shape, r, s, stride, pad, residual=None, out=None, bnred=None):
+def conv_dgrad(dy, wt, x_shape, r, s, stride, pad, residual=None, out=None, bnred=None, residual_stride=1):
     """dy [N,Ho,Wo,K], wt [C,R,S,K] -> dx [N,H,W,C] (+ residual).
 
+    residual_stride=2: `residual` is the compact [N,(H+1)/2,(W+1)/2,C] gradient of a stride-2 1x1 shortcut, added on the
+    even pixels only.
     bnred=(y_bn, st, relu_mask): dx is the upstream gradient of a BatchNorm with saved input y_bn and batch state st;
     the BN-backward partial sums come out of the epilogue and (dx, partial) is returned -- pass partial to bn_backward."""
     n, h, wd, c = x_shape
     k = dy.shape[3]
     dx = out if out is not None else torch.empty(x_shape, dtype=dy.dtype, device=dy.device)
-    if bnred is None:
+    if residual is not None:
+        want = (n, h, wd, c) if residual_stride == 1 else (n, (h + 1) // 2, (wd + 1) // 2, c)
+        if tuple(residual.shape) != want or residual.dtype != dy.dtype:
+            raise ValueError("conv_dgrad: residual must be %s %s" % (want, dy.dtype))
+    if bnred is None and residual_stride == 1:
         check(lib().frhip_conv_dgrad(dt_of(dy), _p(dy), _p(wt), _p(dx), _p(residual), n, h, wd, c, k, r, s, stride, pad, _s()),
               "frhip_conv_dgrad")
         return dx
-    y_bn, st, relu_mask = bnred
-    if tuple(y_bn.shape) != tuple(x_shape) or y_bn.dtype != dy.dtype:
-        raise ValueError("conv_dgrad(bnred): y_bn must have the shape and dtype of dx")
-    rows = lib().frhip_dgrad_stat_rows(dt_of(dy), n, h, wd, c, k, r, s, stride, pad)
-    part = torch.empty((rows, 2, c), dtype=torch.float32, device=dy.device)
-    check(lib().frhip_conv_dgrad_bnred(dt_of(dy), _p(dy), _p(wt), _p(dx), _p(residual), _p(y_bn), _p(st.mean), _p(st.invstd),
+    part = y_bn = st = None
+    relu_mask = False
+    if bnred is not None:
+        y_bn, st, relu_mask = bnred
+        if tuple(y_bn.shape) != tuple(x_shape) or y_bn.dtype != dy.dtype:
+            raise ValueError("conv_dgrad(bnred): y_bn must have the shape and dtype of dx")
+        rows = lib().frhip_dgrad_stat_rows(dt_of(dy), n, h, wd, c, k, r, s, stride, pad)
+        part = torch.empty((rows, 2, c), dtype=torch.float32, device=dy.device)
+    check(lib().frhip_conv_dgrad_fused(dt_of(dy), _p(dy), _p(wt), _p(dx), _p(residual), residual_stride, _p(y_bn),
+                                       _p(st.mean) if st else None, _p(st.invstd) if st else None,
                                        _p(st.scale) if relu_mask else None, _p(st.shift) if relu_mask else None, _p(part),
-                                       n, h, wd, c, k, r, s, stride, pad, _s()), "frhip_conv_dgrad_bnred")
-    return dx, part
+                                       n, h, wd, c, k, r, s, stride, pad, _s()), "frhip_conv_dgrad_fused")
+    return dx if bnred is None else (dx, part)
 
 
 _WORKSPACES = {}

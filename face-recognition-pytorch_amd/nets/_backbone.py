@@ -335,12 +335,17 @@ def basic_block_backward(blk, s, dout, dt, bc, part2=None, next_bn=None):
     the epilogue of conv1's data-gradient and (dx, partial) is returned instead of dx."""
     G = bc.G
     dy2 = ops.bn_backward(dout, s.y2, s.st2, blk.bn2.weight.data, G(blk.bn2.weight), G(blk.bn2.bias), part=part2)
-    shortcut = dout
+    shortcut, sc_stride = dout, 1
     if blk.downsample is not None:
         dconv, dbn = blk.downsample[0], blk.downsample[1]
         dyd = ops.bn_backward(dout, s.yd, s.std, dbn.weight.data, G(dbn.weight), G(dbn.bias))
         wdt = s.wdt if getattr(s, "wdt", None) is not None else ops.pack_wt(dconv.physical(), dt)
-        shortcut = ops.conv_dgrad(dyd, wdt, s.x.shape, 1, 1, dconv.stride, 0)
+        if dconv.stride == 2:
+            # a stride-2 1x1 conv only touches the even pixels: its data gradient is a plain GEMM on the compact grid, and
+            # conv1's data-gradient epilogue adds it there (no zero-stuffed [N,H,W,C] tensor, 4x fewer rows)
+            shortcut, sc_stride = ops.conv_dgrad(dyd, wdt, dyd.shape[:3] + (s.x.shape[3],), 1, 1, 1, 0), 2
+        else:
+            shortcut = ops.conv_dgrad(dyd, wdt, s.x.shape, 1, 1, dconv.stride, 0)
         bc.wgrad(dyd, s.x, phys_grad(G(dconv.weight)), 1, 1, dconv.stride, 0)
     w2t = s.w2t if getattr(s, "w2t", None) is not None else ops.pack_wt(blk.conv2.physical(), dt)
     # the BN1 (+ReLU) backward reduction over (da1, y1) rides in the epilogue of conv2's data-gradient
@@ -350,9 +355,10 @@ def basic_block_backward(blk, s, dout, dt, bc, part2=None, next_bn=None):
                           part=part1)
     w1t = s.w1t if getattr(s, "w1t", None) is not None else ops.pack_wt(blk.conv1.physical(), dt)
     if next_bn is not None:
-        dx = ops.conv_dgrad(dy1, w1t, s.x.shape, 3, 3, 1, 1, residual=shortcut, bnred=(next_bn[0], next_bn[1], False))
+        dx = ops.conv_dgrad(dy1, w1t, s.x.shape, 3, 3, 1, 1, residual=shortcut, bnred=(next_bn[0], next_bn[1], False),
+                            residual_stride=sc_stride)
     else:
-        dx = ops.conv_dgrad(dy1, w1t, s.x.shape, 3, 3, 1, 1, residual=shortcut)
+        dx = ops.conv_dgrad(dy1, w1t, s.x.shape, 3, 3, 1, 1, residual=shortcut, residual_stride=sc_stride)
     bc.wgrad(dy1, s.x, phys_grad(G(blk.conv1.weight)), 3, 3, 1, 1)
     return dx
 

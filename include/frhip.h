@@ -75,6 +75,13 @@ int frhip_conv_dgrad_bnred(int dtype, const void* dy, const void* wt, void* dx, 
                            const void* y_bn, const float* mean, const float* invstd, const float* mask_scale,
                            const float* mask_shift, float* stats_partial, int n, int h, int wd, int c, int k,
                            int r, int s, int stride, int pad, frhip_stream_t stream);
+/* the general form: residual_stride 1 = dense residual [n,h,w,c]; 2 = residual is the COMPACT gradient of a stride-2 1x1
+ * shortcut, [n,(h+1)/2,(w+1)/2,c], added on the even pixels only (the downsample branch of nets/resnet.py:96-101: its
+ * zero-stuffed full-size gradient is never built).  y_bn == NULL: no BatchNorm reduction (stats_partial ignored). */
+int frhip_conv_dgrad_fused(int dtype, const void* dy, const void* wt, void* dx, const void* residual, int residual_stride,
+                           const void* y_bn, const float* mean, const float* invstd, const float* mask_scale,
+                           const float* mask_shift, float* stats_partial, int n, int h, int wd, int c, int k,
+                           int r, int s, int stride, int pad, frhip_stream_t stream);
 /* dw[k,r,s,c] (fp32, caller-zeroed) += sum over output pixels dy * x.  autograd of nn.Conv2d w.r.t. weight.
  * splits <= 0: library picks the split-K factor.  workspace (may be NULL): caller-owned scratch used by THIS call only
  * (one per stream); when splits * sizeof(dw) fits, each K split stores a private slab with plain stores and one reduce

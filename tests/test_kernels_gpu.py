@@ -193,6 +193,28 @@ def test_dgrad_epilogue_bn_backward_reduction(dtype, case):
     np.testing.assert_allclose(a, b, rtol=2e-4, atol=2e-4 * max(1.0, np.abs(b).max()))
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", [(3, 14, 64, 64), (2, 28, 128, 128), (2, 9, 64, 64)])
+def test_dgrad_compact_stride2_residual(dtype, case):
+    """residual_stride=2 (compact gradient of a stride-2 1x1 shortcut, added on the even pixels) == the zero-stuffed dense residual"""
+    ops = _ops()
+    n, h, c, k = case
+    dy = rnd(90, (n, h, h, k)).to(dtype).cuda()
+    wt = ops.pack_wt((rnd(91, (k, 3, 3, c)) * 0.05).cuda(), dtype)
+    hc = (h + 1) // 2
+    compact = rnd(92, (n, hc, hc, c)).to(dtype).cuda()
+    dense = torch.zeros((n, h, h, c), dtype=dtype, device="cuda")
+    dense[:, ::2, ::2, :] = compact
+    y_bn = rnd(93, (n, h, h, c)).to(dtype).cuda()
+    st = ops.bn_finalize(ops.colstats(y_bn.view(-1, c)), n * h * h, torch.ones(c).cuda(), torch.zeros(c).cuda(), None, None)
+    a = ops.conv_dgrad(dy, wt, (n, h, h, c), 3, 3, 1, 1, residual=dense)
+    b = ops.conv_dgrad(dy, wt, (n, h, h, c), 3, 3, 1, 1, residual=compact, residual_stride=2)
+    assert torch.equal(a, b)
+    a2, pa = ops.conv_dgrad(dy, wt, (n, h, h, c), 3, 3, 1, 1, residual=dense, bnred=(y_bn, st, False))
+    b2, pb = ops.conv_dgrad(dy, wt, (n, h, h, c), 3, 3, 1, 1, residual=compact, bnred=(y_bn, st, False), residual_stride=2)
+    assert torch.equal(a2, b2) and torch.equal(a2, a) and torch.equal(pa, pb)
+
+
 def test_linear_shift_wgrad_equals_generic_wgrad():
     """stride-1 weight gradient: contiguous-window kernel (padding resolved at the LDS read) vs the gather kernel"""
     ops = _ops()
