@@ -228,13 +228,24 @@ __global__ __launch_bounds__(EW_THREADS) void bn_bwd_apply_kernel(const T* __res
     }
 }
 
-// out[c] += sum_p partial[p][which][c]
-__global__ void sum_partials_kernel(const float* __restrict__ partial, int nparts, int C, int which, float* __restrict__ out) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+// out[c] += sum_p partial[p][which][c]      (block = 64 channels x 16 lanes; was one thread per channel walking all rows:
+// 199 us per call on the Swin bias gradients with ~1000 partial rows)
+__global__ __launch_bounds__(1024) void sum_partials_kernel(const float* __restrict__ partial, int nparts, int C, int which,
+                                                            float* __restrict__ out) {
+    __shared__ float red[16][64];
+    const int cl = threadIdx.x & 63, pl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
     float acc = 0.f;
-    for (int p = 0; p < nparts; ++p) acc += partial[((size_t)p * 2 + which) * C + c];
-    out[c] += acc;
+    if (c < C)
+        for (int p = pl; p < nparts; p += 16) acc += partial[((size_t)p * 2 + which) * C + c];
+    red[pl][cl] = acc;
+    __syncthreads();
+    if (pl == 0 && c < C) {
+        float a = 0.f;
+#pragma unroll
+        for (int l = 0; l < 16; ++l) a += red[l][cl];
+        out[c] += a;
+    }
 }
 
 // x[rows][C] += bias[C]  (fp32 tail of the backbone: fc bias)
@@ -390,7 +401,7 @@ extern "C" int frhip_bn_bwd_apply(int dtype, const void* dout, const void* y, co
 }
 
 extern "C" int frhip_sum_partials(const float* partial, int nparts, int c, int which, float* out_accum, hipStream_t stream) {
-    hipLaunchKernelGGL(sum_partials_kernel, dim3((c + 63) / 64), dim3(64), 0, stream, partial, nparts, c, which, out_accum);
+    hipLaunchKernelGGL(sum_partials_kernel, dim3((c + 63) / 64), dim3(1024), 0, stream, partial, nparts, c, which, out_accum);
     return check_launch("frhip_sum_partials");
 }
 
