@@ -167,12 +167,18 @@ class BackwardCtx:
         if hi <= lo:
             return
         chunk = self.flat[lo:hi]
+        # RCCL averages in the collective; other backends (gloo in tests) sum and join() scales
+        op = dist.ReduceOp.AVG if dist.get_backend() == "nccl" else dist.ReduceOp.SUM
         if self.side is not None:                       # behind the weight gradients of this slice AND the main stream
             self.side.wait_stream(self.main)
             with torch.cuda.stream(self.side):
-                self.works.append(dist.all_reduce(chunk, op=dist.ReduceOp.AVG, async_op=True))
+                if op != dist.ReduceOp.AVG:
+                    self.side.synchronize()             # host-staged backends read the tensor from the host thread
+                self.works.append(dist.all_reduce(chunk, op=op, async_op=True))
         else:
-            self.works.append(dist.all_reduce(chunk, op=dist.ReduceOp.AVG, async_op=True))
+            if op != dist.ReduceOp.AVG:
+                self.main.synchronize()
+            self.works.append(dist.all_reduce(chunk, op=op, async_op=True))
 
     def reduce_down_to(self, param, force=False):
         """everything from `param` (in parameter order) to the end of the arena is final: hand it to RCCL"""
@@ -191,11 +197,18 @@ class BackwardCtx:
             self.reduced_from = 0
             for p, off in self.offsets.items():         # gradients that live outside the arena (unusual layouts)
                 if off is None:
-                    self.works.append(dist.all_reduce(self.grads[p], op=dist.ReduceOp.AVG, async_op=True))
+                    self.works.append(dist.all_reduce(self.grads[p], async_op=True,
+                                                      op=dist.ReduceOp.AVG if dist.get_backend() == "nccl" else dist.ReduceOp.SUM))
         if self.side is not None:
             self.main.wait_stream(self.side)
         for w in self.works:
             w.wait()                                    # current (main) stream waits for the collective
+        if self.allreduce and self.works and dist.get_backend() != "nccl":
+            ws = dist.get_world_size()
+            self.flat.mul_(1.0 / ws)
+            for p, off in self.offsets.items():
+                if off is None:
+                    self.grads[p].mul_(1.0 / ws)
         self.works, self.keep = [], []
         return self.grads
 
