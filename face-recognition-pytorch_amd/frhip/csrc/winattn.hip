@@ -15,8 +15,10 @@
 namespace frhip {
 
 constexpr int WA_N = 49, WA_D = 32;     // largest window (7x7 tokens); smaller windows (6x6, 3x3) use the same tiles
-constexpr int WA_LD = WA_D + 1;        // padded row of the [49][32] LDS tiles
-constexpr int WA_LM = WA_N + 1;        // padded row of the [49][49] LDS tile
+constexpr int WA_LD = WA_D + 4;        // row pitch of the [49][32] LDS tiles: 16-byte aligned rows -> b128 broadcast reads
+constexpr int WA_LM = WA_N;            // row pitch of the [50][49] LDS tiles: odd, so lane-per-row accesses spread over banks
+// floats of LDS per wave (forward: one [50][49] tile, backward: two), kept a multiple of four for the b128 rows
+constexpr int wa_per_wave(int mats) { return (2 * WA_N * WA_LD + mats * (WA_N + 1) * WA_LM + 64 + 3) & ~3; }
 
 template <typename T> __device__ __forceinline__ void load32(const T* p, float* v);
 template <> __device__ __forceinline__ void load32<float>(const float* p, float* v) {
@@ -40,6 +42,29 @@ template <> __device__ __forceinline__ void store32<bf16_t>(bf16_t* p, const flo
 #pragma unroll
         for (int e = 0; e < 8; ++e) t[e] = (bf16_t)v[8 * c + e];
         *reinterpret_cast<bf16x8_t*>(p + 8 * c) = t; }
+}
+
+// <a, row> and acc += s * row against one 32-float LDS row that every lane reads (broadcast, eight ds_read_b128)
+__device__ __forceinline__ float dot32(const float* a, const float* row) {
+    float d = 0.f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const f32x4_t t = *reinterpret_cast<const f32x4_t*>(row + 4 * c);
+        d += a[4 * c] * t[0]; d += a[4 * c + 1] * t[1]; d += a[4 * c + 2] * t[2]; d += a[4 * c + 3] * t[3];
+    }
+    return d;
+}
+__device__ __forceinline__ void axpy32(float* acc, float s, const float* row) {
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const f32x4_t t = *reinterpret_cast<const f32x4_t*>(row + 4 * c);
+        acc[4 * c] += s * t[0]; acc[4 * c + 1] += s * t[1]; acc[4 * c + 2] += s * t[2]; acc[4 * c + 3] += s * t[3];
+    }
+}
+__device__ __forceinline__ void put32(float* row, const float* v, float s) {
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+        *reinterpret_cast<f32x4_t*>(row + 4 * c) = f32x4_t{v[4 * c] * s, v[4 * c + 1] * s, v[4 * c + 2] * s, v[4 * c + 3] * s};
 }
 
 // Window geometry: `ws` x `ws` tokens, optional cyclic shift (SW-MSA, nets/AlterNet_SwinV2_FAN.py:420-440): token
@@ -72,9 +97,7 @@ __device__ __forceinline__ void wa_softmax_row(const float* qh, const float* sk,
     float mx = -INFINITY;
 #pragma unroll 1
     for (int j = 0; j < n; ++j) {
-        float d = 0.f;
-#pragma unroll
-        for (int e = 0; e < WA_D; ++e) d += qh[e] * sk[j * WA_LD + e];
+        const float d = dot32(qh, sk + j * WA_LD);
         const float sv = d * scale + bias_row[j] + (sreg[j] != my_region ? -100.f : 0.f);
         srow[j] = sv;
         mx = fmaxf(mx, sv);
@@ -93,7 +116,7 @@ __global__ __launch_bounds__(256) void winattn_fwd_kernel(const T* __restrict__ 
                                                           int nwin, WaGeom g, int C, int heads) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    constexpr int PER_WAVE = 2 * WA_N * WA_LD + (WA_N + 1) * WA_LM + 64;
+    constexpr int PER_WAVE = wa_per_wave(1);
     float* sk = reinterpret_cast<float*>(smem_raw) + wave * PER_WAVE;
     float* sv = sk + WA_N * WA_LD;
     float* ss = sv + WA_N * WA_LD;                    // [50][50]: score / probability rows (row 49 = idle lanes)
@@ -115,17 +138,11 @@ __global__ __launch_bounds__(256) void winattn_fwd_kernel(const T* __restrict__ 
 #pragma unroll
     for (int e = 0; e < WA_D; ++e) { nq += q[e] * q[e]; nk += t[e] * t[e]; }
     const float iq = 1.f / fmaxf(sqrtf(nq), 1e-12f), ik = 1.f / fmaxf(sqrtf(nk), 1e-12f);
-    if (active) {
-#pragma unroll
-        for (int e = 0; e < WA_D; ++e) sk[tok * WA_LD + e] = t[e] * ik;
-    }
+    if (active) put32(sk + tok * WA_LD, t, ik);
 #pragma unroll
     for (int e = 0; e < WA_D; ++e) q[e] *= iq;
     load32<T>(row + 2 * C, t);                        // v
-    if (active) {
-#pragma unroll
-        for (int e = 0; e < WA_D; ++e) sv[tok * WA_LD + e] = t[e];
-    }
+    if (active) put32(sv + tok * WA_LD, t, 1.f);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     float* srow = ss + (active ? tok : WA_N) * WA_LM;
@@ -135,9 +152,7 @@ __global__ __launch_bounds__(256) void winattn_fwd_kernel(const T* __restrict__ 
     for (int e = 0; e < WA_D; ++e) o[e] = 0.f;
 #pragma unroll 1
     for (int j = 0; j < n; ++j) {
-        const float pj = srow[j];
-#pragma unroll
-        for (int e = 0; e < WA_D; ++e) o[e] += pj * sv[j * WA_LD + e];
+        axpy32(o, srow[j], sv + j * WA_LD);
     }
     if (active) store32<T>(out + pix * C + h * WA_D, o);
 }
@@ -152,7 +167,7 @@ __global__ __launch_bounds__(256, 1) void winattn_bwd_kernel(const T* __restrict
                                                           int heads, int win_per_block) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    constexpr int PER_WAVE = 2 * WA_N * WA_LD + 2 * (WA_N + 1) * WA_LM + 64;
+    constexpr int PER_WAVE = wa_per_wave(2);
     float* sa = reinterpret_cast<float*>(smem_raw) + wave * PER_WAVE;      // k-hat, later q-hat
     float* sb = sa + WA_N * WA_LD;                                          // v, later dO
     float* sp = sb + WA_N * WA_LD;                                          // P   [50][50]
@@ -187,8 +202,7 @@ __global__ __launch_bounds__(256, 1) void winattn_bwd_kernel(const T* __restrict
         __builtin_amdgcn_wave_barrier();                                      // previous window's LDS reads are done
         if (active) {
             sreg[tok] = region;
-#pragma unroll
-            for (int e = 0; e < WA_D; ++e) { sa[tok * WA_LD + e] = kh[e]; sb[tok * WA_LD + e] = go[e]; }
+            put32(sa + tok * WA_LD, kh, 1.f); put32(sb + tok * WA_LD, go, 1.f);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -198,9 +212,7 @@ __global__ __launch_bounds__(256, 1) void winattn_bwd_kernel(const T* __restrict
         float rd = 0.f;
 #pragma unroll 1
         for (int j = 0; j < n; ++j) {
-            float d = 0.f;
-#pragma unroll
-            for (int e = 0; e < WA_D; ++e) d += go[e] * sb[j * WA_LD + e];
+            const float d = dot32(go, sb + j * WA_LD);
             sd[myrow + j] = d; rd += d * sp[myrow + j];
         }
         // dq-hat_i = scale * sum_j dS_ij k-hat_j ; d(scale) += sum_j dS_ij cos_ij
@@ -214,7 +226,11 @@ __global__ __launch_bounds__(256, 1) void winattn_bwd_kernel(const T* __restrict
             sd[myrow + j] = dsj;
             float c = 0.f;
 #pragma unroll
-            for (int e = 0; e < WA_D; ++e) { const float kv = sa[j * WA_LD + e]; acc[e] += dsj * kv; c += q[e] * kv; }
+            for (int e4 = 0; e4 < 8; ++e4) {
+                const f32x4_t kv = *reinterpret_cast<const f32x4_t*>(sa + j * WA_LD + 4 * e4);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { acc[4 * e4 + u] += dsj * kv[u]; c += q[4 * e4 + u] * kv[u]; }
+            }
             dsc_w += dsj * c;
         }
         if (active) {
@@ -231,19 +247,14 @@ __global__ __launch_bounds__(256, 1) void winattn_bwd_kernel(const T* __restrict
         if (active) store32<T>(drow, acc);
         // ---- dV_j = sum_i P_ij dO_i : dO -> LDS (over v); q-hat -> LDS (over k-hat) for the dK pass
         __builtin_amdgcn_wave_barrier();
-        if (active) {
-#pragma unroll
-            for (int e = 0; e < WA_D; ++e) { sb[tok * WA_LD + e] = go[e]; sa[tok * WA_LD + e] = q[e]; }
-        }
+        if (active) { put32(sb + tok * WA_LD, go, 1.f); put32(sa + tok * WA_LD, q, 1.f); }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int e = 0; e < WA_D; ++e) acc[e] = 0.f;
 #pragma unroll 1
         for (int i = 0; i < n; ++i) {
-            const float pij = sp[i * WA_LM + tok];
-#pragma unroll
-            for (int e = 0; e < WA_D; ++e) acc[e] += pij * sb[i * WA_LD + e];
+            axpy32(acc, sp[i * WA_LM + tok], sb + i * WA_LD);
         }
         if (active) store32<T>(drow + 2 * C, acc);
         // ---- dk-hat_j = scale * sum_i dS_ij q-hat_i
@@ -251,9 +262,7 @@ __global__ __launch_bounds__(256, 1) void winattn_bwd_kernel(const T* __restrict
         for (int e = 0; e < WA_D; ++e) acc[e] = 0.f;
 #pragma unroll 1
         for (int i = 0; i < n; ++i) {
-            const float dij = sd[i * WA_LM + tok];
-#pragma unroll
-            for (int e = 0; e < WA_D; ++e) acc[e] += dij * sa[i * WA_LD + e];
+            axpy32(acc, sd[i * WA_LM + tok], sa + i * WA_LD);
         }
         float dotk = 0.f;
 #pragma unroll
@@ -343,7 +352,7 @@ extern "C" int frhip_winattn_fwd(int dtype, const void* qkv, const float* bias, 
     if (!wa_shape_ok(dtype, b, h, w, c, heads, ws, shift, "frhip_winattn_fwd")) return FRHIP_EINVAL;
     const int nwin = b * (h / ws) * (w / ws);
     WaGeom g; g.H = h; g.W = w; g.ws = ws; g.shift = shift; g.n = ws * ws;
-    const int blocks = (nwin * heads + 3) / 4, lds = 4 * (2 * WA_N * WA_LD + (WA_N + 1) * WA_LM + 64) * 4;
+    const int blocks = (nwin * heads + 3) / 4, lds = 4 * wa_per_wave(1) * 4;
     static bool fattr[2] = {false, false};
     if (!fattr[dtype]) {
         const void* fn = dtype == FRHIP_DT_BF16 ? reinterpret_cast<const void*>(winattn_fwd_kernel<bf16_t>) : reinterpret_cast<const void*>(winattn_fwd_kernel<float>);
@@ -366,7 +375,7 @@ extern "C" int frhip_winattn_bwd(int dtype, const void* qkv, const void* dout, c
     int chunks = (1024 + heads - 1) / heads;                 // ~1024 workgroups
     int wpb = (nwin + chunks - 1) / chunks; if (wpb < 4) wpb = 4;
     chunks = (nwin + wpb - 1) / wpb;
-    const int lds = 4 * (2 * WA_N * WA_LD + 2 * (WA_N + 1) * WA_LM + 64) * 4;
+    const int lds = 4 * wa_per_wave(2) * 4;
     static bool attr_done[2] = {false, false};
     const void* fn = dtype == FRHIP_DT_BF16 ? reinterpret_cast<const void*>(winattn_bwd_kernel<bf16_t>) : reinterpret_cast<const void*>(winattn_bwd_kernel<float>);
     if (!attr_done[dtype]) {

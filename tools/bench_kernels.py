@@ -51,6 +51,19 @@ if what == "ew":
         print("h=%2d c=%3d T=%6.1fMB | apply %6.1fus %4.2fTB/s | apply+res %6.1fus %4.2fTB/s | colstats %6.1fus %4.2fTB/s | bwd_reduce %6.1fus %4.2fTB/s | bwd_apply %6.1fus %4.2fTB/s" % (
             h, c, T, t_apply, 2 * T / t_apply, t_apply_res, 3 * T / t_apply_res, t_stats, T / t_stats, t_bred, 2 * T / t_bred, t_bapp, 3 * T / t_bapp), flush=True)
     sys.exit(0)
+if what == "attn":
+    for (h, c, heads) in [(56, 64, 2), (28, 128, 4), (14, 256, 8), (7, 512, 16)]:
+        rows = B * h * h
+        qkv = torch.randn(rows, 3 * c, device="cuda").bfloat16()
+        do = torch.randn(rows, c, device="cuda").bfloat16()
+        bias = torch.randn(heads, 49, 49, device="cuda")
+        scale = torch.rand(heads, device="cuda") * 5 + 5
+        tf = timeit(lambda: ops.winattn_fwd(qkv, bias, scale, B, h, h, heads))
+        tb = timeit(lambda: ops.winattn_bwd(qkv, do, bias, scale, B, h, h, heads))
+        pairs = rows // 49 * heads
+        gf = pairs * 2 * 2 * 49 * 49 * 32 / 1e9
+        print("h=%2d c=%3d heads=%2d pairs=%6d | fwd %7.1fus %5.1fTF | bwd %7.1fus %5.1fTF" % (h, c, heads, pairs, tf, gf / tf / 1e3, tb, 2.5 * gf / tb / 1e3), flush=True)
+    sys.exit(0)
 for (h, c, k, r, stride) in SHAPES:
     pad = (r - 1) // 2
     x = torch.randn(B, h, h, c, device="cuda").bfloat16()
