@@ -9,12 +9,11 @@
 // Swin34 step FLOPs.
 // Backward recomputes the probabilities, keeps dS / P rows in registers, transposes through LDS for dK / dV, and
 // accumulates d(bias) and d(scale) across all windows of a workgroup's head before one atomic pass.
-#include "common.h"
+#include "winattn.h"
 #include "frhip.h"
 
 namespace frhip {
 
-constexpr int WA_N = 49, WA_D = 32;     // largest window (7x7 tokens); smaller windows (6x6, 3x3) use the same tiles
 constexpr int WA_LD = WA_D + 4;        // row pitch of the [49][32] LDS tiles: 16-byte aligned rows -> b128 broadcast reads
 constexpr int WA_LM = WA_N;            // row pitch of the [50][49] LDS tiles: odd, so lane-per-row accesses spread over banks
 // floats of LDS per wave (forward: one [50][49] tile, backward: two), kept a multiple of four for the b128 rows
@@ -65,28 +64,6 @@ __device__ __forceinline__ void put32(float* row, const float* v, float s) {
 #pragma unroll
     for (int c = 0; c < 8; ++c)
         *reinterpret_cast<f32x4_t*>(row + 4 * c) = f32x4_t{v[4 * c] * s, v[4 * c + 1] * s, v[4 * c + 2] * s, v[4 * c + 3] * s};
-}
-
-// Window geometry: `ws` x `ws` tokens, optional cyclic shift (SW-MSA, nets/AlterNet_SwinV2_FAN.py:420-440): token
-// (ty,tx) of window (wy,wx) of the ROLLED image is pixel ((wy*ws+ty+shift) % H, (wx*ws+tx+shift) % W) of the original,
-// and the output goes back to that same pixel (the reverse roll).  `region` is the 3x3 region id of the rolled
-// position used by the reference's attention mask (:375-397): tokens of different regions get -100 added.
-struct WaGeom { int H, W, ws, shift, n; };
-
-__device__ __forceinline__ size_t wa_pixel(int win, int tok, const WaGeom& g, int* region) {
-    const int wpr = g.W / g.ws, wpi = (g.H / g.ws) * wpr;
-    const int b = win / wpi, r = win - b * wpi, wy = r / wpr, wx = r - wy * wpr;
-    const int ty = tok / g.ws, tx = tok - ty * g.ws;
-    const int hs = wy * g.ws + ty, wsx = wx * g.ws + tx;                 // position in the rolled image
-    int hh = hs + g.shift, ww = wsx + g.shift;
-    if (hh >= g.H) hh -= g.H;
-    if (ww >= g.W) ww -= g.W;
-    if (region) {
-        const int rh = hs < g.H - g.ws ? 0 : (hs < g.H - g.shift ? 1 : 2);
-        const int rw = wsx < g.W - g.ws ? 0 : (wsx < g.W - g.shift ? 1 : 2);
-        *region = g.shift > 0 ? rh * 3 + rw : 0;
-    }
-    return ((size_t)b * g.H + hh) * g.W + ww;
 }
 
 // Score row of this lane's query against all n keys, softmax'ed, kept in the lane's own LDS row `srow`
@@ -347,11 +324,15 @@ static bool wa_shape_ok(int dtype, int b, int h, int w, int c, int heads, int ws
     return true;
 }
 
+static int g_wa_mfma = 1;
+extern "C" int frhip_set_winattn_mfma(int enabled) { const int old = g_wa_mfma; g_wa_mfma = enabled ? 1 : 0; return old; }
+
 extern "C" int frhip_winattn_fwd(int dtype, const void* qkv, const float* bias, const float* scale, void* out, int b, int h,
                                  int w, int c, int heads, int ws, int shift, hipStream_t stream) {
     if (!wa_shape_ok(dtype, b, h, w, c, heads, ws, shift, "frhip_winattn_fwd")) return FRHIP_EINVAL;
     const int nwin = b * (h / ws) * (w / ws);
     WaGeom g; g.H = h; g.W = w; g.ws = ws; g.shift = shift; g.n = ws * ws;
+    if (dtype == FRHIP_DT_BF16 && g_wa_mfma) return winattn_mfma_fwd(qkv, bias, scale, out, nwin, g, c, heads, stream);
     const int blocks = (nwin * heads + 3) / 4, lds = 4 * wa_per_wave(1) * 4;
     static bool fattr[2] = {false, false};
     if (!fattr[dtype]) {
@@ -372,6 +353,7 @@ extern "C" int frhip_winattn_bwd(int dtype, const void* qkv, const void* dout, c
     if (!wa_shape_ok(dtype, b, h, w, c, heads, ws, shift, "frhip_winattn_bwd")) return FRHIP_EINVAL;
     const int nwin = b * (h / ws) * (w / ws);
     WaGeom g; g.H = h; g.W = w; g.ws = ws; g.shift = shift; g.n = ws * ws;
+    if (dtype == FRHIP_DT_BF16 && g_wa_mfma) return winattn_mfma_bwd(qkv, dout, bias, scale, dqkv, dbias, dscale, nwin, g, c, heads, stream);
     int chunks = (1024 + heads - 1) / heads;                 // ~1024 workgroups
     int wpb = (nwin + chunks - 1) / chunks; if (wpb < 4) wpb = 4;
     chunks = (nwin + wpb - 1) / wpb;

@@ -198,6 +198,9 @@ int frhip_winattn_fwd(int dtype, const void* qkv, const float* bias, const float
 int frhip_winattn_bwd(int dtype, const void* qkv, const void* dout, const float* bias, const float* scale,
                       void* dqkv, float* dbias, float* dscale, int b, int h, int w, int c, int heads,
                       int ws, int shift, frhip_stream_t stream);
+/* 1 (default): bf16 calls run the MFMA-tile kernels (bf16 GEMM operands, fp32 scores / softmax -- the reference's autocast
+ * numerics); 0: the fp32-arithmetic VALU kernels for every dtype.  Returns the old value */
+int frhip_set_winattn_mfma(int enabled);
 /* y[rows][c] += bias (in place); act_out (may be NULL) = gelu(y).  Mlp fc1 + GELU: nets/SwinV2.py:16-32 */
 int frhip_bias_gelu_fwd(int dtype, void* y, const float* bias, void* act_out, int rows, int c, frhip_stream_t stream);
 int frhip_gelu_bwd(int dtype, const void* da, const void* h, void* dh, size_t n, frhip_stream_t stream);

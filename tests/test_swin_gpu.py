@@ -11,11 +11,21 @@ pytestmark = pytest.mark.gpu
 NOISE = ("proj.bias", "fc2.bias", "v_bias")        # analytically zero gradients (they only shift a train-mode BN input)
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def _rb(x):
+    """round to bf16 in the forward pass, identity in the backward pass: the casts torch autocast puts in front of `@`"""
+    return x + (x.bfloat16().float() - x).detach()
+
+
+@pytest.mark.parametrize("impl", ["f32", "bf16-valu", "bf16-mfma"])
 @pytest.mark.parametrize("shape", [(3, 14, 128, 4), (2, 7, 512, 16)])
-def test_window_attention_kernel(dtype, shape):
-    """frhip_winattn_fwd / _bwd against the oracle's cosine window attention on the same q, k, v"""
+def test_window_attention_kernel(impl, shape):
+    """frhip_winattn_fwd / _bwd against the oracle's cosine window attention on the same q, k, v.  The bf16 MFMA kernels
+    feed both GEMMs bf16 operands exactly where the reference's autocast does (nets/SwinV2.py:160-176: F.normalize and
+    softmax are fp32 autocast ops, the two `@` cast their inputs to bf16), so their oracle carries those roundings."""
     from frhip import ops
+    from frhip._abi import lib
+    dtype = torch.float32 if impl == "f32" else torch.bfloat16
+    cast = _rb if impl == "bf16-mfma" else (lambda x: x)
     b, hw, c, heads = shape
     g = torch.Generator().manual_seed(b * hw + c)
     qkv = torch.randn((b * hw * hw, 3 * c), generator=g).to(dtype).float()
@@ -27,18 +37,53 @@ def test_window_attention_kernel(dtype, shape):
     br, sr = bias.clone().requires_grad_(True), scale.clone().requires_grad_(True)
     xw = swin_ref.to_windows(qr.view(b, hw, hw, 3 * c))                       # [B_, 49, 3C]
     q, k, v = [t.reshape(-1, 49, heads, 32).transpose(1, 2) for t in xw.split(c, dim=-1)]
-    attn = torch.nn.functional.normalize(q, dim=-1) @ torch.nn.functional.normalize(k, dim=-1).transpose(-2, -1)
+    attn = cast(torch.nn.functional.normalize(q, dim=-1)) @ cast(torch.nn.functional.normalize(k, dim=-1)).transpose(-2, -1)
     attn = torch.softmax(attn * sr.view(1, heads, 1, 1) + br.unsqueeze(0), dim=-1)
-    ref = swin_ref.from_windows((attn @ v).transpose(1, 2).reshape(-1, 49, c), b, hw, hw).reshape(-1, c)
+    ref = swin_ref.from_windows((cast(attn) @ v).transpose(1, 2).reshape(-1, 49, c), b, hw, hw).reshape(-1, c)
     ref.backward(dout)
-    out = ops.winattn_fwd(qkv.to(dtype).cuda(), bias.cuda(), scale.cuda(), b, hw, hw, heads)
-    dqkv, dbias, dscale = ops.winattn_bwd(qkv.to(dtype).cuda(), dout.to(dtype).cuda(), bias.cuda(), scale.cuda(), b, hw, hw, heads)
+    old = lib().frhip_set_winattn_mfma(1 if impl == "bf16-mfma" else 0)
+    try:
+        out = ops.winattn_fwd(qkv.to(dtype).cuda(), bias.cuda(), scale.cuda(), b, hw, hw, heads)
+        dqkv, dbias, dscale = ops.winattn_bwd(qkv.to(dtype).cuda(), dout.to(dtype).cuda(), bias.cuda(), scale.cuda(), b, hw, hw, heads)
+    finally:
+        lib().frhip_set_winattn_mfma(old)
     t = dict(rtol=2e-4, atol=2e-5) if dtype == torch.float32 else dict(rtol=3e-2, atol=3e-2)
     np.testing.assert_allclose(out.float().cpu().numpy(), ref.detach().numpy(), **t)
     sc = qr.grad.abs().max().item()
     np.testing.assert_allclose(dqkv.float().cpu().numpy(), qr.grad.numpy(), rtol=t["rtol"], atol=t["atol"] * max(sc, 1.0))
+    # d(bias), d(scale) are fp32 sums over all windows; the MFMA path's dS differs from the oracle's only by the bf16
+    # rounding of dP's operands being applied in a different order -> same tolerance as the fp32-arithmetic kernels
     np.testing.assert_allclose(dbias.cpu().numpy(), br.grad.numpy(), rtol=2e-3, atol=2e-3 * br.grad.abs().max().item())
     np.testing.assert_allclose(dscale.cpu().numpy(), sr.grad.numpy(), rtol=2e-3, atol=2e-3 * sr.grad.abs().max().item())
+
+
+@pytest.mark.parametrize("geom", [(2, 12, 128, 4, 6, 3), (2, 12, 128, 4, 6, 0), (3, 6, 512, 16, 3, 1), (2, 14, 64, 2, 7, 3)])
+def test_window_attention_mfma_matches_valu_kernels(geom):
+    """shifted / masked and 6x6, 3x3 windows: the bf16 MFMA kernels against the fp32-arithmetic kernels (which the
+    reference fixtures of test_alternet_gpu pin) on the same bf16 operands"""
+    from frhip import ops
+    from frhip._abi import lib
+    b, hw, c, heads, ws, shift = geom
+    n = ws * ws
+    g = torch.Generator().manual_seed(hw * ws + shift)
+    qkv = torch.randn((b * hw * hw, 3 * c), generator=g).bfloat16().cuda()
+    dout = torch.randn((b * hw * hw, c), generator=g).bfloat16().cuda()
+    bias = (16 * torch.sigmoid(torch.randn((heads, n, n), generator=g))).cuda()
+    scale = torch.exp(torch.randn(heads, generator=g) * 0.3 + 1.5).cuda()
+    res = {}
+    for mode in (0, 1):
+        old = lib().frhip_set_winattn_mfma(mode)
+        try:
+            out = ops.winattn_fwd(qkv, bias, scale, b, hw, hw, heads, ws=ws, shift=shift)
+            res[mode] = (out,) + ops.winattn_bwd(qkv, dout, bias, scale, b, hw, hw, heads, ws=ws, shift=shift)
+        finally:
+            lib().frhip_set_winattn_mfma(old)
+    torch.cuda.synchronize()
+    names = ("out", "dqkv", "dbias", "dscale")
+    for name, a, r in zip(names, res[1], res[0]):
+        a, r = a.float().cpu().numpy(), r.float().cpu().numpy()
+        tol = 4e-2 if name in ("out", "dqkv") else 2e-2       # operand roundings of the bf16 GEMMs (q^, k^, P, dS)
+        np.testing.assert_allclose(a, r, rtol=tol, atol=tol * max(np.abs(r).max(), 1e-3), err_msg=name)
 
 
 @pytest.mark.parametrize("tag", ["c128h4", "c512h16"])
