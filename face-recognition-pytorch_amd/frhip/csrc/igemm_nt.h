@@ -45,6 +45,10 @@ struct EpiBnRed {
     // residual is the COMPACT gradient of a stride-2 1x1 shortcut, [n][(res_h+1)/2][(res_w+1)/2][c]: it lands on the even
     // pixels only (everything else receives nothing), so the zero-stuffed full-size tensor is never built.
     int res_h, res_w;
+    // linear-layer epilogue (forward only, no BN-backward partials): out = gemm + bias[n], rounded to T and stored;
+    // act (optional) = gelu(out) of the STORED value (exact erf form); forward statistics then describe out
+    const float* bias;
+    void* act;
 };
 
 // WM x WN waves; each wave owns (MT*16) pixel rows x 64 channels (4 MFMA tiles wide).
@@ -334,6 +338,10 @@ __device__ __forceinline__ void nt_epilogue_store(const char* mine, int P, char*
             }
         }
     } else {
+        float bb[EPV];
+#pragma unroll
+        for (int e = 0; e < EPV; ++e) bb[e] = (br.bias && n + e < Nout) ? br.bias[n + e] : 0.f;
+        T* ao = reinterpret_cast<T*>(br.act);
 #pragma unroll
         for (int it = 0; it < WROWS / RPI; ++it) {
             const int row = it * RPI + rsub;
@@ -345,7 +353,20 @@ __device__ __forceinline__ void nt_epilogue_store(const char* mine, int P, char*
 #pragma unroll
                     for (int e = 0; e < EPV; ++e) v.set(e, v.get(e) + rr.get(e));
                 }
+                if (br.bias) {
+#pragma unroll
+                    for (int e = 0; e < EPV; ++e) v.set(e, v.get(e) + bb[e]);
+                }
                 *reinterpret_cast<Vec16<T>*>(o + (size_t)m * Nout + n) = v;
+                if (ao) {
+                    Vec16<T> ga;
+#pragma unroll
+                    for (int e = 0; e < EPV; ++e) {
+                        const float hr = v.get(e);
+                        ga.set(e, 0.5f * hr * (1.f + erff(hr * 0.70710678118654752f)));
+                    }
+                    *reinterpret_cast<Vec16<T>*>(ao + (size_t)m * Nout + n) = ga;
+                }
             }
 #pragma unroll
             for (int e = 0; e < EPV; ++e) { const float x = v.get(e); s1[e] += x; s2[e] += x * x; }

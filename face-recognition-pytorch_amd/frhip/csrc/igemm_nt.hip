@@ -84,7 +84,7 @@ static int nt_pick_tile(int dtype, const NtGeom& g) {
     return 1;
 }
 
-static const EpiBnRed NO_BNRED = {nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0};
+static const EpiBnRed NO_BNRED = {nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr};
 
 static int nt_dispatch(int dtype, const NtGeom& g, const void* a, const void* b, void* out, const void* res,
                        float* stats, const EpiBnRed& br, int splits, bool atomic, hipStream_t stream) {
@@ -201,7 +201,7 @@ extern "C" int frhip_conv_dgrad_fused(int dtype, const void* dy, const void* wt,
         set_error("frhip_conv_dgrad_fused: y_bn needs mean, invstd and stats_partial");
         return FRHIP_EINVAL;
     }
-    EpiBnRed br = {y_bn, mean, invstd, mask_scale, mask_shift, 0, 0};
+    EpiBnRed br = {y_bn, mean, invstd, mask_scale, mask_shift, 0, 0, nullptr, nullptr};
     if (residual && residual_stride == 2) { br.res_h = h; br.res_w = wd; }
     return dgrad_run(dtype, dy, wt, dx, residual, y_bn ? stats_partial : nullptr, br, n, h, wd, c, k, r, s, stride, pad, stream,
                      "frhip_conv_dgrad_fused");
@@ -217,6 +217,17 @@ extern "C" int frhip_conv_dgrad_bnred(int dtype, const void* dy, const void* wt,
     }
     return frhip_conv_dgrad_fused(dtype, dy, wt, dx, residual, 1, y_bn, mean, invstd, mask_scale, mask_shift, stats_partial,
                                   n, h, wd, c, k, r, s, stride, pad, stream);
+}
+
+extern "C" int frhip_linear_fwd(int dtype, const void* a, const void* w, const float* bias, void* out, void* act_out,
+                                float* stats_partial, int m, int n, int k, hipStream_t stream) {
+    // out[m][n] = sum_k a[m][k] * w[n][k] + bias[n]; act_out = gelu(out); stats_partial as frhip_conv_fwd (a 1x1 conv)
+    NtGeom g;
+    int rc = fill_geom(g, dtype, m, 1, 1, k, 1, 1, n, 1, 1, 1, 0, 0, "frhip_linear_fwd");
+    if (rc) return rc;
+    EpiBnRed br = NO_BNRED;
+    br.bias = bias; br.act = act_out;
+    return nt_dispatch(dtype, g, a, w, out, nullptr, stats_partial, br, 1, false, stream);
 }
 
 extern "C" int frhip_gemm_nt(int dtype, const void* a, const void* b, void* out, int m, int n, int k,

@@ -118,6 +118,22 @@ def gemm_nt(a, b, out=None, splits=1, atomic_f32=False):
     return out
 
 
+def linear_fwd(a, w, bias=None, want_act=False, want_stats=False):
+    """nn.Linear with its epilogue: out = a [M,K] @ w [N,K]^T + bias (fp32 [N]); act = gelu(out) when want_act;
+    part = BatchNorm partial sums of out when want_stats.  Returns (out, act, part)."""
+    m, k = a.shape
+    n = w.shape[0]
+    assert w.shape[1] == k and a.dtype == w.dtype
+    out = torch.empty((m, n), dtype=a.dtype, device=a.device)
+    act = torch.empty_like(out) if want_act else None
+    part = None
+    if want_stats:
+        rows = lib().frhip_conv_stat_rows(dt_of(a), m, n, 1, 1, k, 1, 1, 1, 0)
+        part = torch.empty((rows, 2, n), dtype=torch.float32, device=a.device)
+    check(lib().frhip_linear_fwd(dt_of(a), _p(a), _p(w), _p(bias), _p(out), _p(act), _p(part), m, n, k, _s()), "frhip_linear_fwd")
+    return out, act, part
+
+
 def gemm_tn(p, q, out, kc=None, splits=0):
     """out[kc][c] fp32 += sum_m p[m][:kc] * q[m][:c]"""
     m, ldp = p.shape

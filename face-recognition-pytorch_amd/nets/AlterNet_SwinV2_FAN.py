@@ -95,18 +95,16 @@ def attn_block_forward(blk, x, dt, training, save):
     at = blk.attn
     x2 = x.view(m, c)
     wqkv = _S._w2d(at.qkv, dt)
-    qkv = ops.gemm_nt(x2, wqkv)
     qb = torch.cat([at.q_bias.data, torch.zeros_like(at.v_bias.data), at.v_bias.data])
-    ops.bias_gelu_fwd(qkv, qb, False)
+    qkv, _, _ = ops.linear_fwd(x2, wqkv, qb)                                  # bias add in the GEMM epilogue
     with torch.enable_grad():
         cpb = [p.detach().requires_grad_(True) for p in at.cpb_params()]
         bias_t, scale_t = at.bias_and_scale(cpb)
     bias, scale = bias_t.detach().contiguous(), scale_t.detach().contiguous()
     ao = ops.winattn_fwd(qkv, bias, scale, b, h, w, at.num_heads, blk.window_size, blk.shift_size)
     wproj = _S._w2d(at.proj, dt)
-    po = ops.gemm_nt(ao, wproj)
-    ops.bias_gelu_fwd(po, at.proj.bias.data, False)
-    st2 = bn_forward_state(blk.norm2, ops.colstats(po) if training else None, m, training)
+    po, _, part2 = ops.linear_fwd(ao, wproj, at.proj.bias.data, want_stats=training)   # + norm2's batch statistics
+    st2 = bn_forward_state(blk.norm2, part2, m, training)
     keep = None
     if training and blk.drop_path_rate > 0:
         # stochastic depth: one Bernoulli(keep) per sample scales the whole normalised branch (timm DropPath)

@@ -118,26 +118,22 @@ def swin_block_forward(blk, x, dt, training, save):
     at = blk.attn
     x2 = x.view(m, c)
     wqkv = _w2d(at.qkv, dt)
-    qkv = ops.gemm_nt(x2, wqkv)
     qb = torch.cat([at.q_bias.data, torch.zeros_like(at.v_bias.data), at.v_bias.data])
-    ops.bias_gelu_fwd(qkv, qb, False)
+    qkv, _, _ = ops.linear_fwd(x2, wqkv, qb)                                  # bias add in the GEMM epilogue
     with torch.enable_grad():
         cpb = [p.detach().requires_grad_(True) for p in at.cpb_params()]
         bias_t, scale_t = at.bias_and_scale(cpb)
     bias, scale = bias_t.detach().contiguous(), scale_t.detach().contiguous()
     ao = ops.winattn_fwd(qkv, bias, scale, b, h, w, at.num_heads)
     wproj = _w2d(at.proj, dt)
-    po = ops.gemm_nt(ao, wproj)
-    ops.bias_gelu_fwd(po, at.proj.bias.data, False)
-    st2 = bn_forward_state(blk.norm2, ops.colstats(po) if training else None, m, training)
+    po, _, part2 = ops.linear_fwd(ao, wproj, at.proj.bias.data, want_stats=training)   # + norm2's batch statistics
+    st2 = bn_forward_state(blk.norm2, part2, m, training)
     x1 = ops.bn_apply(po, st2, res=x2)
     w1 = _w2d(blk.mlp.fc1, dt)
-    hid = ops.gemm_nt(x1, w1)
-    act = ops.bias_gelu_fwd(hid, blk.mlp.fc1.bias.data, True)
+    hid, act, _ = ops.linear_fwd(x1, w1, blk.mlp.fc1.bias.data, want_act=True)          # bias + GELU, both tensors kept
     w2 = _w2d(blk.mlp.fc2, dt)
-    mo = ops.gemm_nt(act, w2)
-    ops.bias_gelu_fwd(mo, blk.mlp.fc2.bias.data, False)
-    st3 = bn_forward_state(blk.norm3, ops.colstats(mo) if training else None, m, training)
+    mo, _, part3 = ops.linear_fwd(act, w2, blk.mlp.fc2.bias.data, want_stats=training)
+    st3 = bn_forward_state(blk.norm3, part3, m, training)
     out = ops.bn_apply(mo, st3, res=x1).view(b, h, w, c)
     s = None
     if save:

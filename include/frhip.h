@@ -89,6 +89,11 @@ int frhip_conv_dgrad_fused(int dtype, const void* dy, const void* wt, void* dx, 
 int frhip_conv_wgrad(int dtype, const void* dy, const void* x, float* dw, int n, int h, int w, int c,
                      int k, int r, int s, int stride, int pad, int splits, float* workspace, size_t workspace_bytes,
                      frhip_stream_t stream);
+/* nn.Linear forward with its epilogue fused (nets/SwinV2.py:16-32 Mlp, :150-176 qkv / proj): out[m][n] = a[m][k] . w[n][k] +
+ * bias[n] (bias may be NULL), stored in `dtype`; act_out (may be NULL) = gelu(out), exact erf form, of the stored value;
+ * stats_partial (may be NULL): per-tile BatchNorm partial sums of `out`, rows = frhip_conv_stat_rows(dtype, m, n, 1,1,k,1,1,1,0) */
+int frhip_linear_fwd(int dtype, const void* a, const void* w, const float* bias, void* out, void* act_out,
+                     float* stats_partial, int m, int n, int k, frhip_stream_t stream);
 /* out[m][n] = sum_k a[m][k]*b[n][k].  atomic_f32 = 0: out has `dtype`, overwritten (splits ignored);
  * atomic_f32 = 1: out is fp32, caller-zeroed, K is split `splits` ways and added atomically.  nn.Linear: nets/resnet.py:244 */
 int frhip_gemm_nt(int dtype, const void* a, const void* b, void* out, int m, int n, int k, int splits,

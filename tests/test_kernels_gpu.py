@@ -249,6 +249,29 @@ def test_gemm_nt_store_and_splitk(dtype, mnk):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("mnk", [(600, 256, 64), (1000, 192, 128), (5000, 512, 256), (300, 72, 64)])
+def test_linear_fwd_fused_bias_gelu_stats(dtype, mnk):
+    """frhip_linear_fwd = nn.Linear + (GELU) + BatchNorm partial sums in one GEMM epilogue, against the separate passes"""
+    ops = _ops()
+    m, n, k = mnk
+    a, w = q(rnd(31, (m, k)), dtype), q(rnd(32, (n, k), 0.2), dtype)
+    bias = rnd(33, (n,))
+    out, act, part = ops.linear_fwd(a.to(dtype).cuda(), w.to(dtype).cuda(), bias.cuda(), want_act=True, want_stats=True)
+    ref = q(q(a @ w.t(), dtype) + bias, dtype)                     # the GEMM result is rounded, then the biased value
+    t = tol(dtype, ref.abs().max().item())
+    np.testing.assert_allclose(out.float().cpu().numpy(), ref.numpy(), **t)
+    got = out.float().cpu()
+    np.testing.assert_allclose(act.float().cpu().numpy(), q(torch.nn.functional.gelu(got), dtype).numpy(),
+                               rtol=1e-2 if dtype == torch.bfloat16 else 1e-5, atol=1e-2 if dtype == torch.bfloat16 else 1e-5)
+    sums = part.sum(0).cpu()
+    np.testing.assert_allclose(sums[0].numpy(), got.sum(0).numpy(), rtol=1e-4, atol=1e-3 * got.abs().sum(0).max().item())
+    np.testing.assert_allclose(sums[1].numpy(), (got * got).sum(0).numpy(), rtol=1e-4, atol=1e-3)
+    plain, none_act, none_part = ops.linear_fwd(a.to(dtype).cuda(), w.to(dtype).cuda())
+    assert none_act is None and none_part is None
+    np.testing.assert_allclose(plain.float().cpu().numpy(), (a @ w.t()).numpy(), **t)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("shape", [(96, 200, 208, 64), (1000, 128, 128, 512), (70, 24, 24, 32)])
 def test_gemm_tn(dtype, shape):
     ops = _ops()
