@@ -81,6 +81,20 @@ template <> struct Mma<float> {
     }
 };
 
+// GELU (exact erf form, nn.GELU default) pieces for a pre-activation h: cdf = Phi(h), pdf = phi(h).
+// erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, below fp32 round-off of the products it feeds) sharing ONE
+// exponential with the density: erf(h/sqrt2) = 1 - poly(t) * exp(-h^2/2), t = 1/(1 + p*|h|/sqrt2).  About 18 VALU
+// instructions, branch-free; libm's erff costs twice that plus a divergent branch, which a GEMM epilogue cannot hide.
+__device__ __forceinline__ void gelu_parts(float h, float& cdf, float& pdf) {
+    const float ax = fabsf(h) * 0.70710678118654752f;
+    const float t = __builtin_amdgcn_rcpf(1.f + 0.3275911f * ax);
+    const float ex = __expf(-0.5f * h * h);
+    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+    const float er = copysignf(1.f - poly * ex, h);
+    cdf = 0.5f * (1.f + er);
+    pdf = 0.3989422804014327f * ex;
+}
+
 __device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 

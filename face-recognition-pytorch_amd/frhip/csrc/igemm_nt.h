@@ -49,6 +49,9 @@ struct EpiBnRed {
     // act (optional) = gelu(out) of the STORED value (exact erf form); forward statistics then describe out
     const float* bias;
     void* act;
+    // gelu_bwd != 0 (data-gradient of a Linear that feeds a GELU): out = gemm o gelu'(y), y = the saved pre-activation
+    // (same shape as out); the forward-style statistics then carry the column sums of out = the bias gradient
+    int gelu_bwd;
 };
 
 // WM x WN waves; each wave owns (MT*16) pixel rows x 64 channels (4 MFMA tiles wide).
@@ -307,7 +310,7 @@ __device__ __forceinline__ void nt_epilogue_store(const char* mine, int P, char*
 #pragma unroll
     for (int e = 0; e < EPV; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
     T* o = reinterpret_cast<T*>(out);
-    if (stats && br.y) {
+    if (stats && br.y && !br.gelu_bwd) {
         // BN-backward partials: per-channel constants of this lane's EPV channels
         float mu[EPV], is[EPV], ms[EPV], mb[EPV];
 #pragma unroll
@@ -357,13 +360,25 @@ __device__ __forceinline__ void nt_epilogue_store(const char* mine, int P, char*
 #pragma unroll
                     for (int e = 0; e < EPV; ++e) v.set(e, v.get(e) + bb[e]);
                 }
+                if (br.gelu_bwd) {
+                    const Vec16<T> hv = ops.y_row(it);
+#pragma unroll
+                    for (int e = 0; e < EPV; ++e) {
+                        const float hh = hv.get(e);
+                        float cdf, pdf;
+                        gelu_parts(hh, cdf, pdf);
+                        v.set(e, v.get(e) * (cdf + hh * pdf));
+                    }
+                }
                 *reinterpret_cast<Vec16<T>*>(o + (size_t)m * Nout + n) = v;
                 if (ao) {
                     Vec16<T> ga;
 #pragma unroll
                     for (int e = 0; e < EPV; ++e) {
                         const float hr = v.get(e);
-                        ga.set(e, 0.5f * hr * (1.f + erff(hr * 0.70710678118654752f)));
+                        float cdf, pdf;
+                        gelu_parts(hr, cdf, pdf);
+                        ga.set(e, hr * cdf);
                     }
                     *reinterpret_cast<Vec16<T>*>(ao + (size_t)m * Nout + n) = ga;
                 }

@@ -35,7 +35,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void nt_kernel(NtGeom 
 
     if constexpr (EPI == EPI_STORE) {
         EpiOperands<T, WROWS> eo;
-        eo.fetch(res, stats ? br.y : nullptr, g.M, g.Nout, m0, n0, br.res_h, br.res_w);
+        eo.fetch(res, (stats || br.gelu_bwd) ? br.y : nullptr, g.M, g.Nout, m0, n0, br.res_h, br.res_w);
         const char* mine = ml.template stage_out<T>(smem);
         nt_epilogue_store<T, WM, WN, WROWS, THREADS, Tile::BN>(mine, Tile::template stage_pitch<T>(), smem, g.M, g.Nout, out,
                                                                res != nullptr, stats, br, eo, mtile, ntile, m0, n0);
@@ -84,7 +84,7 @@ static int nt_pick_tile(int dtype, const NtGeom& g) {
     return 1;
 }
 
-static const EpiBnRed NO_BNRED = {nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr};
+static const EpiBnRed NO_BNRED = {nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, 0};
 
 static int nt_dispatch(int dtype, const NtGeom& g, const void* a, const void* b, void* out, const void* res,
                        float* stats, const EpiBnRed& br, int splits, bool atomic, hipStream_t stream) {
@@ -201,7 +201,7 @@ extern "C" int frhip_conv_dgrad_fused(int dtype, const void* dy, const void* wt,
         set_error("frhip_conv_dgrad_fused: y_bn needs mean, invstd and stats_partial");
         return FRHIP_EINVAL;
     }
-    EpiBnRed br = {y_bn, mean, invstd, mask_scale, mask_shift, 0, 0, nullptr, nullptr};
+    EpiBnRed br = {y_bn, mean, invstd, mask_scale, mask_shift, 0, 0, nullptr, nullptr, 0};
     if (residual && residual_stride == 2) { br.res_h = h; br.res_w = wd; }
     return dgrad_run(dtype, dy, wt, dx, residual, y_bn ? stats_partial : nullptr, br, n, h, wd, c, k, r, s, stride, pad, stream,
                      "frhip_conv_dgrad_fused");
@@ -228,6 +228,18 @@ extern "C" int frhip_linear_fwd(int dtype, const void* a, const void* w, const f
     EpiBnRed br = NO_BNRED;
     br.bias = bias; br.act = act_out;
     return nt_dispatch(dtype, g, a, w, out, nullptr, stats_partial, br, 1, false, stream);
+}
+
+extern "C" int frhip_linear_dgrad_gelu(int dtype, const void* dy, const void* wt, const void* pre, void* dx,
+                                       float* stats_partial, int m, int n, int k, hipStream_t stream) {
+    // dx[m][n] = (sum_k dy[m][k] * wt[n][k]) * gelu'(pre[m][n]); stats_partial[.][0][n] sums to the column sums of dx
+    if (!pre) { set_error("frhip_linear_dgrad_gelu: the saved pre-activation is required"); return FRHIP_EINVAL; }
+    NtGeom g;
+    int rc = fill_geom(g, dtype, m, 1, 1, k, 1, 1, n, 1, 1, 1, 0, 0, "frhip_linear_dgrad_gelu");
+    if (rc) return rc;
+    EpiBnRed br = NO_BNRED;
+    br.y = pre; br.gelu_bwd = 1;
+    return nt_dispatch(dtype, g, dy, wt, dx, nullptr, stats_partial, br, 1, false, stream);
 }
 
 extern "C" int frhip_gemm_nt(int dtype, const void* a, const void* b, void* out, int m, int n, int k,

@@ -33,6 +33,6 @@ __device__ __forceinline__ size_t wa_pixel(int win, int tok, const WaGeom& g, in
 int winattn_mfma_fwd(const void* qkv, const float* bias, const float* scale, void* out, int nwin, const WaGeom& g, int C,
                      int heads, hipStream_t stream);
 int winattn_mfma_bwd(const void* qkv, const void* dout, const float* bias, const float* scale, void* dqkv, float* dbias,
-                     float* dscale, int nwin, const WaGeom& g, int C, int heads, hipStream_t stream);
+                     float* dscale, float* colsum, int nwin, const WaGeom& g, int C, int heads, hipStream_t stream);
 
 }  // namespace frhip

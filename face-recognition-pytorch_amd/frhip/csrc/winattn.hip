@@ -283,7 +283,9 @@ __global__ __launch_bounds__(256) void bias_gelu_fwd_kernel(T* __restrict__ y, c
             const float hh = x.get(e) + bias[c0 + e];
             x.set(e, hh);
             const float hr = x.get(e);                    // GELU of the STORED (rounded) pre-activation
-            g.set(e, 0.5f * hr * (1.f + erff(hr * 0.70710678118654752f)));
+            float cdf, pdf;
+            gelu_parts(hr, cdf, pdf);
+            g.set(e, hr * cdf);
         }
         *reinterpret_cast<Vec16<T>*>(y + v * EPV) = x;
         if (a) *reinterpret_cast<Vec16<T>*>(a + v * EPV) = g;
@@ -300,8 +302,8 @@ __global__ __launch_bounds__(256) void gelu_bwd_kernel(const T* __restrict__ da,
 #pragma unroll
         for (int e = 0; e < EPV; ++e) {
             const float hh = x.get(e);
-            const float cdf = 0.5f * (1.f + erff(hh * 0.70710678118654752f));
-            const float pdf = 0.3989422804014327f * __expf(-0.5f * hh * hh);
+            float cdf, pdf;
+            gelu_parts(hh, cdf, pdf);
             x.set(e, g.get(e) * (cdf + hh * pdf));
         }
         *reinterpret_cast<Vec16<T>*>(dh + v * EPV) = x;
@@ -325,7 +327,11 @@ static bool wa_shape_ok(int dtype, int b, int h, int w, int c, int heads, int ws
 }
 
 static int g_wa_mfma = 1;
-extern "C" int frhip_set_winattn_mfma(int enabled) { const int old = g_wa_mfma; g_wa_mfma = enabled ? 1 : 0; return old; }
+extern "C" int frhip_set_winattn_mfma(int enabled) {
+    const int old = g_wa_mfma;
+    if (enabled >= 0) g_wa_mfma = enabled ? 1 : 0;              // negative: query only
+    return old;
+}
 
 extern "C" int frhip_winattn_fwd(int dtype, const void* qkv, const float* bias, const float* scale, void* out, int b, int h,
                                  int w, int c, int heads, int ws, int shift, hipStream_t stream) {
@@ -353,7 +359,7 @@ extern "C" int frhip_winattn_bwd(int dtype, const void* qkv, const void* dout, c
     if (!wa_shape_ok(dtype, b, h, w, c, heads, ws, shift, "frhip_winattn_bwd")) return FRHIP_EINVAL;
     const int nwin = b * (h / ws) * (w / ws);
     WaGeom g; g.H = h; g.W = w; g.ws = ws; g.shift = shift; g.n = ws * ws;
-    if (dtype == FRHIP_DT_BF16 && g_wa_mfma) return winattn_mfma_bwd(qkv, dout, bias, scale, dqkv, dbias, dscale, nwin, g, c, heads, stream);
+    if (dtype == FRHIP_DT_BF16 && g_wa_mfma) return winattn_mfma_bwd(qkv, dout, bias, scale, dqkv, dbias, dscale, nullptr, nwin, g, c, heads, stream);
     int chunks = (1024 + heads - 1) / heads;                 // ~1024 workgroups
     int wpb = (nwin + chunks - 1) / chunks; if (wpb < 4) wpb = 4;
     chunks = (nwin + wpb - 1) / wpb;
@@ -387,4 +393,17 @@ extern "C" int frhip_gelu_bwd(int dtype, const void* da, const void* h, void* dh
     if (dtype == FRHIP_DT_BF16) hipLaunchKernelGGL(gelu_bwd_kernel<bf16_t>, dim3(ew_blocks(nvec)), dim3(256), 0, stream, (const bf16_t*)da, (const bf16_t*)h, (bf16_t*)dh, nvec);
     else hipLaunchKernelGGL(gelu_bwd_kernel<float>, dim3(ew_blocks(nvec)), dim3(256), 0, stream, (const float*)da, (const float*)h, (float*)dh, nvec);
     return check_launch("frhip_gelu_bwd");
+}
+
+extern "C" int frhip_winattn_bwd_colsum(int dtype, const void* qkv, const void* dout, const float* bias, const float* scale,
+                                        void* dqkv, float* dbias, float* dscale, float* dqkv_colsum, int b, int h, int w,
+                                        int c, int heads, int ws, int shift, hipStream_t stream) {
+    if (!wa_shape_ok(dtype, b, h, w, c, heads, ws, shift, "frhip_winattn_bwd_colsum")) return FRHIP_EINVAL;
+    if (dtype != FRHIP_DT_BF16 || !g_wa_mfma) {
+        set_error("frhip_winattn_bwd_colsum: only the bf16 MFMA kernels produce the column sums (frhip_set_winattn_mfma)");
+        return FRHIP_EINVAL;
+    }
+    const int nwin = b * (h / ws) * (w / ws);
+    WaGeom g; g.H = h; g.W = w; g.ws = ws; g.shift = shift; g.n = ws * ws;
+    return winattn_mfma_bwd(qkv, dout, bias, scale, dqkv, dbias, dscale, dqkv_colsum, nwin, g, c, heads, stream);
 }

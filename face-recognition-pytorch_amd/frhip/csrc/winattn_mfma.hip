@@ -218,7 +218,7 @@ constexpr int WM_BWD_WAVE = 4 * WM_TILE + WM_PTILE + 1024;
 
 // xt[te][t][r] = d(x^)[token 16t + c][e = 16te + 4g + r] -> d(x) through x^ = x / |x|, stored as bf16 (8-byte pieces)
 __device__ __forceinline__ void wm_store_unnormalised(const f32x4_t (&xt)[2][4], const char* xh, const float* sinv, const int* spix,
-                                                      float sc, bf16_t* dst_base, int C, int n, int lane) {
+                                                      float sc, bf16_t* dst_base, int C, int n, int lane, f32x4_t (&colsum)[2]) {
     const int grp = lane >> 4, c = lane & 15;
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
@@ -240,7 +240,10 @@ __device__ __forceinline__ void wm_store_unnormalised(const f32x4_t (&xt)[2][4],
                 f32x4_t o;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) o[r] = (dv[te][r] - xv[te][r] * dot) * inv;
-                *reinterpret_cast<bf16x4_t*>(dst + 16 * te) = wm_pack4(o);
+                const bf16x4_t ob = wm_pack4(o);
+                *reinterpret_cast<bf16x4_t*>(dst + 16 * te) = ob;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) colsum[te][r] += (float)ob[r];           // of the values as stored
             }
         }
     }
@@ -249,7 +252,8 @@ __device__ __forceinline__ void wm_store_unnormalised(const f32x4_t (&xt)[2][4],
 __global__ __launch_bounds__(256, 1) void wm_bwd_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
                                                         const float* __restrict__ bias, const float* __restrict__ scale,
                                                         bf16_t* __restrict__ dqkv, float* __restrict__ dbias,
-                                                        float* __restrict__ dscale, int nwin, WaGeom g, int C, int win_per_block) {
+                                                        float* __restrict__ dscale, float* __restrict__ colsum, int nwin,
+                                                        WaGeom g, int C, int win_per_block) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int wave = wave_id(), lane = lane_id();
     char* qh = smem + wave * WM_BWD_WAVE;
@@ -271,6 +275,11 @@ __global__ __launch_bounds__(256, 1) void wm_bwd_kernel(const bf16_t* __restrict
 #pragma unroll
         for (int ti = 0; ti < 4; ++ti) db[tj][ti] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     float dsc = 0.f;
+    f32x4_t csum[3][2];                                            // column sums of the stored dq, dk, dv (bias gradients)
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int te = 0; te < 2; ++te) csum[a][te] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     const bool active = lane < n;
     const int tok = active ? lane : 0;
     const int w_begin = blockIdx.y * win_per_block, w_end = min(nwin, w_begin + win_per_block);
@@ -349,7 +358,7 @@ __global__ __launch_bounds__(256, 1) void wm_bwd_kernel(const bf16_t* __restrict
                 for (int te = 0; te < 2; ++te) xt[te][ti] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka[te], df, xt[te][ti], 0, 0, 0);
             }
         }
-        wm_store_unnormalised(xt, qh, siq, spix, sc, dqkv + h * WA_D, C, n, lane);
+        wm_store_unnormalised(xt, qh, siq, spix, sc, dqkv + h * WA_D, C, n, lane, csum[0]);
         // ---- dVt[e][j] = sum_i dOt[e][i] P[i][j]   (both operands transposed reads: K runs along the query rows)
 #pragma unroll
         for (int te = 0; te < 2; ++te)
@@ -373,7 +382,12 @@ __global__ __launch_bounds__(256, 1) void wm_bwd_kernel(const bf16_t* __restrict
             if (j < n) {
                 bf16_t* dst = dqkv + (size_t)spix[j] * 3 * C + 2 * C + h * WA_D + 4 * grp;
 #pragma unroll
-                for (int te = 0; te < 2; ++te) *reinterpret_cast<bf16x4_t*>(dst + 16 * te) = wm_pack4(xt[te][tj]);
+                for (int te = 0; te < 2; ++te) {
+                    const bf16x4_t ob = wm_pack4(xt[te][tj]);
+                    *reinterpret_cast<bf16x4_t*>(dst + 16 * te) = ob;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) csum[2][te][r] += (float)ob[r];
+                }
             }
         }
         // ---- dS -> LDS over P, then dk^t[e][j] = sum_i Q^t[e][i] dS[i][j]
@@ -401,7 +415,7 @@ __global__ __launch_bounds__(256, 1) void wm_bwd_kernel(const bf16_t* __restrict
                 for (int te = 0; te < 2; ++te) xt[te][tj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[te], df, xt[te][tj], 0, 0, 0);
             }
         }
-        wm_store_unnormalised(xt, kh, sik, spix, sc, dqkv + C + h * WA_D, C, n, lane);
+        wm_store_unnormalised(xt, kh, sik, spix, sc, dqkv + C + h * WA_D, C, n, lane, csum[1]);
     }
     // ---- combine the four waves' d(bias) tiles and d(scale): one atomic pass per workgroup
     __syncthreads();
@@ -415,7 +429,25 @@ __global__ __launch_bounds__(256, 1) void wm_bwd_kernel(const bf16_t* __restrict
     for (int d = 1; d < 64; d <<= 1) dsc += __shfl_xor(dsc, d);
     __shared__ float red_s[4];
     if (lane == 0) red_s[wave] = dsc;
+    float* red_c = red + 4 * 4096;                                 // [4 waves][3][32]
+    if (colsum) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int te = 0; te < 2; ++te)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float v = csum[a][te][r];
+#pragma unroll
+                    for (int d = 1; d < 16; d <<= 1) v += __shfl_xor(v, d);       // over the 16 tokens of a lane group
+                    if (c == 0) red_c[(wave * 3 + a) * 32 + 16 * te + 4 * grp + r] = v;
+                }
+    }
     __syncthreads();
+    if (colsum && threadIdx.x < 96) {
+        const int a = threadIdx.x >> 5, e = threadIdx.x & 31;
+        atomicAdd(colsum + a * C + h * WA_D + e, red_c[a * 32 + e] + red_c[96 + a * 32 + e] + red_c[192 + a * 32 + e] + red_c[288 + a * 32 + e]);
+    }
     for (int idx = threadIdx.x; idx < n * n; idx += 256) {
         const int i = idx / n, j = idx - i * n, o = i * 64 + j;
         atomicAdd(dbias + (size_t)h * n * n + idx, red[o] + red[4096 + o] + red[8192 + o] + red[12288 + o]);
@@ -450,7 +482,7 @@ int winattn_mfma_fwd(const void* qkv, const float* bias, const float* scale, voi
 }
 
 int winattn_mfma_bwd(const void* qkv, const void* dout, const float* bias, const float* scale, void* dqkv, float* dbias,
-                     float* dscale, int nwin, const WaGeom& g, int C, int heads, hipStream_t stream) {
+                     float* dscale, float* colsum, int nwin, const WaGeom& g, int C, int heads, hipStream_t stream) {
     const int lds = 4 * WM_BWD_WAVE;
     static bool attr_done = false;
     if (!attr_done) {
@@ -463,7 +495,7 @@ int winattn_mfma_bwd(const void* qkv, const void* dout, const float* bias, const
     int wpb;
     const int chunks = wm_chunks(nwin, heads, 1024, &wpb);
     hipLaunchKernelGGL(wm_bwd_kernel, dim3(heads, chunks), dim3(256), lds, stream, (const bf16_t*)qkv, (const bf16_t*)dout, bias,
-                       scale, (bf16_t*)dqkv, dbias, dscale, nwin, g, C, wpb);
+                       scale, (bf16_t*)dqkv, dbias, dscale, colsum, nwin, g, C, wpb);
     return check_launch("frhip_winattn_bwd");
 }
 

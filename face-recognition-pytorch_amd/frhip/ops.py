@@ -134,6 +134,21 @@ def linear_fwd(a, w, bias=None, want_act=False, want_stats=False):
     return out, act, part
 
 
+def linear_dgrad_gelu(dy, wt, pre, want_colsum=True):
+    """dx = (dy [M,K] @ wt [N,K]^T) * gelu'(pre [M,N]); colsum [N] fp32 = sum over rows of dx (the bias gradient)"""
+    m, k = dy.shape
+    n = wt.shape[0]
+    assert tuple(pre.shape) == (m, n) and pre.dtype == dy.dtype == wt.dtype
+    dx = torch.empty((m, n), dtype=dy.dtype, device=dy.device)
+    part = None
+    if want_colsum:
+        rows = lib().frhip_conv_stat_rows(dt_of(dy), m, n, 1, 1, k, 1, 1, 1, 0)
+        part = torch.empty((rows, 2, n), dtype=torch.float32, device=dy.device)
+    check(lib().frhip_linear_dgrad_gelu(dt_of(dy), _p(dy), _p(wt), _p(pre), _p(dx), _p(part), m, n, k, _s()),
+          "frhip_linear_dgrad_gelu")
+    return dx, (part[:, 0].sum(0) if want_colsum else None)
+
+
 def gemm_tn(p, q, out, kc=None, splits=0):
     """out[kc][c] fp32 += sum_m p[m][:kc] * q[m][:c]"""
     m, ldp = p.shape
@@ -519,11 +534,19 @@ def winattn_fwd(qkv, bias, scale, b, h, w, heads, ws=7, shift=0):
     return out
 
 
-def winattn_bwd(qkv, dout, bias, scale, b, h, w, heads, ws=7, shift=0):
+def winattn_bwd(qkv, dout, bias, scale, b, h, w, heads, ws=7, shift=0, want_colsum=False):
+    """-> dqkv, dbias, dscale [, colsum fp32 [3c] = column sums of dqkv, or None when this dtype / kernel mode cannot fuse them]"""
     c = qkv.shape[1] // 3
     dqkv = torch.empty_like(qkv)
     dbias = torch.zeros_like(bias)
     dscale = torch.zeros_like(scale)
+    if want_colsum:
+        if qkv.dtype != torch.bfloat16 or not lib().frhip_set_winattn_mfma(-1):
+            return winattn_bwd(qkv, dout, bias, scale, b, h, w, heads, ws, shift) + (None,)
+        colsum = torch.zeros(3 * c, dtype=torch.float32, device=qkv.device)
+        check(lib().frhip_winattn_bwd_colsum(dt_of(qkv), _p(qkv), _p(dout), _p(bias), _p(scale), _p(dqkv), _p(dbias), _p(dscale),
+                                             _p(colsum), b, h, w, c, heads, ws, shift, _s()), "frhip_winattn_bwd_colsum")
+        return dqkv, dbias, dscale, colsum
     check(lib().frhip_winattn_bwd(dt_of(qkv), _p(qkv), _p(dout), _p(bias), _p(scale), _p(dqkv), _p(dbias), _p(dscale),
                                   b, h, w, c, heads, ws, shift, _s()), "frhip_winattn_bwd")
     return dqkv, dbias, dscale

@@ -133,9 +133,11 @@ def attn_block_backward(blk, s, dout, dt, bc):
     ops.colsum_accumulate(dpo, G(at.proj.bias))
     bc.on_side(lambda: ops.gemm_tn(dpo, s.ao, G(at.proj.weight)), dpo, s.ao)
     dao = ops.gemm_nt(dpo, ops.transpose2d(s.wproj))
-    dqkv, dbias, dscale = ops.winattn_bwd(s.qkv, dao, s.bias, s.scale, b, h, w, at.num_heads, blk.window_size, blk.shift_size)
-    gsum = torch.zeros(3 * c, dtype=torch.float32, device=dout.device)
-    _S._colsum_via_gemm(dqkv, gsum)
+    dqkv, dbias, dscale, gsum = ops.winattn_bwd(s.qkv, dao, s.bias, s.scale, b, h, w, at.num_heads, blk.window_size,
+                                                blk.shift_size, want_colsum=True)
+    if gsum is None:                                 # fp32 validation kernels: column sums by a ones-GEMM
+        gsum = torch.zeros(3 * c, dtype=torch.float32, device=dout.device)
+        _S._colsum_via_gemm(dqkv, gsum)
     G(at.q_bias).add_(gsum[:c])
     G(at.v_bias).add_(gsum[2 * c:])
     bc.on_side(lambda: ops.gemm_tn(dqkv, s.x2, G(at.qkv.weight)), dqkv, s.x2)

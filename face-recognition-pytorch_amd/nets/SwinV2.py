@@ -163,9 +163,9 @@ def swin_block_backward(blk, s, dout, dt, bc):
     dmo = ops.bn_backward(d2, s.mo, s.st3, blk.norm3.weight.data, G(blk.norm3.weight), G(blk.norm3.bias))
     ops.colsum_accumulate(dmo, G(blk.mlp.fc2.bias))
     bc.on_side(lambda: ops.gemm_tn(dmo, s.act, G(blk.mlp.fc2.weight).view(c, 4 * c)), dmo, s.act)
-    dact = ops.gemm_nt(dmo, ops.transpose2d(s.w2))                 # [M, 4C]
-    dhid = ops.gelu_bwd(dact, s.hid)
-    _colsum_via_gemm(dhid, G(blk.mlp.fc1.bias))
+    # [M, 4C]: fc2's data-gradient with gelu'(hid) and fc1.bias's gradient (column sums) fused into its epilogue
+    dhid, db1 = ops.linear_dgrad_gelu(dmo, ops.transpose2d(s.w2), s.hid)
+    G(blk.mlp.fc1.bias).add_(db1)
     bc.on_side(lambda: ops.gemm_tn(dhid, s.x1, G(blk.mlp.fc1.weight).view(4 * c, c)), dhid, s.x1)
     dx1 = _dgrad_add(dhid, s.w1, d2)
     # ---- attention branch: x1 = x + BN(proj(attn(qkv(x))))
@@ -173,9 +173,10 @@ def swin_block_backward(blk, s, dout, dt, bc):
     ops.colsum_accumulate(dpo, G(at.proj.bias))
     bc.on_side(lambda: ops.gemm_tn(dpo, s.ao, G(at.proj.weight)), dpo, s.ao)
     dao = ops.gemm_nt(dpo, ops.transpose2d(s.wproj))
-    dqkv, dbias, dscale = ops.winattn_bwd(s.qkv, dao, s.bias, s.scale, b, h, w, at.num_heads)
-    gsum = torch.zeros(3 * c, dtype=torch.float32, device=dout.device)
-    _colsum_via_gemm(dqkv, gsum)
+    dqkv, dbias, dscale, gsum = ops.winattn_bwd(s.qkv, dao, s.bias, s.scale, b, h, w, at.num_heads, want_colsum=True)
+    if gsum is None:                                 # fp32 validation kernels: column sums by a ones-GEMM
+        gsum = torch.zeros(3 * c, dtype=torch.float32, device=dout.device)
+        _colsum_via_gemm(dqkv, gsum)
     G(at.q_bias).add_(gsum[:c])
     G(at.v_bias).add_(gsum[2 * c:])
     bc.on_side(lambda: ops.gemm_tn(dqkv, s.x2, G(at.qkv.weight)), dqkv, s.x2)

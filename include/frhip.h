@@ -94,6 +94,11 @@ int frhip_conv_wgrad(int dtype, const void* dy, const void* x, float* dw, int n,
  * stats_partial (may be NULL): per-tile BatchNorm partial sums of `out`, rows = frhip_conv_stat_rows(dtype, m, n, 1,1,k,1,1,1,0) */
 int frhip_linear_fwd(int dtype, const void* a, const void* w, const float* bias, void* out, void* act_out,
                      float* stats_partial, int m, int n, int k, frhip_stream_t stream);
+/* data-gradient of the Linear that feeds a GELU (Mlp.fc2 backward, nets/SwinV2.py:16-32): dx[m][n] = (dy[m][k] . wt[n][k]) *
+ * gelu'(pre[m][n]) with pre = the saved fc1 output; stats_partial (may be NULL, rows as frhip_linear_fwd): [.][0][n] sums to
+ * the column sums of dx = the gradient of fc1.bias */
+int frhip_linear_dgrad_gelu(int dtype, const void* dy, const void* wt, const void* pre, void* dx, float* stats_partial,
+                            int m, int n, int k, frhip_stream_t stream);
 /* out[m][n] = sum_k a[m][k]*b[n][k].  atomic_f32 = 0: out has `dtype`, overwritten (splits ignored);
  * atomic_f32 = 1: out is fp32, caller-zeroed, K is split `splits` ways and added atomically.  nn.Linear: nets/resnet.py:244 */
 int frhip_gemm_nt(int dtype, const void* a, const void* b, void* out, int m, int n, int k, int splits,
@@ -203,8 +208,13 @@ int frhip_winattn_fwd(int dtype, const void* qkv, const float* bias, const float
 int frhip_winattn_bwd(int dtype, const void* qkv, const void* dout, const float* bias, const float* scale,
                       void* dqkv, float* dbias, float* dscale, int b, int h, int w, int c, int heads,
                       int ws, int shift, frhip_stream_t stream);
+/* frhip_winattn_bwd that also accumulates dqkv_colsum[3c] (fp32, caller-zeroed) += column sums of the stored dqkv = the
+ * gradients of q_bias / v_bias (nets/SwinV2.py:150-154).  bf16 with the MFMA kernels only; FRHIP_EINVAL otherwise */
+int frhip_winattn_bwd_colsum(int dtype, const void* qkv, const void* dout, const float* bias, const float* scale,
+                             void* dqkv, float* dbias, float* dscale, float* dqkv_colsum, int b, int h, int w, int c,
+                             int heads, int ws, int shift, frhip_stream_t stream);
 /* 1 (default): bf16 calls run the MFMA-tile kernels (bf16 GEMM operands, fp32 scores / softmax -- the reference's autocast
- * numerics); 0: the fp32-arithmetic VALU kernels for every dtype.  Returns the old value */
+ * numerics); 0: the fp32-arithmetic VALU kernels for every dtype.  Negative: query.  Returns the old value */
 int frhip_set_winattn_mfma(int enabled);
 /* y[rows][c] += bias (in place); act_out (may be NULL) = gelu(y).  Mlp fc1 + GELU: nets/SwinV2.py:16-32 */
 int frhip_bias_gelu_fwd(int dtype, void* y, const float* bias, void* act_out, int rows, int c, frhip_stream_t stream);

@@ -272,6 +272,25 @@ def test_linear_fwd_fused_bias_gelu_stats(dtype, mnk):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("mnk", [(600, 256, 64), (5000, 512, 128), (300, 72, 64)])
+def test_linear_dgrad_gelu_fused(dtype, mnk):
+    """frhip_linear_dgrad_gelu = data-gradient GEMM * gelu'(saved pre-activation) + column sums, vs the separate kernels"""
+    ops = _ops()
+    m, n, k = mnk
+    dy, wt = q(rnd(41, (m, k)), dtype), q(rnd(42, (n, k), 0.2), dtype)
+    pre = q(rnd(43, (m, n)) * 1.5, dtype)
+    dx, colsum = ops.linear_dgrad_gelu(dy.to(dtype).cuda(), wt.to(dtype).cuda(), pre.to(dtype).cuda())
+    sep = ops.gelu_bwd(ops.gemm_nt(dy.to(dtype).cuda(), wt.to(dtype).cuda()), pre.to(dtype).cuda())
+    np.testing.assert_array_equal(dx.float().cpu().numpy(), sep.float().cpu().numpy())        # same arithmetic, same roundings
+    x = pre.clone().requires_grad_(True)
+    torch.nn.functional.gelu(x).backward(q(dy @ wt.t(), dtype))
+    t = tol(dtype, x.grad.abs().max().item())
+    np.testing.assert_allclose(dx.float().cpu().numpy(), x.grad.numpy(), **t)
+    want = dx.float().sum(0).cpu().numpy()
+    np.testing.assert_allclose(colsum.cpu().numpy(), want, rtol=1e-4, atol=1e-4 * np.abs(dx.float().cpu().numpy()).sum(0).max())
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("shape", [(96, 200, 208, 64), (1000, 128, 128, 512), (70, 24, 24, 32)])
 def test_gemm_tn(dtype, shape):
     ops = _ops()

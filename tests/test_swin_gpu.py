@@ -75,10 +75,14 @@ def test_window_attention_mfma_matches_valu_kernels(geom):
         old = lib().frhip_set_winattn_mfma(mode)
         try:
             out = ops.winattn_fwd(qkv, bias, scale, b, hw, hw, heads, ws=ws, shift=shift)
-            res[mode] = (out,) + ops.winattn_bwd(qkv, dout, bias, scale, b, hw, hw, heads, ws=ws, shift=shift)
+            res[mode] = (out,) + ops.winattn_bwd(qkv, dout, bias, scale, b, hw, hw, heads, ws=ws, shift=shift, want_colsum=True)
         finally:
             lib().frhip_set_winattn_mfma(old)
     torch.cuda.synchronize()
+    assert res[0][4] is None                      # the fp32-arithmetic kernels leave the column sums to the caller
+    colsum = res[1][4].cpu().numpy()              # fused q_bias / v_bias gradient = column sums of the STORED dqkv
+    stored = res[1][1].float().sum(0).cpu().numpy()
+    np.testing.assert_allclose(colsum, stored, rtol=1e-3, atol=1e-3 * np.abs(res[1][1].float().cpu().numpy()).sum(0).max())
     names = ("out", "dqkv", "dbias", "dscale")
     for name, a, r in zip(names, res[1], res[0]):
         a, r = a.float().cpu().numpy(), r.float().cpu().numpy()
