@@ -37,7 +37,7 @@ BATCH = 512
 def make_conf(args, rank, world):
     rate = 1.0 if world == 1 else 0.1            # cfg 2 (1 GPU, full head) / cfg 3 (PartialFC rate 0.1 over the node)
     return types.SimpleNamespace(
-        network=args.network, emd_size=512, img_size=112, local_rank=rank % max(torch.cuda.device_count(), 1),
+        network=args.network, emd_size=512, img_size=args.img_size, local_rank=rank % max(torch.cuda.device_count(), 1),
         world_size=world, sample_rate=rate, mixed_precision=True, loss_s=30.0, loss_m=0.35, n_classes=args.classes,
         optimizer="SGD", lr=0.1, wd=5e-4, mom=0.9, loss="PartialFC", lr_scheduler=None, frhip_dtype="bf16",
         ckpt_path=None)
@@ -141,10 +141,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=BATCH)
+    ap.add_argument("--batch", type=int, default=None, help="images per GPU (default 512; 256 for AlterNet50 @192, cfg 5)")
     ap.add_argument("--classes", type=int, default=NUM_CLASSES)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--network", default="ResNet50", help="ResNet50 (headline, BASELINE cfg 2/3) or Swin34 (cfg 4)")
+    ap.add_argument("--network", default="ResNet50",
+                    help="ResNet50 (headline, BASELINE cfg 2/3), Swin34 (cfg 4) or AlterNet50 (cfg 5 geometry: 192x192, bf16)")
     ap.add_argument("--graph", action="store_true",
                     help="replay the step as one HIP graph (default: eager launches; eager is GPU-bound at B=512 and "
                          "lets the side-stream weight-gradient GEMMs overlap the main stream)")
@@ -152,6 +153,9 @@ def main():
     ap.add_argument("--dist-path", action="store_true",
                     help="rehearse the N>1 code path (RCCL group, DDP wrap, PartialFC rate 0.1) in a 1-rank group")
     args = ap.parse_args()
+    args.img_size = 192 if args.network.startswith("AlterNet") else 112
+    if args.batch is None:
+        args.batch = 256 if args.network.startswith("AlterNet") else BATCH
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -185,7 +189,7 @@ def main():
     model = Model(conf, None, "train")
     model.sync_loss = False
     gen = torch.Generator().manual_seed(1234 + rank)
-    img = torch.randn((args.batch, 3, 112, 112), generator=gen).clamp_(-1, 1).cuda()
+    img = torch.randn((args.batch, 3, args.img_size, args.img_size), generator=gen).clamp_(-1, 1).cuda()
     ids = torch.randint(0, args.classes, (args.batch,), generator=gen).cuda()
     meter = ConvMeter(ops)
     log("model + synthetic batch ready (B=%d, classes=%d)" % (args.batch, args.classes))
@@ -225,17 +229,17 @@ def main():
         n, ms, fl = meter.measure()
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-        if os.path.exists(tpath):      # HBM bytes per launch of the same kernels from the committed rocprofv3 --pmc passes
+        if os.path.exists(tpath) and args.network == "ResNet50" and args.batch == BATCH:      # HBM bytes per launch of the same kernels from the committed rocprofv3 --pmc passes
             traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
         achieved = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         line = {
             "metric": "train imgs/sec IR-50-layout ResNet50 + ArcFace/PartialFC head, 112x112" if args.network == "ResNet50"
-                      else "train imgs/sec %s + ArcFace/PartialFC head, 112x112" % args.network,
+                      else "train imgs/sec %s + ArcFace/PartialFC head, %dx%d" % (args.network, args.img_size, args.img_size),
             "value": round(args.batch * world * args.steps / dt, 1), "unit": "imgs/sec", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "BASELINE cfg %d: %s+%s, %d ids, B=%d/GPU, SGD "
-                                   "mom 0.9 wd 5e-4, s=30 m=0.35" % ((2 if world == 1 else 3) if args.network == "ResNet50" else 4,
+                                   "mom 0.9 wd 5e-4, s=30 m=0.35" % ((2 if world == 1 else 3) if args.network == "ResNet50" else (5 if args.network.startswith("AlterNet") else 4),
                                                                      "ResNet50([3,4,14,4] BasicBlock)" if args.network == "ResNet50" else args.network,
                                                                      "ArcFace (PartialFC rate 1.0)" if conf.sample_rate >= 1 else "ArcFace (PartialFC rate %.1f)" % conf.sample_rate,
                                                                      args.classes, args.batch),
