@@ -236,6 +236,7 @@ static int head_geom(NtGeom& g, int dtype, int n, int cl, int d, const char* who
     g.H = 1; g.W = 1; g.C = d; g.Ho = 1; g.Wo = 1; g.R = 1; g.S = 1; g.stride = 1; g.pad = 0; g.mode = 0;
     g.M = n; g.Nout = cl; g.Ktot = d; g.ksteps = d / bke; g.ksteps_per_split = g.ksteps;
     g.a_bytes = (uint32_t)(1LL * n * d * es); g.b_bytes = (uint32_t)(1LL * cl * d * es);
+    g.par_a = -1; g.par_b = -1; g.hc = 0; g.wc = 0; g.par_r0 = 0; g.par_s0 = 0;
     return FRHIP_OK;
 }
 

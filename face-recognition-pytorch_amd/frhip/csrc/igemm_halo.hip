@@ -30,7 +30,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void halo_kernel(HaloG
     const int wm = wave / WN, wn = wave % WN;
     const int m0 = g.m_origin + mtile * Tile::BM + wm * Tile::WROWS, n0 = ntile * Tile::BN + wn * 64;
     EpiOperands<T, Tile::WROWS> eo;
-    eo.fetch(res, (stats || br.gelu_bwd) ? br.y : nullptr, g.M, g.Nout, m0, n0, br.res_h, br.res_w);
+    eo.fetch(res, (stats || br.gelu_bwd) ? br.y : nullptr, g.M, g.Nout, m0, n0, br.res_h, br.res_w, &br.map);
     const char* mine = ml.template stage_out<T>(smem);
     nt_epilogue_store<T, WM, WN, Tile::WROWS, Tile::THREADS, Tile::BN>(mine, Tile::template stage_pitch<T>(), smem, g.M, g.Nout,
                                                                        out, res != nullptr, stats, br, eo, g.stat_row0 + mtile, ntile, m0, n0);

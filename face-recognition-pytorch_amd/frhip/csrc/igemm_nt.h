@@ -26,6 +26,22 @@ struct NtGeom {
     int M, Nout, Ktot;      // GEMM sizes: rows, cols, taps*C
     int ksteps, ksteps_per_split;
     uint32_t a_bytes, b_bytes;
+    // stride-2 data-gradient, one PARITY CLASS per launch (par_a >= 0): the GEMM rows are the output pixels
+    // (2i + par_a, 2j + par_b), i < hc, j < wc, and only the taps that reach them (r = par_r0, par_r0 + 2, ...; likewise s)
+    // are walked -- the full-grid formulation multiplies 3 of 4 (row, tap) pairs by zeros.
+    int par_a, par_b, hc, wc, par_r0, par_s0;
+};
+
+// dense output row of GEMM row m (identity unless a parity class is active)
+struct OutMap {
+    int hc, wc, ho, wo, a, b;        // wc == 0: identity
+    __device__ __forceinline__ long long row(int m) const {
+        if (wc == 0) return m;
+        const int per = hc * wc;
+        const int img = m / per, rem = m - img * per;
+        const int i = rem / wc, j = rem - i * wc;
+        return ((long long)img * ho + 2 * i + a) * wo + 2 * j + b;
+    }
 };
 
 constexpr int NT_ROWB = 128;                 // bytes per LDS row = one K step
@@ -47,6 +63,7 @@ struct EpiBnRed {
     int res_h, res_w;
     // linear-layer epilogue (forward only, no BN-backward partials): out = gemm + bias[n], rounded to T and stored;
     // act (optional) = gelu(out) of the STORED value (exact erf form); forward statistics then describe out
+    OutMap map;
     const float* bias;
     void* act;
     // gelu_bwd != 0 (data-gradient of a Linear that feeds a GELU): out = gemm o gelu'(y), y = the saved pre-activation
@@ -106,14 +123,16 @@ struct NtMainloop {
         const int sub = lane >> 3;
         const uint32_t chunk_bytes = (uint32_t)(((lane & 7) ^ sub) * 16);
         RowSet<Tile::A_PIECES> ar;
-        const int HoWo = g.Ho * g.Wo;
+        const int rowlen = g.par_a >= 0 ? g.wc : g.Wo;
+        const int HoWo = g.par_a >= 0 ? g.hc * g.wc : g.Ho * g.Wo;
 #pragma unroll
         for (int j = 0; j < Tile::A_PIECES; ++j) {
             const int row = (wave * Tile::A_PIECES + j) * 8 + sub;
             const int m = mtile * BM + row;
             if (m < g.M) {
                 const int n = m / HoWo, rem = m - n * HoWo;
-                const int ho = rem / g.Wo, wo = rem - ho * g.Wo;
+                int ho = rem / rowlen, wo = rem - ho * rowlen;
+                if (g.par_a >= 0) { ho = 2 * ho + g.par_a; wo = 2 * wo + g.par_b; }
                 ar.pixbase[j] = n * g.H * g.W;
                 if (g.mode == 0) { ar.hb[j] = ho * g.stride - g.pad; ar.wb[j] = wo * g.stride - g.pad; }
                 else             { ar.hb[j] = ho + g.pad;            ar.wb[j] = wo + g.pad; }
@@ -134,6 +153,13 @@ struct NtMainloop {
         int tap = ks_begin / cchunks;
         int c0 = (ks_begin - tap * cchunks) * BKE;
         int fr = tap / g.S, fs = tap - fr * g.S;
+        const int tstep = g.par_a >= 0 ? 2 : 1, fs0 = g.par_a >= 0 ? g.par_s0 : 0;
+        if (g.par_a >= 0) {                                  // `tap` counted the class's taps: (ir, is) -> (r0 + 2ir, s0 + 2is)
+            const int ns = (g.S - g.par_s0 + 1) >> 1;
+            const int ir = tap / ns, is = tap - ir * ns;
+            fr = g.par_r0 + 2 * ir; fs = g.par_s0 + 2 * is;
+            tap = fr * g.S + fs;
+        }
 
         auto stage = [&](int buf) {
             char* sa = smem + buf * Tile::STAGE_BYTES;
@@ -162,7 +188,7 @@ struct NtMainloop {
             }
             // advance to the next K step
             c0 += BKE;
-            if (c0 == g.C) { c0 = 0; ++tap; ++fs; if (fs == g.S) { fs = 0; ++fr; } }
+            if (c0 == g.C) { c0 = 0; fs += tstep; if (fs >= g.S) { fs = fs0; fr += tstep; } tap = fr * g.S + fs; }
         };
 
         // fragment read addresses (bytes inside a stage): row = base + i, chunk (g + 4s) ^ (row & 7)
@@ -239,6 +265,7 @@ struct EpiOperands {
     const T* r; const T* y;
     int M, Nout, m0, n, rsub;
     int res_h, res_w;
+    OutMap map;
     // element index of residual row for output row m, or -1 when that pixel receives no residual
     __device__ __forceinline__ long long res_index(int m) const {
         if (res_w == 0) return (long long)m * Nout + n;
@@ -250,9 +277,10 @@ struct EpiOperands {
         return ((long long)(img * hc + (h >> 1)) * wc + (w >> 1)) * Nout + n;
     }
     __device__ __forceinline__ void fetch(const void* __restrict__ res, const void* __restrict__ ybn, int M_, int Nout_,
-                                          int m0_, int n0, int res_h_ = 0, int res_w_ = 0) {
+                                          int m0_, int n0, int res_h_ = 0, int res_w_ = 0, const OutMap* map_ = nullptr) {
         const int lane = lane_id();
         M = M_; Nout = Nout_; m0 = m0_; res_h = res_h_; res_w = res_w_;
+        if (map_) map = *map_; else map.wc = 0;
         n = n0 + (lane % LPR) * EPV; rsub = lane / LPR;
         r = reinterpret_cast<const T*>(res);
         y = reinterpret_cast<const T*>(ybn);
@@ -261,9 +289,9 @@ struct EpiOperands {
             for (int it = 0; it < ITERS; ++it) {
                 const int m = m0 + it * RPI + rsub;
                 const bool ok = m < M && n < Nout;
-                const size_t idx = (size_t)m * Nout + n;
+                const size_t idx = (size_t)map.row(m) * Nout + n;
                 if (r && ok) {
-                    const long long ri = res_index(m);
+                    const long long ri = res_index((int)map.row(m));
                     if (ri >= 0) rv[it] = *reinterpret_cast<const Vec16<T>*>(r + ri);
                     else {
 #pragma unroll
@@ -278,7 +306,7 @@ struct EpiOperands {
     __device__ __forceinline__ Vec16<T> res_row(int it) const {
         if constexpr (PRE) return rv[it];
         else {
-            const long long ri = res_index(m0 + it * RPI + rsub);
+            const long long ri = res_index((int)map.row(m0 + it * RPI + rsub));
             Vec16<T> z;
 #pragma unroll
             for (int e = 0; e < EPV; ++e) z.set(e, 0.f);
@@ -287,7 +315,7 @@ struct EpiOperands {
     }
     __device__ __forceinline__ Vec16<T> y_row(int it) const {
         if constexpr (PRE) return yv[it];
-        else return *reinterpret_cast<const Vec16<T>*>(y + (size_t)(m0 + it * RPI + rsub) * Nout + n);
+        else return *reinterpret_cast<const Vec16<T>*>(y + (size_t)map.row(m0 + it * RPI + rsub) * Nout + n);
     }
 };
 
@@ -330,7 +358,7 @@ __device__ __forceinline__ void nt_epilogue_store(const char* mine, int P, char*
 #pragma unroll
                     for (int e = 0; e < EPV; ++e) v.set(e, v.get(e) + rr.get(e));
                 }
-                *reinterpret_cast<Vec16<T>*>(o + (size_t)m * Nout + n) = v;
+                *reinterpret_cast<Vec16<T>*>(o + (size_t)br.map.row(m) * Nout + n) = v;
                 const Vec16<T> yr = ops.y_row(it);
 #pragma unroll
                 for (int e = 0; e < EPV; ++e) {
@@ -370,7 +398,8 @@ __device__ __forceinline__ void nt_epilogue_store(const char* mine, int P, char*
                         v.set(e, v.get(e) * (cdf + hh * pdf));
                     }
                 }
-                *reinterpret_cast<Vec16<T>*>(o + (size_t)m * Nout + n) = v;
+                const size_t orow = (size_t)br.map.row(m);
+                *reinterpret_cast<Vec16<T>*>(o + orow * Nout + n) = v;
                 if (ao) {
                     Vec16<T> ga;
 #pragma unroll
@@ -380,7 +409,7 @@ __device__ __forceinline__ void nt_epilogue_store(const char* mine, int P, char*
                         gelu_parts(hr, cdf, pdf);
                         ga.set(e, hr * cdf);
                     }
-                    *reinterpret_cast<Vec16<T>*>(ao + (size_t)m * Nout + n) = ga;
+                    *reinterpret_cast<Vec16<T>*>(ao + orow * Nout + n) = ga;
                 }
             }
 #pragma unroll

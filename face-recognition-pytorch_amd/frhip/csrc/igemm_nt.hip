@@ -35,7 +35,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void nt_kernel(NtGeom 
 
     if constexpr (EPI == EPI_STORE) {
         EpiOperands<T, WROWS> eo;
-        eo.fetch(res, (stats || br.gelu_bwd) ? br.y : nullptr, g.M, g.Nout, m0, n0, br.res_h, br.res_w);
+        eo.fetch(res, (stats || br.gelu_bwd) ? br.y : nullptr, g.M, g.Nout, m0, n0, br.res_h, br.res_w, &br.map);
         const char* mine = ml.template stage_out<T>(smem);
         nt_epilogue_store<T, WM, WN, WROWS, THREADS, Tile::BN>(mine, Tile::template stage_pitch<T>(), smem, g.M, g.Nout, out,
                                                                res != nullptr, stats, br, eo, mtile, ntile, m0, n0);
@@ -84,7 +84,7 @@ static int nt_pick_tile(int dtype, const NtGeom& g) {
     return 1;
 }
 
-static const EpiBnRed NO_BNRED = {nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, 0};
+static const EpiBnRed NO_BNRED = {nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, {0, 0, 0, 0, 0, 0}, nullptr, nullptr, 0};
 
 static int nt_dispatch(int dtype, const NtGeom& g, const void* a, const void* b, void* out, const void* res,
                        float* stats, const EpiBnRed& br, int splits, bool atomic, hipStream_t stream) {
@@ -131,7 +131,32 @@ static int fill_geom(NtGeom& g, int dtype, int n, int h, int w, int c, int ho, i
     g.M = n * ho * wo; g.Nout = k; g.Ktot = r * s * c;
     g.ksteps = r * s * (c / bke); g.ksteps_per_split = g.ksteps;
     g.a_bytes = (uint32_t)a_bytes; g.b_bytes = (uint32_t)b_bytes;
+    g.par_a = -1; g.par_b = -1; g.hc = 0; g.wc = 0; g.par_r0 = 0; g.par_s0 = 0;
     return FRHIP_OK;
+}
+
+// Stride-2 3x3 (pad 1) data-gradient as four parity-class launches (see NtGeom::par_a): 1 + 2 + 2 + 4 taps over a
+// quarter of the rows each, instead of 9 taps over all rows of which 3 in 4 gather only zeros.
+static bool dgrad_by_parity(const NtGeom& g) { return g.mode == 1 && g.stride == 2 && g.R == 3 && g.S == 3 && g.pad == 1; }
+
+static int nt_block_rows(int dtype, const NtGeom& g) {
+    static const int bm_of[5] = {128, 128, 256, 256, 256};
+    return bm_of[nt_pick_tile(dtype, g)];
+}
+
+// g: the full-grid geometry of the data-gradient.  Fills the geometry / output map of class (a, b); returns its row count
+static int parity_class(const NtGeom& g, int dtype, int a, int b, NtGeom& gc, OutMap& map) {
+    gc = g;
+    gc.par_a = a; gc.par_b = b;
+    gc.hc = (g.Ho - a + 1) / 2; gc.wc = (g.Wo - b + 1) / 2;
+    gc.par_r0 = (a + g.pad) & 1; gc.par_s0 = (b + g.pad) & 1;
+    const int nr = (g.R - gc.par_r0 + 1) / 2, ns = (g.S - gc.par_s0 + 1) / 2;
+    const int n_img = g.M / (g.Ho * g.Wo);
+    gc.M = n_img * gc.hc * gc.wc;
+    gc.ksteps = nr * ns * (g.C / (NT_ROWB / (dtype == FRHIP_DT_BF16 ? 2 : 4)));
+    gc.ksteps_per_split = gc.ksteps;
+    map.hc = gc.hc; map.wc = gc.wc; map.ho = g.Ho; map.wo = g.Wo; map.a = a; map.b = b;
+    return gc.M;
 }
 
 }  // namespace frhip
@@ -174,6 +199,17 @@ static int dgrad_run(int dtype, const void* dy, const void* wt, void* dx, const 
     if (rc) return rc;
     if (halo_applicable(dtype, h, wd, k, c, r, s, stride, pad))       // gathered tensor = dy [n,h,w,k] -> dx [n,h,w,c]
         return halo_run(dtype, dy, wt, dx, residual, stats, br, n, h, wd, k, c, -1, stream);
+    if (dgrad_by_parity(g)) {
+        float* st = stats;
+        for (int cls = 0; cls < 4; ++cls) {
+            NtGeom gc; EpiBnRed bc = br;
+            if (parity_class(g, dtype, cls >> 1, cls & 1, gc, bc.map) == 0) continue;
+            rc = nt_dispatch(dtype, gc, dy, wt, dx, residual, st, bc, 1, false, stream);
+            if (rc) return rc;
+            if (st) st += (size_t)((gc.M + nt_block_rows(dtype, gc) - 1) / nt_block_rows(dtype, gc)) * 2 * gc.Nout;
+        }
+        return FRHIP_OK;
+    }
     return nt_dispatch(dtype, g, dy, wt, dx, residual, stats, br, 1, false, stream);
 }
 
@@ -187,8 +223,17 @@ extern "C" int frhip_dgrad_stat_rows(int dtype, int n, int h, int wd, int c, int
     const int m = n * h * wd;
     if (halo_applicable(dtype, h, wd, k, c, r, s, stride, pad)) return halo_stat_rows(dtype, m, k, c);
     NtGeom g; g.M = m; g.Nout = c;
-    static const int bm_of[5] = {128, 128, 256, 256, 256};
-    const int bm = bm_of[nt_pick_tile(dtype, g)];
+    g.mode = 1; g.stride = stride; g.R = r; g.S = s; g.pad = pad; g.Ho = h; g.Wo = wd; g.C = k;
+    if (dgrad_by_parity(g)) {
+        int rows = 0;
+        for (int cls = 0; cls < 4; ++cls) {
+            NtGeom gc; OutMap map;
+            const int mc = parity_class(g, dtype, cls >> 1, cls & 1, gc, map);
+            rows += (mc + nt_block_rows(dtype, gc) - 1) / nt_block_rows(dtype, gc);
+        }
+        return rows;
+    }
+    const int bm = nt_block_rows(dtype, g);
     return (m + bm - 1) / bm;
 }
 
@@ -201,7 +246,7 @@ extern "C" int frhip_conv_dgrad_fused(int dtype, const void* dy, const void* wt,
         set_error("frhip_conv_dgrad_fused: y_bn needs mean, invstd and stats_partial");
         return FRHIP_EINVAL;
     }
-    EpiBnRed br = {y_bn, mean, invstd, mask_scale, mask_shift, 0, 0, nullptr, nullptr, 0};
+    EpiBnRed br = {y_bn, mean, invstd, mask_scale, mask_shift, 0, 0, {0, 0, 0, 0, 0, 0}, nullptr, nullptr, 0};
     if (residual && residual_stride == 2) { br.res_h = h; br.res_w = wd; }
     return dgrad_run(dtype, dy, wt, dx, residual, y_bn ? stats_partial : nullptr, br, n, h, wd, c, k, r, s, stride, pad, stream,
                      "frhip_conv_dgrad_fused");

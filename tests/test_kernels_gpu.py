@@ -165,7 +165,8 @@ def test_halo_tail_balancing_equals_single_launch(case):
 
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("case", [(3, 14, 64, 128, 1, True), (2, 28, 128, 128, 1, False), (2, 16, 64, 64, 2, True),
-                                  (5, 7, 256, 256, 1, True), (1, 9, 64, 64, 1, False)])
+                                  (5, 7, 256, 256, 1, True), (1, 9, 64, 64, 1, False),
+                                  (3, 9, 128, 64, 2, False), (2, 7, 64, 128, 2, True)])      # stride 2, odd sizes: parity classes
 def test_dgrad_epilogue_bn_backward_reduction(dtype, case):
     """conv_dgrad(bnred=...) = conv_dgrad followed by the stand-alone BN-backward reduction over (dx, y_bn)"""
     ops = _ops()
