@@ -3,6 +3,7 @@
 // Reference semantics: nn.BatchNorm2d / nn.BatchNorm1d defaults (eps 1e-5, momentum 0.1, biased batch variance
 // for normalisation, unbiased for running_var) as used by /root/reference/nets/resnet.py:81-86, :187, :196-199,
 // and the residual add of BasicBlock.forward (:89-103).
+#include <cstdlib>
 #include "common.h"
 #include "frhip.h"
 
@@ -161,7 +162,28 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __re
 // out = act( y*scale + shift  [+ res  |  + res*rscale + rshift] )
 // Each thread owns one 16-byte channel group for its whole life, so the per-channel vectors are read once into
 // registers and the row loop is pure streaming.
-template <typename T>
+// Streaming accesses of the element-wise passes.  Every operand of bn_apply / bn_bwd_apply is read exactly once, and the
+// producer wrote it a whole conv earlier: non-temporal loads (no allocation in L2 / the last-level cache on the way in)
+// are worth 0.45 ms of the 29.5-ms ResNet50 step (tools/nt_ab.sh, two passes: 30.54 / 30.67 -> 30.15 / 30.15 ms on one box,
+// 29.46 / 29.52 -> 29.06 / 29.10 on another).  A micro-benchmark that re-reads ONE buffer says the opposite for tensors
+// below ~100 MB (they sit in the 256-MB last-level cache between its iterations) -- the step is the judge.  Non-temporal
+// STORES measured neutral to slightly negative in the step (the consumer conv wants those lines).
+// g_ew_nt bits: 1 = non-temporal loads (residual / backward passes), 4 = also in the plain apply, 2 = non-temporal stores;
+// FRHIP_EW_NT_MB = smallest tensor (MB) that gets them.
+template <typename T, bool NT> __device__ __forceinline__ Vec16<T> ew_load(const T* p) {
+    Vec16<T> r;
+    if constexpr (NT) r.v = __builtin_nontemporal_load(reinterpret_cast<const decltype(r.v)*>(p));
+    else r = *reinterpret_cast<const Vec16<T>*>(p);
+    return r;
+}
+template <typename T, bool NT> __device__ __forceinline__ void ew_store(T* p, const Vec16<T>& x) {
+    if constexpr (NT) __builtin_nontemporal_store(x.v, reinterpret_cast<decltype(x.v)*>(p));
+    else *reinterpret_cast<Vec16<T>*>(p) = x;
+}
+static size_t EW_NT_BYTES = (size_t)(getenv("FRHIP_EW_NT_MB") ? atoi(getenv("FRHIP_EW_NT_MB")) : 0) << 20;
+static int g_ew_nt = getenv("FRHIP_EW_NT") ? atoi(getenv("FRHIP_EW_NT")) : 5;
+
+template <typename T, bool NTL, bool NTS>
 __global__ __launch_bounds__(EW_THREADS) void bn_apply_kernel(const T* __restrict__ y, const float* __restrict__ scale,
                                                               const float* __restrict__ shift, const T* __restrict__ res,
                                                               const float* __restrict__ rscale, const float* __restrict__ rshift,
@@ -178,9 +200,9 @@ __global__ __launch_bounds__(EW_THREADS) void bn_apply_kernel(const T* __restric
 #pragma unroll EW_UNROLL
     for (int r = blockIdx.x * rlanes + rl; r < rows; r += gridDim.x * rlanes) {
         const size_t idx = (size_t)r * C + cg * EPV;
-        Vec16<T> a = *reinterpret_cast<const Vec16<T>*>(y + idx);
+        Vec16<T> a = ew_load<T, NTL>(y + idx);
         if (res) {
-            const Vec16<T> rv = *reinterpret_cast<const Vec16<T>*>(res + idx);
+            const Vec16<T> rv = ew_load<T, NTL>(res + idx);
 #pragma unroll
             for (int e = 0; e < EPV; ++e) {
                 float o = a.get(e) * sc[e] + sh[e] + (rv.get(e) * rs[e] + rb[e]);
@@ -193,12 +215,12 @@ __global__ __launch_bounds__(EW_THREADS) void bn_apply_kernel(const T* __restric
                 a.set(e, relu ? fmaxf(o, 0.f) : o);
             }
         }
-        *reinterpret_cast<Vec16<T>*>(out + idx) = a;
+        ew_store<T, NTS>(out + idx, a);
     }
 }
 
 // dy = ca * d_eff + cb * y + cc,  d_eff = dout * mask
-template <typename T>
+template <typename T, bool NTL, bool NTS>
 __global__ __launch_bounds__(EW_THREADS) void bn_bwd_apply_kernel(const T* __restrict__ dout, const T* __restrict__ y,
                                                                   const float* __restrict__ ca, const float* __restrict__ cb,
                                                                   const float* __restrict__ cc, const float* __restrict__ mscale,
@@ -216,15 +238,15 @@ __global__ __launch_bounds__(EW_THREADS) void bn_bwd_apply_kernel(const T* __res
 #pragma unroll EW_UNROLL
     for (int r = blockIdx.x * rlanes + rl; r < rows; r += gridDim.x * rlanes) {
         const size_t idx = (size_t)r * C + cg * EPV;
-        const Vec16<T> d = *reinterpret_cast<const Vec16<T>*>(dout + idx);
-        Vec16<T> b = *reinterpret_cast<const Vec16<T>*>(y + idx);
+        const Vec16<T> d = ew_load<T, NTL>(dout + idx);
+        Vec16<T> b = ew_load<T, NTL>(y + idx);
 #pragma unroll
         for (int e = 0; e < EPV; ++e) {
             const float yy = b.get(e);
             const float de = (yy * ms[e] + mb[e] > 0.f) ? d.get(e) : 0.f;
             b.set(e, a_[e] * de + b_[e] * yy + c_[e]);
         }
-        *reinterpret_cast<Vec16<T>*>(dy + idx) = b;
+        ew_store<T, NTS>(dy + idx, b);
     }
 }
 
@@ -377,12 +399,17 @@ extern "C" int frhip_bn_apply(int dtype, const void* y, const float* scale, cons
                               hipStream_t stream) {
     if (!shape_ok(dtype, c, "frhip_bn_apply")) return FRHIP_EINVAL;
     const int blocks = ew_row_blocks(rows, c, dtype);
-    if (dtype == FRHIP_DT_BF16)
-        hipLaunchKernelGGL(bn_apply_kernel<bf16_t>, dim3(blocks), dim3(EW_THREADS), 0, stream, (const bf16_t*)y, scale,
-                           shift, (const bf16_t*)res, res_scale, res_shift, relu, (bf16_t*)out, rows, c);
-    else
-        hipLaunchKernelGGL(bn_apply_kernel<float>, dim3(blocks), dim3(EW_THREADS), 0, stream, (const float*)y, scale,
-                           shift, (const float*)res, res_scale, res_shift, relu, (float*)out, rows, c);
+    const size_t bytes = (size_t)rows * c * (dtype == FRHIP_DT_BF16 ? 2 : 4);
+    const bool ntl = (g_ew_nt & 1) && bytes >= EW_NT_BYTES && (res != nullptr || (g_ew_nt & 4)), nts = (g_ew_nt & 2) && bytes >= EW_NT_BYTES / 2;
+#define BN_APPLY_GO(T, L, S)                                                                                                  \
+    hipLaunchKernelGGL((bn_apply_kernel<T, L, S>), dim3(blocks), dim3(EW_THREADS), 0, stream, (const T*)y, scale, shift,     \
+                       (const T*)res, res_scale, res_shift, relu, (T*)out, rows, c)
+#define BN_APPLY_PICK(T)                                                                                                      \
+    do { if (ntl && nts) BN_APPLY_GO(T, true, true); else if (ntl) BN_APPLY_GO(T, true, false);                               \
+         else if (nts) BN_APPLY_GO(T, false, true); else BN_APPLY_GO(T, false, false); } while (0)
+    if (dtype == FRHIP_DT_BF16) BN_APPLY_PICK(bf16_t); else BN_APPLY_PICK(float);
+#undef BN_APPLY_PICK
+#undef BN_APPLY_GO
     return check_launch("frhip_bn_apply");
 }
 
@@ -391,12 +418,17 @@ extern "C" int frhip_bn_bwd_apply(int dtype, const void* dout, const void* y, co
                                   int rows, int c, hipStream_t stream) {
     if (!shape_ok(dtype, c, "frhip_bn_bwd_apply")) return FRHIP_EINVAL;
     const int blocks = ew_row_blocks(rows, c, dtype);
-    if (dtype == FRHIP_DT_BF16)
-        hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(blocks), dim3(EW_THREADS), 0, stream, (const bf16_t*)dout,
-                           (const bf16_t*)y, ca, cb, cc, mask_scale, mask_shift, (bf16_t*)dy, rows, c);
-    else
-        hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(blocks), dim3(EW_THREADS), 0, stream, (const float*)dout,
-                           (const float*)y, ca, cb, cc, mask_scale, mask_shift, (float*)dy, rows, c);
+    const size_t bytes = (size_t)rows * c * (dtype == FRHIP_DT_BF16 ? 2 : 4);
+    const bool ntl = (g_ew_nt & 1) && bytes >= EW_NT_BYTES, nts = (g_ew_nt & 2) && bytes >= EW_NT_BYTES / 2;
+#define BN_BWD_GO(T, L, S)                                                                                                    \
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<T, L, S>), dim3(blocks), dim3(EW_THREADS), 0, stream, (const T*)dout, (const T*)y, \
+                       ca, cb, cc, mask_scale, mask_shift, (T*)dy, rows, c)
+#define BN_BWD_PICK(T)                                                                                                        \
+    do { if (ntl && nts) BN_BWD_GO(T, true, true); else if (ntl) BN_BWD_GO(T, true, false);                                   \
+         else if (nts) BN_BWD_GO(T, false, true); else BN_BWD_GO(T, false, false); } while (0)
+    if (dtype == FRHIP_DT_BF16) BN_BWD_PICK(bf16_t); else BN_BWD_PICK(float);
+#undef BN_BWD_PICK
+#undef BN_BWD_GO
     return check_launch("frhip_bn_bwd_apply");
 }
 
