@@ -34,8 +34,10 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, uint3
 constexpr uint32_t OOB_OFFSET = 0x80000000u;   // >= any num_records we use (< 2 GiB per tensor)
 
 // 16 bytes per lane, global -> LDS without touching VGPRs.  LDS dest = lds_base + lane*16.
+// AUX = cache policy bits of the buffer instruction (gfx950: 1 = sc0, 2 = nt, 16 = sc1)
+template <int AUX = 0>
 __device__ __forceinline__ void glds16(__amdgpu_buffer_rsrc_t rsrc, void* lds_base, uint32_t voff) {
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_ADDR(lds_base), 16, voff, 0, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_ADDR(lds_base), 16, voff, 0, 0, AUX);
 }
 
 // ---- element <-> float

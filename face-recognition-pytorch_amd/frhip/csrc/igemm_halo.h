@@ -13,6 +13,9 @@
 // `s_waitcnt vmcnt(PIECES)` + one raw s_barrier per iteration retires exactly the previous iteration's loads and
 // leaves the current iteration's in flight across the barrier.
 #pragma once
+#ifndef HALO_A_AUX
+#define HALO_A_AUX 0      // cache policy of the activation-window loads (experiment switch)
+#endif
 #include <type_traits>
 #include "igemm_nt.h"
 
@@ -88,7 +91,7 @@ struct HaloMainloop {
             const int r = piece * 8 + sub;
             const int p = p_lo + r;
             const uint32_t off = (p >= 0 && p < g.M) ? (uint32_t)(p * g.C + c0) * (uint32_t)sizeof(T) + chunk_bytes : OOB_OFFSET;
-            glds16(ra, smem + hb * Tile::HALO_BYTES + piece * 1024, off);
+            glds16<HALO_A_AUX>(ra, smem + hb * Tile::HALO_BYTES + piece * 1024, off);
         };
         uint32_t brow_off[Tile::B_PIECES];
 #pragma unroll

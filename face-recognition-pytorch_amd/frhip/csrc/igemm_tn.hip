@@ -11,6 +11,10 @@
 #include "common.h"
 #include "frhip.h"
 
+#ifndef T9_AUX
+#define T9_AUX 0          // cache policy of the nine-tap kernel's operand loads (experiment switch)
+#endif
+
 namespace frhip {
 
 struct TnGeom {
@@ -466,12 +470,12 @@ void tn_taps9_kernel(TnGeom g, const void* __restrict__ p_ptr, const void* __res
         char* sq = sp + Cfg::P_BYTES;
 #pragma unroll
         for (int j = 0; j < Cfg::P_PIECES; ++j) {
-            glds16(rp, sp + (wave * Cfg::P_PIECES + j) * 1024, okp[j] ? offp[j] : OOB_OFFSET);
+            glds16<T9_AUX>(rp, sp + (wave * Cfg::P_PIECES + j) * 1024, okp[j] ? offp[j] : OOB_OFFSET);
             offp[j] += incp;
         }
 #pragma unroll
         for (int j = 0; j < Cfg::QPW_MAX; ++j) {
-            if (j < qpw) glds16(rq, sq + (wave + Cfg::NW * j) * 1024, okq[j] ? offq[j] : OOB_OFFSET);
+            if (j < qpw) glds16<T9_AUX>(rq, sq + (wave + Cfg::NW * j) * 1024, okq[j] ? offq[j] : OOB_OFFSET);
             offq[j] += incq;
         }
     };
