@@ -17,6 +17,18 @@
 
 namespace frhip {
 
+// Workgroup -> (output tile, K split).  All output tiles of ONE K split read the same pixel range of both operands (each
+// tile its own channel slice), so they should run at the same time on the same XCD and share its L2.  A (tiles, splits)
+// grid does the opposite: linear id % 8 picks the XCD, so with 8 tiles per split every XCD sees ONE tile of every split
+// and re-reads its operand slices from HBM (PMC: 280 MB fetched per 256-channel weight-gradient launch against 103 MB of
+// operands).  One-dimensional grid, XCD-remapped, tile fastest: consecutive ids of one XCD = the tiles of one split.
+struct TnSlot { int tile, split; };
+__device__ __forceinline__ TnSlot tn_slot(int ntiles) {
+    const uint32_t lin = xcd_remap(blockIdx.x, gridDim.x);
+    TnSlot s; s.split = (int)(lin / (uint32_t)ntiles); s.tile = (int)(lin - (uint32_t)s.split * (uint32_t)ntiles);
+    return s;
+}
+
 struct TnGeom {
     int H, W, C;             // Q tensor
     int Ho, Wo, R, S, stride, pad;
@@ -85,7 +97,7 @@ template <int RB> struct TnFrag<float, RB> {
 
 template <typename T, int RB, int NT>
 __device__ __forceinline__ void tn_epilogue(f32x4_t (&acc)[NT][NT], char* smem, float* __restrict__ out,
-                                            const TnGeom& g, int co0, int ci0, int tap, int taps) {
+                                            const TnGeom& g, int co0, int ci0, int tap, int taps, int split) {
     typedef TnTile<T, RB> Tile;
     static_assert(NT == Tile::NT, "accumulator shape");
     const int lane = lane_id(), wave = wave_id();
@@ -113,7 +125,7 @@ __device__ __forceinline__ void tn_epilogue(f32x4_t (&acc)[NT][NT], char* smem, 
         if (co < g.Kc && ci < g.C) {
             const float v = *reinterpret_cast<const float*>(mine + row * P + col * 4);
             const size_t idx = ((size_t)co * taps + tap) * g.C + ci;
-            if (g.slab_stride) out[(size_t)blockIdx.y * g.slab_stride + idx] = v;     // private slab: plain coalesced store
+            if (g.slab_stride) out[(size_t)split * g.slab_stride + idx] = v;     // private slab: plain coalesced store
             else atomicAdd(out + idx, v);
         }
     }
@@ -128,11 +140,12 @@ __global__ __launch_bounds__(TN_THREADS, 2) void tn_kernel(TnGeom g, const void*
     constexpr int NT = Tile::NT;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = lane_id(), wave = wave_id();
-    uint32_t lin = xcd_remap(blockIdx.x, gridDim.x);
+    const TnSlot slot = tn_slot(co_tiles * ci_tiles * taps);
+    uint32_t lin = (uint32_t)slot.tile;
     const int tap = (int)(lin % (uint32_t)taps); lin /= (uint32_t)taps;
     const int ci_tile = (int)(lin % (uint32_t)ci_tiles), co_tile = (int)(lin / (uint32_t)ci_tiles);
     const int fr = tap / g.S, fs = tap - fr * g.S;
-    const int ks_begin = blockIdx.y * g.ksteps_per_split;
+    const int ks_begin = slot.split * g.ksteps_per_split;
     const int ks_end = min(g.ksteps, ks_begin + g.ksteps_per_split);
     const int wco = wave >> 1, wci = wave & 1;
 
@@ -227,7 +240,7 @@ __global__ __launch_bounds__(TN_THREADS, 2) void tn_kernel(TnGeom g, const void*
         compute(cur);
     }
 
-    tn_epilogue<T, RB, NT>(acc, smem, out, g, co0, ci0, tap, taps);
+    tn_epilogue<T, RB, NT>(acc, smem, out, g, co0, ci0, tap, taps, slot.split);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -247,12 +260,13 @@ __global__ __launch_bounds__(TN_THREADS, 2) void tn_lin_kernel(TnGeom g, const v
     constexpr int ZERO_OFF = 2 * Tile::STAGE_BYTES;          // 16 zero bytes behind the two stages
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = lane_id(), wave = wave_id();
-    uint32_t lin = xcd_remap(blockIdx.x, gridDim.x);
+    const TnSlot slot = tn_slot(co_tiles * ci_tiles * taps);
+    uint32_t lin = (uint32_t)slot.tile;
     const int tap = (int)(lin % (uint32_t)taps); lin /= (uint32_t)taps;
     const int ci_tile = (int)(lin % (uint32_t)ci_tiles), co_tile = (int)(lin / (uint32_t)ci_tiles);
     const int dy = tap / g.S - g.pad, dx = tap % g.S - g.pad;
     const int shift = dy * g.W + dx;
-    const int ks_begin = blockIdx.y * g.ksteps_per_split;
+    const int ks_begin = slot.split * g.ksteps_per_split;
     const int ks_end = min(g.ksteps, ks_begin + g.ksteps_per_split);
     const int wco = wave >> 1, wci = wave & 1;
 
@@ -368,7 +382,7 @@ __global__ __launch_bounds__(TN_THREADS, 2) void tn_lin_kernel(TnGeom g, const v
         }
         compute(cur);
     }
-    tn_epilogue<T, RB, NT>(acc, smem, out, g, co0, ci0, tap, taps);
+    tn_epilogue<T, RB, NT>(acc, smem, out, g, co0, ci0, tap, taps, slot.split);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -425,9 +439,10 @@ void tn_taps9_kernel(TnGeom g, const void* __restrict__ p_ptr, const void* __res
     typedef T9Cfg<WCO, WCI, COF, CIF> Cfg;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = lane_id(), wave = wave_id();
-    const uint32_t lin = xcd_remap(blockIdx.x, gridDim.x);
+    const TnSlot slot = tn_slot(co_tiles * ci_tiles);
+    const uint32_t lin = (uint32_t)slot.tile;
     const int ci_tile = (int)(lin % (uint32_t)ci_tiles), co_tile = (int)(lin / (uint32_t)ci_tiles);
-    const int ks_begin = blockIdx.y * g.ksteps_per_split;
+    const int ks_begin = slot.split * g.ksteps_per_split;
     const int ks_end = min(g.ksteps, ks_begin + g.ksteps_per_split);
     const int wco = wave / WCI, wci = wave % WCI;
     const int co0 = co_tile * Cfg::CO_T, ci0 = ci_tile * 64;
@@ -625,7 +640,7 @@ void tn_taps9_kernel(TnGeom g, const void* __restrict__ p_ptr, const void* __res
             return;
         }
     }
-    float* dst = out + (g.slab_stride ? (size_t)blockIdx.y * g.slab_stride : 0);
+    float* dst = out + (g.slab_stride ? (size_t)slot.split * g.slab_stride : 0);
 #pragma unroll
     for (int a = 0; a < COF; ++a)
 #pragma unroll
@@ -661,7 +676,7 @@ static int tn_taps9_launch(const TnGeom& g, const void* p, const void* q, float*
         }
         attr_done = true;
     }
-    hipLaunchKernelGGL(kern, dim3(co_tiles * ci_tiles, splits), dim3(64 * Cfg::NW), Cfg::LDS, stream, g, p, q, out, co_tiles, ci_tiles);
+    hipLaunchKernelGGL(kern, dim3(co_tiles * ci_tiles * splits), dim3(64 * Cfg::NW), Cfg::LDS, stream, g, p, q, out, co_tiles, ci_tiles);
     return check_launch("igemm_tn(taps9)");
 }
 
@@ -708,7 +723,7 @@ static int tn_lin_launch(const TnGeom& g, const void* p, const void* q, float* o
         }
         attr_done = true;
     }
-    dim3 grid(co_tiles * ci_tiles * taps, splits);
+    dim3 grid(co_tiles * ci_tiles * taps * splits);
     hipLaunchKernelGGL(kern, grid, dim3(TN_THREADS), lds, stream, g, p, q, out, co_tiles, ci_tiles, taps);
     return check_launch("igemm_tn(lin)");
 }
@@ -726,7 +741,7 @@ static int tn_launch(const TnGeom& g, const void* p, const void* q, float* out, 
         }
         attr_done = true;
     }
-    dim3 grid(co_tiles * ci_tiles * taps, splits);
+    dim3 grid(co_tiles * ci_tiles * taps * splits);
     hipLaunchKernelGGL(kern, grid, dim3(TN_THREADS), Tile::LDS_BYTES, stream, g, p, q, out, co_tiles, ci_tiles, taps);
     return check_launch("igemm_tn");
 }
