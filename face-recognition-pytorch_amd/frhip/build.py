@@ -1,4 +1,5 @@
 """Build libfrhip.so (gfx950 only) in-tree with hipcc.  No JIT cache: the .so travels with the repo snapshot."""
+import hashlib
 import os
 import subprocess
 import sys
@@ -13,11 +14,22 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-munsafe-fp-ato
          "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
 
 
+def _digest(paths):
+    """content hash of the inputs of one object (source, every header, the flags): a snapshot copy may scramble mtimes"""
+    h = hashlib.sha1(" ".join(FLAGS).replace(ROOT, "").encode())
+    for p in sorted(paths):
+        h.update(os.path.basename(p).encode())
+        with open(p, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
 def _stale(target, deps):
-    if not os.path.exists(target):
+    stamp = target + ".sha1"
+    if not os.path.exists(target) or not os.path.exists(stamp):
         return True
-    t = os.path.getmtime(target)
-    return any(os.path.getmtime(d) > t for d in deps)
+    with open(stamp) as f:
+        return f.read().strip() != _digest(deps)
 
 
 def build(force=False, verbose=False):
@@ -35,11 +47,13 @@ def build(force=False, verbose=False):
             cmd = [HIPCC] + FLAGS + ["-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd))
-            procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
-    for src, p in procs:
+            procs.append((src, o, [s] + headers, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    for src, o, deps, p in procs:
         out, _ = p.communicate()
         if p.returncode != 0:
             raise RuntimeError("hipcc failed on %s:\n%s" % (src, out.decode(errors="replace")))
+        with open(o + ".sha1", "w") as f:
+            f.write(_digest(deps))
     if force or procs or not os.path.exists(LIB):
         cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
         r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
