@@ -97,10 +97,7 @@ def attn_block_forward(blk, x, dt, training, save):
     wqkv = _S._w2d(at.qkv, dt)
     qb = torch.cat([at.q_bias.data, torch.zeros_like(at.v_bias.data), at.v_bias.data])
     qkv, _, _ = ops.linear_fwd(x2, wqkv, qb)                                  # bias add in the GEMM epilogue
-    with torch.enable_grad():
-        cpb = [p.detach().requires_grad_(True) for p in at.cpb_params()]
-        bias_t, scale_t = at.bias_and_scale(cpb)
-    bias, scale = bias_t.detach().contiguous(), scale_t.detach().contiguous()
+    cpb, bias_t, scale_t, bias, scale, cpb_on_side = _S.position_bias(blk)
     ao = ops.winattn_fwd(qkv, bias, scale, b, h, w, at.num_heads, blk.window_size, blk.shift_size)
     wproj = _S._w2d(at.proj, dt)
     po, _, part2 = ops.linear_fwd(ao, wproj, at.proj.bias.data, want_stats=training)   # + norm2's batch statistics
@@ -119,6 +116,7 @@ def attn_block_forward(blk, x, dt, training, save):
         s = Saved()
         (s.x2, s.wqkv, s.qkv, s.cpb, s.bias_t, s.scale_t, s.bias, s.scale, s.ao, s.wproj, s.po, s.st2, s.keep, s.shape) = (
             x2, wqkv, qkv, cpb, bias_t, scale_t, bias, scale, ao, wproj, po, st2, keep, (b, h, w, c))
+        s.cpb_on_side = cpb_on_side
     return out, s
 
 
@@ -142,9 +140,7 @@ def attn_block_backward(blk, s, dout, dt, bc):
     G(at.v_bias).add_(gsum[2 * c:])
     bc.on_side(lambda: ops.gemm_tn(dqkv, s.x2, G(at.qkv.weight)), dqkv, s.x2)
     dx = _S._dgrad_add(dqkv, s.wqkv, d2)
-    gs = torch.autograd.grad([s.bias_t, s.scale_t], s.cpb, [dbias, dscale])
-    for p, g in zip(at.cpb_params(), gs):
-        G(p).add_(g.reshape(p.shape))
+    _S.position_bias_backward(blk, s, dbias, dscale, bc)
     return dx.view(b, h, w, c)
 
 
@@ -202,9 +198,11 @@ class AlterNet(nn.Module):
     def _forward_impl(self, x, training, save):
         dt = self.dtype
         sv = Saved() if save else None
+        layers = list(self._layers())
+        if training and save:
+            _S.precompute_position_bias([m for m in layers if not isinstance(m, BasicBlock)], x.device)
         cur = stem_forward(self, x, training, sv)
         saved = []
-        layers = list(self._layers())
         convs = [c for b in layers if isinstance(b, BasicBlock)
                  for c in ((b.conv1, b.conv2) + ((b.downsample[0],) if b.downsample is not None else ()))]
         wprep = prepare_conv_weights(convs, dt) if convs else None

@@ -18,6 +18,7 @@ Underneath (window_size 7, shift 0 -- the only configuration the reference can r
 The whole backbone is one autograd node (nets/_backbone.EncoderFn).  No CPU fallback.
 """
 import math
+import os
 
 import numpy as np
 import torch
@@ -112,6 +113,60 @@ def _colsum_via_gemm(x2d, out_accum):
     out_accum += tmp[:, 0]
 
 
+def precompute_position_bias(attn_blocks, device):
+    """The 169-entry continuous-position-bias MLP and the logit scale of every attention block depend on parameters only
+    (nets/SwinV2.py:150-158): ~8 tiny ATen launches per block forward and ~12 backward.  In a training step they run on the
+    side stream -- forward for all blocks up front (behind the stem), backward deferred behind the weight gradients -- so
+    they stay off the main stream's critical path.  Stashes (cpb, bias_t, scale_t, bias, scale, ready-event) on the block."""
+    from ._backbone import side_stream, _OVERLAP_WGRAD
+    if not _OVERLAP_WGRAD or os.environ.get("FRHIP_CPB_SIDE", "1") != "1":
+        return
+    main, side = torch.cuda.current_stream(device), side_stream(device)
+    side.wait_stream(main)                        # the optimizer's parameter update of the previous step
+    with torch.cuda.stream(side):
+        for blk in attn_blocks:
+            at = blk.attn
+            with torch.enable_grad():
+                cpb = [p.detach().requires_grad_(True) for p in at.cpb_params()]
+                bias_t, scale_t = at.bias_and_scale(cpb)
+            bias, scale = bias_t.detach().contiguous(), scale_t.detach().contiguous()
+            for t in (bias, scale):
+                t.record_stream(main)
+            ev = torch.cuda.Event()
+            ev.record(side)
+            blk._cpb_ready = (cpb, bias_t, scale_t, bias, scale, ev)
+
+
+def position_bias(blk):
+    """(cpb leaves, bias_t, scale_t, bias, scale, on_side): precomputed on the side stream when available, else inline"""
+    at = blk.attn
+    pre = getattr(blk, "_cpb_ready", None)
+    if pre is not None:
+        blk._cpb_ready = None
+        cpb, bias_t, scale_t, bias, scale, ev = pre
+        torch.cuda.current_stream(bias.device).wait_event(ev)
+        return cpb, bias_t, scale_t, bias, scale, True
+    with torch.enable_grad():
+        cpb = [p.detach().requires_grad_(True) for p in at.cpb_params()]
+        bias_t, scale_t = at.bias_and_scale(cpb)
+    return cpb, bias_t, scale_t, bias_t.detach().contiguous(), scale_t.detach().contiguous(), False
+
+
+def position_bias_backward(blk, s, dbias, dscale, bc):
+    """d(bias table), d(logit scale) -> the position-bias MLP's parameters (parameter-space torch autograd).  Autograd runs a
+    node on the stream of its forward op, so the graph built on the side stream is differentiated there as well."""
+    at = blk.attn
+
+    def run():
+        gs = torch.autograd.grad([s.bias_t, s.scale_t], s.cpb, [dbias, dscale])
+        for p, g in zip(at.cpb_params(), gs):
+            bc.G(p).add_(g.reshape(p.shape))
+    if getattr(s, "cpb_on_side", False):
+        bc.on_side(run, dbias, dscale, s.bias_t, s.scale_t)
+    else:
+        run()
+
+
 def swin_block_forward(blk, x, dt, training, save):
     b, h, w, c = x.shape
     m = b * h * w
@@ -120,10 +175,7 @@ def swin_block_forward(blk, x, dt, training, save):
     wqkv = _w2d(at.qkv, dt)
     qb = torch.cat([at.q_bias.data, torch.zeros_like(at.v_bias.data), at.v_bias.data])
     qkv, _, _ = ops.linear_fwd(x2, wqkv, qb)                                  # bias add in the GEMM epilogue
-    with torch.enable_grad():
-        cpb = [p.detach().requires_grad_(True) for p in at.cpb_params()]
-        bias_t, scale_t = at.bias_and_scale(cpb)
-    bias, scale = bias_t.detach().contiguous(), scale_t.detach().contiguous()
+    cpb, bias_t, scale_t, bias, scale, cpb_on_side = position_bias(blk)
     ao = ops.winattn_fwd(qkv, bias, scale, b, h, w, at.num_heads)
     wproj = _w2d(at.proj, dt)
     po, _, part2 = ops.linear_fwd(ao, wproj, at.proj.bias.data, want_stats=training)   # + norm2's batch statistics
@@ -141,6 +193,7 @@ def swin_block_forward(blk, x, dt, training, save):
         (s.x2, s.wqkv, s.qkv, s.cpb, s.bias_t, s.scale_t, s.bias, s.scale, s.ao, s.wproj, s.po, s.st2, s.x1, s.w1, s.hid,
          s.act, s.w2, s.mo, s.st3, s.shape) = (x2, wqkv, qkv, cpb, bias_t, scale_t, bias, scale, ao, wproj, po, st2, x1, w1,
                                                 hid, act, w2, mo, st3, (b, h, w, c))
+        s.cpb_on_side = cpb_on_side
     return out, s
 
 
@@ -182,9 +235,7 @@ def swin_block_backward(blk, s, dout, dt, bc):
     bc.on_side(lambda: ops.gemm_tn(dqkv, s.x2, G(at.qkv.weight)), dqkv, s.x2)
     dx = _dgrad_add(dqkv, s.wqkv, dx1)
     # ---- the 169-entry position-bias MLP and the logit scale (parameter space, torch autograd)
-    gs = torch.autograd.grad([s.bias_t, s.scale_t], s.cpb, [dbias, dscale])
-    for p, g in zip(at.cpb_params(), gs):
-        G(p).add_(g.reshape(p.shape))
+    position_bias_backward(blk, s, dbias, dscale, bc)
     return dx.view(b, h, w, c)
 
 
@@ -231,6 +282,8 @@ class Swin(nn.Module):
     def _forward_impl(self, x, training, save):
         dt = self.dtype
         sv = Saved() if save else None
+        if training and save:
+            precompute_position_bias([m for m in self._layers() if not isinstance(m, _Conv)], x.device)
         cur = stem_forward(self, x, training, sv)
         saved = []
         for mod in self._layers():
