@@ -89,17 +89,17 @@ class SwinTransformerBlock(nn.Module):
         self.norm2 = _BN(dim)
 
 
-def attn_block_forward(blk, x, dt, training, save):
+def attn_block_forward(blk, x, dt, training, save, wprep=None):
     b, h, w, c = x.shape
     m = b * h * w
     at = blk.attn
     x2 = x.view(m, c)
-    wqkv = _S._w2d(at.qkv, dt)
+    wqkv, wqkv_t = _S._lin_operands(at.qkv, dt, wprep)
     qb = torch.cat([at.q_bias.data, torch.zeros_like(at.v_bias.data), at.v_bias.data])
     qkv, _, _ = ops.linear_fwd(x2, wqkv, qb)                                  # bias add in the GEMM epilogue
     cpb, bias_t, scale_t, bias, scale, cpb_on_side = _S.position_bias(blk)
     ao = ops.winattn_fwd(qkv, bias, scale, b, h, w, at.num_heads, blk.window_size, blk.shift_size)
-    wproj = _S._w2d(at.proj, dt)
+    wproj, wproj_t = _S._lin_operands(at.proj, dt, wprep)
     po, _, part2 = ops.linear_fwd(ao, wproj, at.proj.bias.data, want_stats=training)   # + norm2's batch statistics
     st2 = bn_forward_state(blk.norm2, part2, m, training)
     keep = None
@@ -117,6 +117,7 @@ def attn_block_forward(blk, x, dt, training, save):
         (s.x2, s.wqkv, s.qkv, s.cpb, s.bias_t, s.scale_t, s.bias, s.scale, s.ao, s.wproj, s.po, s.st2, s.keep, s.shape) = (
             x2, wqkv, qkv, cpb, bias_t, scale_t, bias, scale, ao, wproj, po, st2, keep, (b, h, w, c))
         s.cpb_on_side = cpb_on_side
+        s.wqkv_t, s.wproj_t = wqkv_t, wproj_t
     return out, s
 
 
@@ -130,7 +131,7 @@ def attn_block_backward(blk, s, dout, dt, bc):
     dpo = ops.bn_backward(dbranch, s.po, s.st2, blk.norm2.weight.data, G(blk.norm2.weight), G(blk.norm2.bias))
     ops.colsum_accumulate(dpo, G(at.proj.bias))
     bc.on_side(lambda: ops.gemm_tn(dpo, s.ao, G(at.proj.weight)), dpo, s.ao)
-    dao = ops.gemm_nt(dpo, ops.transpose2d(s.wproj))
+    dao = ops.gemm_nt(dpo, _S._transposed(s.wproj, s.wproj_t))
     dqkv, dbias, dscale, gsum = ops.winattn_bwd(s.qkv, dao, s.bias, s.scale, b, h, w, at.num_heads, blk.window_size,
                                                 blk.shift_size, want_colsum=True)
     if gsum is None:                                 # fp32 validation kernels: column sums by a ones-GEMM
@@ -139,7 +140,7 @@ def attn_block_backward(blk, s, dout, dt, bc):
     G(at.q_bias).add_(gsum[:c])
     G(at.v_bias).add_(gsum[2 * c:])
     bc.on_side(lambda: ops.gemm_tn(dqkv, s.x2, G(at.qkv.weight)), dqkv, s.x2)
-    dx = _S._dgrad_add(dqkv, s.wqkv, d2)
+    dx = _S._dgrad_add(dqkv, s.wqkv, d2, s.wqkv_t)
     _S.position_bias_backward(blk, s, dbias, dscale, bc)
     return dx.view(b, h, w, c)
 
@@ -199,8 +200,11 @@ class AlterNet(nn.Module):
         dt = self.dtype
         sv = Saved() if save else None
         layers = list(self._layers())
+        lprep = None
         if training and save:
-            _S.precompute_position_bias([m for m in layers if not isinstance(m, BasicBlock)], x.device)
+            attn = [m for m in layers if not isinstance(m, BasicBlock)]
+            _S.precompute_position_bias(attn, x.device)
+            lprep = _S.prepare_linear_weights([l for b in attn for l in (b.attn.qkv, b.attn.proj)], dt)
         cur = stem_forward(self, x, training, sv)
         saved = []
         convs = [c for b in layers if isinstance(b, BasicBlock)
@@ -210,7 +214,7 @@ class AlterNet(nn.Module):
             if isinstance(mod, BasicBlock):
                 cur, s = basic_block_forward(mod, cur, dt, training, save, wprep)
             else:
-                cur, s = attn_block_forward(mod, cur, dt, training, save)
+                cur, s = attn_block_forward(mod, cur, dt, training, save, lprep)
             saved.append(s)
         if cur.shape[1] != 6 or cur.shape[2] != 6:
             raise NotImplementedError("AdaptiveAvgPool2d((6,6)) is the identity only for 192x192 inputs")

@@ -105,6 +105,25 @@ def _w2d(conv_or_lin, dt):
     return ops.cast_from_f32(w.reshape(w.shape[0], -1).contiguous(), dt)
 
 
+def prepare_linear_weights(mods, dt):
+    """{module: (w [N,K] in dt, w^T [K,N] in dt)} for every Linear / 1x1 weight of a step in ONE launch (the batched
+    conv-operand kernel: a Linear is a 1x1 convolution) instead of a cast per forward use and a transpose per backward use"""
+    mods = list(mods)
+    ws = [m.weight.data.reshape(m.weight.shape[0], 1, 1, -1) for m in mods]
+    outs = ops.prep_conv_weights(ws, dt)
+    return {m: (wc.view(wc.shape[0], wc.shape[3]), wt.view(wt.shape[0], wt.shape[3])) for m, (wc, wt) in zip(mods, outs)}
+
+
+def _lin_operands(mod, dt, wprep):
+    if wprep is not None and mod in wprep:
+        return wprep[mod]
+    return _w2d(mod, dt), None
+
+
+def _transposed(w2d, wt):
+    return wt if wt is not None else ops.transpose2d(w2d)
+
+
 def _colsum_via_gemm(x2d, out_accum):
     """out_accum[c] += sum_rows x2d[:, c] for rows wider than the element-wise reducer handles (3C up to 1536)"""
     ones = torch.ones((x2d.shape[0], 8), dtype=x2d.dtype, device=x2d.device)
@@ -167,23 +186,23 @@ def position_bias_backward(blk, s, dbias, dscale, bc):
         run()
 
 
-def swin_block_forward(blk, x, dt, training, save):
+def swin_block_forward(blk, x, dt, training, save, wprep=None):
     b, h, w, c = x.shape
     m = b * h * w
     at = blk.attn
     x2 = x.view(m, c)
-    wqkv = _w2d(at.qkv, dt)
+    wqkv, wqkv_t = _lin_operands(at.qkv, dt, wprep)
     qb = torch.cat([at.q_bias.data, torch.zeros_like(at.v_bias.data), at.v_bias.data])
     qkv, _, _ = ops.linear_fwd(x2, wqkv, qb)                                  # bias add in the GEMM epilogue
     cpb, bias_t, scale_t, bias, scale, cpb_on_side = position_bias(blk)
     ao = ops.winattn_fwd(qkv, bias, scale, b, h, w, at.num_heads)
-    wproj = _w2d(at.proj, dt)
+    wproj, wproj_t = _lin_operands(at.proj, dt, wprep)
     po, _, part2 = ops.linear_fwd(ao, wproj, at.proj.bias.data, want_stats=training)   # + norm2's batch statistics
     st2 = bn_forward_state(blk.norm2, part2, m, training)
     x1 = ops.bn_apply(po, st2, res=x2)
-    w1 = _w2d(blk.mlp.fc1, dt)
+    w1, w1_t = _lin_operands(blk.mlp.fc1, dt, wprep)
     hid, act, _ = ops.linear_fwd(x1, w1, blk.mlp.fc1.bias.data, want_act=True)          # bias + GELU, both tensors kept
-    w2 = _w2d(blk.mlp.fc2, dt)
+    w2, w2_t = _lin_operands(blk.mlp.fc2, dt, wprep)
     mo, _, part3 = ops.linear_fwd(act, w2, blk.mlp.fc2.bias.data, want_stats=training)
     st3 = bn_forward_state(blk.norm3, part3, m, training)
     out = ops.bn_apply(mo, st3, res=x1).view(b, h, w, c)
@@ -194,14 +213,15 @@ def swin_block_forward(blk, x, dt, training, save):
          s.act, s.w2, s.mo, s.st3, s.shape) = (x2, wqkv, qkv, cpb, bias_t, scale_t, bias, scale, ao, wproj, po, st2, x1, w1,
                                                 hid, act, w2, mo, st3, (b, h, w, c))
         s.cpb_on_side = cpb_on_side
+        s.wqkv_t, s.wproj_t, s.w1_t, s.w2_t = wqkv_t, wproj_t, w1_t, w2_t
     return out, s
 
 
-def _dgrad_add(dy2d, w2d, residual2d):
+def _dgrad_add(dy2d, w2d, residual2d, wt=None):
     """dy [M,K] @ w [K,C] + residual [M,C], as a 1x1 data-gradient with the residual add fused"""
     m, k = dy2d.shape
     c = w2d.shape[1]
-    wt = ops.transpose2d(w2d)                       # [C][K]: K-contiguous rows of the transposed weight
+    wt = _transposed(w2d, wt)                       # [C][K]: K-contiguous rows of the transposed weight
     return ops.conv_dgrad(dy2d.view(m, 1, 1, k), wt.view(c, 1, 1, k), (m, 1, 1, c), 1, 1, 1, 0,
                           residual=residual2d.view(m, 1, 1, c)).view(m, c)
 
@@ -217,15 +237,15 @@ def swin_block_backward(blk, s, dout, dt, bc):
     ops.colsum_accumulate(dmo, G(blk.mlp.fc2.bias))
     bc.on_side(lambda: ops.gemm_tn(dmo, s.act, G(blk.mlp.fc2.weight).view(c, 4 * c)), dmo, s.act)
     # [M, 4C]: fc2's data-gradient with gelu'(hid) and fc1.bias's gradient (column sums) fused into its epilogue
-    dhid, db1 = ops.linear_dgrad_gelu(dmo, ops.transpose2d(s.w2), s.hid)
+    dhid, db1 = ops.linear_dgrad_gelu(dmo, _transposed(s.w2, s.w2_t), s.hid)
     G(blk.mlp.fc1.bias).add_(db1)
     bc.on_side(lambda: ops.gemm_tn(dhid, s.x1, G(blk.mlp.fc1.weight).view(4 * c, c)), dhid, s.x1)
-    dx1 = _dgrad_add(dhid, s.w1, d2)
+    dx1 = _dgrad_add(dhid, s.w1, d2, s.w1_t)
     # ---- attention branch: x1 = x + BN(proj(attn(qkv(x))))
     dpo = ops.bn_backward(dx1, s.po, s.st2, blk.norm2.weight.data, G(blk.norm2.weight), G(blk.norm2.bias))
     ops.colsum_accumulate(dpo, G(at.proj.bias))
     bc.on_side(lambda: ops.gemm_tn(dpo, s.ao, G(at.proj.weight)), dpo, s.ao)
-    dao = ops.gemm_nt(dpo, ops.transpose2d(s.wproj))
+    dao = ops.gemm_nt(dpo, _transposed(s.wproj, s.wproj_t))
     dqkv, dbias, dscale, gsum = ops.winattn_bwd(s.qkv, dao, s.bias, s.scale, b, h, w, at.num_heads, want_colsum=True)
     if gsum is None:                                 # fp32 validation kernels: column sums by a ones-GEMM
         gsum = torch.zeros(3 * c, dtype=torch.float32, device=dout.device)
@@ -233,7 +253,7 @@ def swin_block_backward(blk, s, dout, dt, bc):
     G(at.q_bias).add_(gsum[:c])
     G(at.v_bias).add_(gsum[2 * c:])
     bc.on_side(lambda: ops.gemm_tn(dqkv, s.x2, G(at.qkv.weight)), dqkv, s.x2)
-    dx = _dgrad_add(dqkv, s.wqkv, dx1)
+    dx = _dgrad_add(dqkv, s.wqkv, dx1, s.wqkv_t)
     # ---- the 169-entry position-bias MLP and the logit scale (parameter space, torch autograd)
     position_bias_backward(blk, s, dbias, dscale, bc)
     return dx.view(b, h, w, c)
@@ -282,8 +302,11 @@ class Swin(nn.Module):
     def _forward_impl(self, x, training, save):
         dt = self.dtype
         sv = Saved() if save else None
+        wprep = None
         if training and save:
-            precompute_position_bias([m for m in self._layers() if not isinstance(m, _Conv)], x.device)
+            blocks = [m for m in self._layers() if not isinstance(m, _Conv)]
+            precompute_position_bias(blocks, x.device)
+            wprep = prepare_linear_weights([l for b in blocks for l in (b.attn.qkv, b.attn.proj, b.mlp.fc1, b.mlp.fc2)], dt)
         cur = stem_forward(self, x, training, sv)
         saved = []
         for mod in self._layers():
@@ -293,7 +316,7 @@ class Swin(nn.Module):
                 saved.append(cur if save else None)
                 cur = nxt
             else:
-                cur, s = swin_block_forward(mod, cur, dt, training, save)
+                cur, s = swin_block_forward(mod, cur, dt, training, save, wprep)
                 saved.append(s)
         if cur.shape[1] != 7 or cur.shape[2] != 7:
             raise NotImplementedError("AdaptiveAvgPool2d((7,7)) is the identity only for 112x112 inputs")
