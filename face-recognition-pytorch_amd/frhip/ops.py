@@ -310,18 +310,20 @@ def stem_fwd(x, wp, st):
     return out, arg
 
 
-def stem_bwd(x, wp, dpool, arg, st, gamma, dgamma, dbeta, dw27, scratch=None):
-    """backward of the stem given the gradient of the pooled map: accumulates dgamma, dbeta and dw27 [64, 27] (fp32)"""
+def stem_bwd(x, wp, dpool, arg, st, gamma, dgamma, dbeta, dw27, scratch=None, part=None):
+    """backward of the stem given the gradient of the pooled map: accumulates dgamma, dbeta and dw27 [64, 27] (fp32).
+    part: [rows, 2, 64] partial sums { sum d, sum d * xhat } already reduced elsewhere (skips the recompute reduction pass)"""
     b, _, h, w = x.shape
     dev = x.device
     nb = lib().frhip_stem_blocks(b, h, w)
-    part = torch.empty((nb, 2, 64), dtype=torch.float32, device=dev)
-    check(lib().frhip_stem_bwd_reduce(dt_of(wp), _p(x), _p(wp), _p(dpool), _p(arg), _p(st.mean), _p(st.invstd), _p(st.scale),
-                                      _p(st.shift), b, h, w, _p(part), _s()), "frhip_stem_bwd_reduce")
+    if part is None:
+        part = torch.empty((nb, 2, 64), dtype=torch.float32, device=dev)
+        check(lib().frhip_stem_bwd_reduce(dt_of(wp), _p(x), _p(wp), _p(dpool), _p(arg), _p(st.mean), _p(st.invstd), _p(st.scale),
+                                          _p(st.shift), b, h, w, _p(part), _s()), "frhip_stem_bwd_reduce")
     coef = torch.empty((3, 64), dtype=torch.float32, device=dev)
     if scratch is None:
         scratch = torch.empty((64 * 2 * 64,), dtype=torch.float32, device=dev)
-    check(lib().frhip_bn_bwd_finalize(_p(part), nb, _p(scratch), 64, float(b * h * w), _p(gamma), _p(st.mean), _p(st.invstd),
+    check(lib().frhip_bn_bwd_finalize(_p(part), part.shape[0], _p(scratch), 64, float(b * h * w), _p(gamma), _p(st.mean), _p(st.invstd),
                                       _p(dgamma), _p(dbeta), _p(coef[0]), _p(coef[1]), _p(coef[2]), _s()),
           "frhip_bn_bwd_finalize")
     slabs = torch.empty((nb, 64, 32), dtype=torch.float32, device=dev)

@@ -19,7 +19,7 @@ import torch.nn as nn
 
 from ._backbone import (BackwardCtx, BasicBlock, Saved, _BN, _Conv, _Linear, basic_block_backward,
                         basic_block_forward, compute_dtype, encoder_call, prepare_conv_weights, stem_backward,
-                        stem_forward,
+                        stem_forward, stem_reduction_operands,
                         tail_backward, tail_forward)
 
 _BLOCKS = {18: (2, 2, 2, 2), 34: (3, 4, 6, 4), 50: (3, 4, 14, 4), 100: (3, 13, 30, 4), 200: (3, 43, 50, 4)}
@@ -88,11 +88,12 @@ class ResNet(nn.Module):
         part = None
         for i in range(len(blocks) - 1, -1, -1):
             # the gradient leaving block i enters bn2 of block i-1: its reduction rides in block i's last kernel
-            nxt = (sv.blocks[i - 1].y2, sv.blocks[i - 1].st2) if i > 0 else None
+            # ... and the gradient leaving block 0 enters the stem's pool / ReLU / BN (stem_reduction_operands)
+            nxt = (sv.blocks[i - 1].y2, sv.blocks[i - 1].st2) if i > 0 else stem_reduction_operands(self, sv)
             res = basic_block_backward(blocks[i], sv.blocks[i], dout, self.dtype, bc, part2=part, next_bn=nxt)
             dout, part = res if nxt is not None else (res, None)
             bc.reduce_down_to(blocks[i].conv1.weight)      # data parallel: block i and everything behind it is final
-        stem_backward(self, sv, dout, bc)
+        stem_backward(self, sv, dout, bc, part)
         return bc.join()
 
 

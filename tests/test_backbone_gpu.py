@@ -75,6 +75,39 @@ def test_resnet18_bf16_tracks_fp32():
         assert cos > 0.95, (k, cos.item())
 
 
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_stem_reduction_fused_into_block0_matches_recompute_pass(dtype, monkeypatch):
+    """the stem's BN-backward sums from the (dpool, pooled) reduction fused into block 0's data-gradient epilogue (default)
+    against the stem's own recompute reduction pass: same gradients for the stem's parameters and everything else.
+    bn1.weight starts near the reference's initial 1.0 here, and one channel is made (near-)dead to exercise the
+    regularised 1 / gamma"""
+    import nets._backbone as BB
+    grads = {}
+    for fused in (True, False):
+        monkeypatch.setattr(BB, "_STEM_FUSED_REDUCE", fused)
+        net, _ = _net("ResNet18", dtype, 4747)
+        with torch.no_grad():
+            net.bn1.weight[3] = 1e-6
+            net.bn1.weight[5] = 0.0
+        net.train()
+        y = net(recipe.images(4748, 6).cuda())
+        y.backward(recipe.normal(4749, (6, 512), 0.05).cuda())
+        grads[fused] = {k: p.grad.detach().float().cpu() for k, p in net.named_parameters()}
+    tol = 2e-4 if dtype == "fp32" else 3e-2
+    live = torch.ones(64, dtype=torch.bool)
+    live[3] = live[5] = False
+    for k in grads[True]:
+        a, b = grads[True][k], grads[False][k]
+        assert torch.isfinite(a).all(), k
+        if k == "bn1.weight":                      # d(gamma) of the dead channels is regularised towards 0, not compared
+            a, b = a[live], b[live]
+        if k == "conv1.weight":                    # their dy carries gamma * (...) ~ 0 either way
+            a, b = a[live], b[live]
+        scale = max(b.abs().max().item(), 1e-6)
+        # + 1e-6: analytically-zero gradients (a bias in front of a train-mode BN) are pure round-off in both runs
+        np.testing.assert_allclose(a.numpy(), b.numpy(), rtol=tol, atol=tol * scale + 1e-6, err_msg=k)
+
+
 def test_checkpoint_roundtrip_with_reference_keys():
     net, sd = _net("ResNet18", "fp32", 4242)
     out = net.state_dict()
