@@ -90,7 +90,7 @@ class Model(nn.Module):
         self.opt.zero_grad()
         self.encoder.train()
         if hasattr(self.loss, "prepare"):          # label all-gather + the one sync sampling needs, before the GPU gets busy
-            self.loss.prepare(id_)
+            self.loss.prepare(id_, self.opt)
         feat = normalize(self.forward(img))
         self.loss.train()
         loss = self.loss(feat, id_, self.opt)

@@ -291,11 +291,17 @@ class _PartialFCBase(torch.nn.Module):
         return buf.to(dev, non_blocking=True)
 
     @torch.no_grad()
-    def prepare(self, local_labels):
+    def prepare(self, local_labels, optimizer=None):
         """Optional, call at the START of a step (before the backbone is enqueued): gathers the labels of all ranks and
         counts this shard's distinct positives.  The one host synchronisation sampling needs (is num_sample >= #positives?,
         reference :112) then happens while the GPU still has the previous step to chew on, and forward() runs without any
-        -- a mid-step synchronisation drains the launch queue and costs ~3 ms of idle GPU per step at B = 512."""
+        -- a mid-step synchronisation drains the launch queue and costs ~3 ms of idle GPU per step at B = 512.
+
+        With `optimizer` the whole label side of forward() moves here as well: update() of the previous step's rows, the
+        shard-relative labels, sample() (index draw, row gathers, optimizer parameter swap).  None of it needs the
+        embeddings, and it is ~60 small launches whose HOST cost (30-50 us each) sits between the backbone and the head
+        otherwise: with a sampled head (rate 0.1: 60 us of GPU work) the GPU catches up with the host there and idles
+        for ~1.5 ms per step.  At the start of a step the host is ahead of the GPU, so the same work is free."""
         lab = local_labels.view(-1).long()
         if self.world_size > 1 or _FORCE_COLLECTIVES:
             glabels = [torch.zeros_like(lab) for _ in range(self.world_size)]
@@ -303,13 +309,44 @@ class _PartialFCBase(torch.nn.Module):
             labels = torch.cat(glabels)
         else:
             labels = lab.clone()
-        n_pos = None
+        n_pos, check = None, None
         if self.sample_rate < 1:
             mask = (self.class_start <= labels) & (labels < self.class_start + self.num_local)
             hits = torch.zeros(self.num_local + 1, dtype=torch.int32, device=labels.device)
             hits.index_fill_(0, torch.where(mask, labels - self.class_start, torch.full_like(labels, self.num_local)), 1)
-            n_pos = int(hits[:self.num_local].sum().item())
-        self._prep = (local_labels.data_ptr(), labels, n_pos)
+            count = hits[:self.num_local].sum()
+            if optimizer is not None and labels.is_cuda:
+                # No synchronisation at all in the steady state: sample on the assumption num_sample >= #positives (with
+                # num_sample = 1 525 rows against ~512 distinct owned labels per step it always holds), ship the count to
+                # a pinned slot, and let forward() -- a whole backbone pass later, the copy is long done -- verify it and
+                # redo the sampling on the reference's other branch (RNG state restored) in the case it does not.  A
+                # blocking .item() here stops the host from running ahead across the step boundary: the GPU then starts
+                # every step with an empty queue.
+                pins = getattr(self, "_npos_pins", None)
+                if pins is None:
+                    pins = self._npos_pins = [torch.zeros(1, dtype=torch.int64, pin_memory=True) for _ in range(4)]
+                    self._npos_turn = 0
+                pin = pins[self._npos_turn % len(pins)]
+                self._npos_turn += 1
+                pin.copy_(count.to(torch.int64).view(1), non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record()
+                check = [ev, pin, torch.get_rng_state(), None, None]
+                n_pos = 0                                  # optimistic: the sync-free branch of sample()
+            else:
+                n_pos = int(count.item())
+        ready = None
+        if optimizer is not None:
+            self.update()
+            glab = labels.view(-1, 1)
+            index_positive = (self.class_start <= glab) & (glab < self.class_start + self.num_local)
+            rel = torch.where(index_positive, glab - self.class_start, torch.full_like(glab, -1))
+            if self.sample_rate < 1:
+                if check is not None:
+                    check[3], check[4] = rel.clone(), index_positive
+                self.sample(rel, index_positive, optimizer, n_pos)
+            ready = rel.view(-1).to(torch.int32).contiguous()
+        self._prep = (local_labels.data_ptr(), labels, n_pos, ready, check)
 
     @torch.no_grad()
     def update(self):
@@ -326,7 +363,20 @@ class _PartialFCBase(torch.nn.Module):
     def forward(self, local_embeddings, local_labels, optimizer):
         local_labels.squeeze_()
         local_labels = local_labels.long()
-        self.update()
+        prep = getattr(self, "_prep", None)
+        ready = prep[3] if prep is not None and len(prep) > 3 else None
+        if ready is None:
+            self.update()
+        elif prep[4] is not None:                          # verify prepare()'s optimistic sampling (never blocks in practice)
+            ev, pin, rng_state, rel, index_positive = prep[4]
+            ev.synchronize()
+            if int(pin[0]) > self.num_sample:              # more distinct positives than sampled rows: the reference's other branch
+                torch.set_rng_state(rng_state)
+                self.step -= 1
+                with torch.no_grad():
+                    self.sample(rel, index_positive, optimizer, None)
+                ready = rel.view(-1).to(torch.int32).contiguous()
+                prep = prep[:3] + (ready, None)
         batch_size = local_embeddings.size(0)
         if self.last_batch_size == 0:
             self.last_batch_size = batch_size
@@ -350,6 +400,10 @@ class _PartialFCBase(torch.nn.Module):
                 labels, n_pos = prep[1], prep[2]
             else:
                 labels = local_labels.clone()
+        if ready is not None and ready.numel() == embeddings.shape[0]:      # everything label-side was done by prepare()
+            return _MarginSoftmaxFn.apply(embeddings, self.weight_activated, ready, self.kernels,
+                                          float(self.margin_softmax.scale), float(self.margin_softmax.margin),
+                                          2 if (_FORCE_COLLECTIVES and self.world_size == 1) else self.world_size)
         labels = labels.view(-1, 1)
         index_positive = (self.class_start <= labels) & (labels < self.class_start + self.num_local)
         # shard-relative label, -1 when another rank owns the class (reference :188-193); written with where()

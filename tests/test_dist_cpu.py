@@ -42,7 +42,9 @@ def _worker(rank, ws, path, name, ret, use_prepare=False):
         lab[1] = 3
     torch.manual_seed(1000 + rank)
     lab_in = lab.clone()
-    if use_prepare:                 # the sync-free route: labels gathered and positives counted before the step's forward
+    if use_prepare == "full":       # ... and the whole label side (update, relabel, sample, optimizer swap) before the forward
+        pfc.prepare(lab_in, opt)
+    elif use_prepare:               # the sync-free route: labels gathered and positives counted before the step's forward
         pfc.prepare(lab_in)
     loss = pfc(emb, lab_in, opt)
     loss.backward()
@@ -57,7 +59,8 @@ def _worker(rank, ws, path, name, ret, use_prepare=False):
 
 
 @pytest.mark.parametrize("name,use_prepare", [("head_ws2_rate10", False), ("head_ws2_rate03", False), ("head_ws8_rate01", False),
-                                              ("head_ws2_rate03", True), ("head_ws2_rate10", True)])
+                                              ("head_ws2_rate03", True), ("head_ws2_rate10", True),
+                                              ("head_ws2_rate03", "full"), ("head_ws2_rate10", "full"), ("head_ws8_rate01", "full")])
 def test_partial_fc_host_logic_multi_rank(golden, name, use_prepare):
     g = golden(name)
     ws = int(g["ws"])

@@ -81,3 +81,34 @@ def test_bf16_training_reduces_loss(pg):
     losses = [float(model.training_step((img, ids.clone()))["loss"]) for _ in range(6)]
     assert np.isfinite(losses).all()
     assert losses[-1] < losses[0] * 0.7, losses
+
+
+@pytest.mark.parametrize("distinct", [16, 8])
+def test_prepare_optimistic_sampling_falls_back_to_the_reference_branch(pg, distinct):
+    """PartialFC.prepare(labels, optimizer) samples without a host synchronisation on the assumption num_sample >= #positives
+    and forward() verifies it: with more distinct positives than sampled rows (12 rows, 16 distinct labels) the result must be
+    what the synchronising route gives -- the reference's `index = positive` branch, same RNG stream afterwards."""
+    import nets.PartialFC as P
+    torch.cuda.set_device(0)
+    conf = _conf(0.05, "fp32")                       # 256 ids -> num_sample = 12
+    res = []
+    for use_prepare in (True, False):
+        torch.manual_seed(4100)
+        head = P.PartialFC(conf, 256).cuda()
+        with torch.no_grad():
+            head.weight.copy_(recipe.normal(4101, (256, 512), 0.01).cuda())
+        opt = torch.optim.SGD([{"params": [head.weight_activated]}], lr=0.1, momentum=0.9)
+        emb = recipe.normal(4102, (16, 512), 1.0).cuda().requires_grad_(True)
+        lab = (torch.arange(16) % distinct * 7 + 3).cuda()
+        torch.manual_seed(4103)
+        if use_prepare:
+            head.prepare(lab, opt)
+        loss = head(emb, lab.clone(), opt)
+        loss.backward()
+        res.append((float(loss.detach()), head.weight_index.cpu().clone(), emb.grad.cpu().clone(), torch.rand(1).item(), head.step))
+    (la, ia, ga, ra, sa), (lb, ib, gb, rb, sb) = res
+    assert torch.equal(ia, ib) and sa == sb == 1
+    assert ia.numel() == (16 if distinct == 16 else 12)
+    np.testing.assert_allclose(la, lb, rtol=1e-6)
+    np.testing.assert_allclose(ga.numpy(), gb.numpy(), rtol=1e-5, atol=1e-7)
+    assert ra == rb                                  # the CPU generator is where the reference would have left it
