@@ -28,6 +28,7 @@ import torch.nn.functional as F
 from frhip import ops
 
 from ._backbone import (BackwardCtx, BasicBlock, Saved, _BN, _Conv, _Linear, bn_forward_state, compute_dtype,  # noqa: F401
+                        stem_reduction_operands,
                         encoder_call, phys_grad, stem_backward, stem_forward, tail_backward, tail_forward)
 
 LN100 = math.log(1.0 / 0.01)
@@ -217,16 +218,23 @@ def swin_block_forward(blk, x, dt, training, save, wprep=None):
     return out, s
 
 
-def _dgrad_add(dy2d, w2d, residual2d, wt=None):
-    """dy [M,K] @ w [K,C] + residual [M,C], as a 1x1 data-gradient with the residual add fused"""
+def _dgrad_add(dy2d, w2d, residual2d, wt=None, bnred=None):
+    """dy [M,K] @ w [K,C] + residual [M,C], as a 1x1 data-gradient with the residual add fused.
+    bnred=(y [.., C], BN state, relu): also the BN-backward partial sums of the result against y -> (dx, partial)"""
     m, k = dy2d.shape
     c = w2d.shape[1]
     wt = _transposed(w2d, wt)                       # [C][K]: K-contiguous rows of the transposed weight
+    if bnred is not None:
+        dx, part = ops.conv_dgrad(dy2d.view(m, 1, 1, k), wt.view(c, 1, 1, k), (m, 1, 1, c), 1, 1, 1, 0,
+                                  residual=residual2d.view(m, 1, 1, c), bnred=(bnred[0].view(m, 1, 1, c), bnred[1], bnred[2]))
+        return dx.view(m, c), part
     return ops.conv_dgrad(dy2d.view(m, 1, 1, k), wt.view(c, 1, 1, k), (m, 1, 1, c), 1, 1, 1, 0,
                           residual=residual2d.view(m, 1, 1, c)).view(m, c)
 
 
-def swin_block_backward(blk, s, dout, dt, bc):
+def swin_block_backward(blk, s, dout, dt, bc, next_bn=None):
+    """next_bn=(y, st, relu): the BatchNorm whose upstream gradient the returned dx is (the stem's, for the first block): its
+    backward reduction rides in the last data-gradient and (dx, partial) is returned"""
     G = bc.G
     b, h, w, c = s.shape
     m = b * h * w
@@ -253,10 +261,14 @@ def swin_block_backward(blk, s, dout, dt, bc):
     G(at.q_bias).add_(gsum[:c])
     G(at.v_bias).add_(gsum[2 * c:])
     bc.on_side(lambda: ops.gemm_tn(dqkv, s.x2, G(at.qkv.weight)), dqkv, s.x2)
-    dx = _dgrad_add(dqkv, s.wqkv, dx1, s.wqkv_t)
+    part = None
+    if next_bn is not None:
+        dx, part = _dgrad_add(dqkv, s.wqkv, dx1, s.wqkv_t, bnred=next_bn)
+    else:
+        dx = _dgrad_add(dqkv, s.wqkv, dx1, s.wqkv_t)
     # ---- the 169-entry position-bias MLP and the logit scale (parameter space, torch autograd)
     position_bias_backward(blk, s, dbias, dscale, bc)
-    return dx.view(b, h, w, c)
+    return dx.view(b, h, w, c) if next_bn is None else (dx.view(b, h, w, c), part)
 
 
 # ------------------------------------------------------------------------------------------------- network
@@ -333,14 +345,20 @@ class Swin(nn.Module):
         dt = self.dtype
         bc = BackwardCtx(params, d_emb.device, allreduce=getattr(self, "_frhip_allreduce", False))
         dout = tail_backward(self, sv, d_emb, bc)
-        for mod, s in zip(reversed(list(self._layers())), reversed(sv.layers)):
+        layers = list(self._layers())
+        part = None
+        for i in range(len(layers) - 1, -1, -1):
+            mod, s = layers[i], sv.layers[i]
             if isinstance(mod, _Conv):
                 wt = ops.pack_wt(mod.physical(), dt)
                 bc.wgrad(dout, s, phys_grad(bc.G(mod.weight)), 2, 2, 2, 0)
                 dout = ops.conv_dgrad(dout, wt, s.shape, 2, 2, 2, 0)
+            elif i == 0 and stem_reduction_operands(self, sv) is not None:
+                # the gradient leaving the first block enters the stem's pool / ReLU / BN: its sums ride in the block's last kernel
+                dout, part = swin_block_backward(mod, s, dout, dt, bc, next_bn=stem_reduction_operands(self, sv))
             else:
                 dout = swin_block_backward(mod, s, dout, dt, bc)
-        stem_backward(self, sv, dout, bc)
+        stem_backward(self, sv, dout, bc, part)
         return bc.join()
 
 
