@@ -1,0 +1,34 @@
+"""The bench line the round ends with (profiles/r01_final_bench.json = stdout of `python bench.py` on the MI355X box) carries
+every field of the driver's contract, with the metric and workload BASELINE.json names."""
+import json
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_committed_bench_line_has_the_contract_fields():
+    line = json.load(open(os.path.join(ROOT, "profiles", "r01_final_bench.json")))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in line, k
+    assert line["unit"] == "imgs/sec" and line["higher_is_better"] is True and line["scaling"] == "weak"
+    assert line["vs_baseline"] is None                      # BASELINE.md publishes no number for this metric
+    assert line["dtype"] == "bf16" and line["data"] == "synthetic" and line["n_gpus"] == 1
+    assert "workload" in line["config"] and "model" not in line["config"]
+    assert "ResNet50" in line["config"]["workload"] and "B=512" in line["config"]["workload"]
+    assert abs(line["value"] - 512 * 1e3 / line["ms_per_step"]) / line["value"] < 1e-3
+    r = line["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    c = line["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c, k
+    assert c["kind"] == "port" and c["cores"] >= 1
+
+
+def test_bench_cli_defaults_match_the_contract():
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    for flag in ("--gpus", "--steps", "--warmup"):
+        assert flag in src
+    assert 'default=1)' in src                               # --gpus defaults to one GPU
