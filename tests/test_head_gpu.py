@@ -32,6 +32,16 @@ def _run_head(ops, dtype, emb, w_act, ll, s, m, upstream=1.0):
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("shape", [(24, 1003, 128), (130, 200, 512), (8, 16, 64)])
 def test_head_matches_oracle(dtype, shape):
+    _check_head_against_oracle(dtype, shape)
+
+
+def test_head_matches_oracle_at_cfg2_size():
+    """BASELINE cfg 2: 512 rows x 122 000 classes x 512 dims, bf16 -- the oracle's explicit 250-MB logit matrix on the host
+    against the fused kernels that never store it"""
+    _check_head_against_oracle(torch.bfloat16, (512, 122000, 512))
+
+
+def _check_head_against_oracle(dtype, shape):
     from frhip import ops
     n, classes, d = shape
     g = torch.Generator().manual_seed(n + classes)
