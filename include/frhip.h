@@ -261,6 +261,10 @@ int frhip_prep_conv_weights(int dtype, const frhip_wprep* table, int ntensors, i
  * (CoarseDropout fill_value 0 after Normalize).  Resize = OpenCV INTER_LINEAR (8-bit fixed point), identity when sizes match. */
 int frhip_augment_u8(const uint8_t* in, float* out, const int32_t* flip, const int32_t* holes, int nholes,
                      int b, int hin, int win, int size, frhip_stream_t stream);
+/* the same with RandomGamma in front (utils/data_partial.py:137-138): lut uint8 [b][256] (may be NULL), the per-image table
+ * ((i / 255) ** gamma * 255 truncated to uint8, gamma = uniform(gamma_limit) / 100) applied to the source bytes before Resize */
+int frhip_augment_u8_lut(const uint8_t* in, const uint8_t* lut, float* out, const int32_t* flip, const int32_t* holes,
+                         int nholes, int b, int hin, int win, int size, frhip_stream_t stream);
 
 /* ---- optimizer: torch.optim.SGD(momentum, weight_decay).step() + torch.nn.utils.clip_grad_norm_ of the training step
  * (model/FR_PartialFC.py:153-160, :181-190) as multi-tensor kernels.  A chunk is a run of at most

@@ -1,6 +1,7 @@
-"""TEST INFRASTRUCTURE ONLY -- numpy restatement of the tail of the reference's input pipeline
-(/root/reference/utils/data_partial.py:134-164): alb.Resize -> alb.HorizontalFlip -> alb.Normalize(0.5, 0.5) ->
-alb.CoarseDropout -> ToTensorV2, with the random decisions (flip flags, hole rectangles) as explicit inputs.
+"""TEST INFRASTRUCTURE ONLY -- numpy restatement of the reference's input pipeline without MotionBlur / ISONoise
+(/root/reference/utils/data_partial.py:134-164): [alb.RandomGamma] -> alb.Resize -> alb.HorizontalFlip ->
+alb.Normalize(0.5, 0.5) -> alb.CoarseDropout -> ToTensorV2, with the random decisions (gammas, flip flags, hole rectangles) as
+explicit inputs.
 
 PARITY UNPINNED: albumentations and OpenCV are not installed in the build container and the reference holds no fixture
 for this path, so this file restates the published algorithms (cv2.resize INTER_LINEAR on 8-bit images: 11-bit fixed-point
@@ -40,11 +41,19 @@ def resize_linear_u8(img, size):
     return np.clip(d, 0, 255).astype(np.uint8)
 
 
-def augment(images, size, flip=None, holes=None):
-    """images uint8 [B,H,W,3]; flip bool/int [B] or None; holes int [B,K,4] (x1,y1,x2,y2 exclusive, x2<=x1 unused) or None
-    -> float32 [B,3,size,size]"""
+def gamma_table(gamma):
+    """albumentations RandomGamma on uint8 (functional.gamma_transform): the cv2.LUT table for exponent `gamma`
+    (= uniform(gamma_limit) / 100): ((arange(0, 256/255, 1/255)) ** gamma * 255) truncated to uint8"""
+    return (np.power(np.arange(0, 256.0 / 255, 1.0 / 255), gamma) * 255).astype(np.uint8)[:256]
+
+
+def augment(images, size, flip=None, holes=None, gamma=None):
+    """images uint8 [B,H,W,3]; flip bool/int [B] or None; holes int [B,K,4] (x1,y1,x2,y2 exclusive, x2<=x1 unused) or None;
+    gamma float [B] or None (NaN / <= 0: that image is left alone) -> float32 [B,3,size,size]"""
     out = np.empty((images.shape[0], 3, size, size), dtype=np.float32)
     for n, img in enumerate(images):
+        if gamma is not None and np.isfinite(gamma[n]) and gamma[n] > 0:
+            img = gamma_table(float(gamma[n]))[img]
         r = resize_linear_u8(img, size)
         if flip is not None and flip[n]:
             r = r[:, ::-1]

@@ -72,3 +72,44 @@ def test_augment_kernel_matches_oracle(shape):
     np.testing.assert_array_equal(got, want)                            # integer resize + one float op: bit-exact
     plain = DeviceTransform(_conf(size), train=False)
     np.testing.assert_array_equal(plain(torch.from_numpy(img).cuda()).cpu().numpy(), augment_ref.augment(img, size))
+
+
+def test_oracle_gamma_table_properties():
+    """gamma 1 is the identity up to the float truncation albumentations has too, end points are fixed, tables are monotone"""
+    t1 = augment_ref.gamma_table(1.0)
+    assert t1[0] == 0 and t1[255] >= 254 and np.abs(t1.astype(int) - np.arange(256)).max() <= 1
+    for g in (0.8, 1.2):
+        t = augment_ref.gamma_table(g)
+        assert t.shape == (256,) and t.dtype == np.uint8 and t[0] == 0 and (np.diff(t.astype(int)) >= 0).all()
+    assert (augment_ref.gamma_table(0.8).astype(int) >= augment_ref.gamma_table(1.2).astype(int)).all()     # gamma < 1 brightens
+
+
+def test_device_transform_gamma_draws():
+    from utils.device_transform import DeviceTransform
+    conf = _conf(aug=("RandomGammaContrast", "RandomHorizontalFlip"))
+    conf.img_augmenation.gamma_p, conf.img_augmenation.gamma_s = 0.5, (80, 120)
+    t = DeviceTransform(conf, seed=5)
+    g = t.draw_gamma(200)
+    on = np.isfinite(g)
+    assert 60 < on.sum() < 140 and (g[on] >= 0.8).all() and (g[on] <= 1.2).all()
+    lut = DeviceTransform.gamma_tables(g)
+    assert lut.shape == (200, 256) and (lut[~on] == np.arange(256)).all()
+    assert DeviceTransform(_conf(), seed=5).draw_gamma(4) is None
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(4, 112, 112, 112), (3, 150, 130, 112)])
+def test_augment_kernel_with_random_gamma_matches_oracle(shape):
+    from utils.device_transform import DeviceTransform
+    b, h, w, size = shape
+    rng = np.random.default_rng(17)
+    img = rng.integers(0, 256, (b, h, w, 3), dtype=np.uint8)
+    conf = _conf(size, aug=("RandomGammaContrast", "RandomHorizontalFlip", "RandomErasing"))
+    conf.img_augmenation.gamma_p, conf.img_augmenation.gamma_s = 0.7, (80, 120)
+    t = DeviceTransform(conf, seed=19)
+    gamma = t.draw_gamma(b)
+    gamma[0], gamma[1] = 0.85, np.nan                                   # one image with, one without the transform
+    flip, holes = t.draw(b)
+    got = t.apply(torch.from_numpy(img).cuda(), flip, holes, gamma).cpu().numpy()
+    np.testing.assert_array_equal(got, augment_ref.augment(img, size, flip, holes, gamma))
+    assert not np.array_equal(got[0], augment_ref.augment(img[:1], size, flip[:1], holes[:1])[0])     # the table did something
