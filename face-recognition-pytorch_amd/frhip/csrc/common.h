@@ -97,6 +97,21 @@ __device__ __forceinline__ void gelu_parts(float h, float& cdf, float& pdf) {
     pdf = 0.3989422804014327f * ex;
 }
 
+// Sum over the lanes whose id differs from this one in bit 3 / 4 / 5; every lane gets the result.  DPP row rotate and the
+// gfx950 v_permlane{16,32}_swap (rows of 16 / halves of 32 lanes exchanged between two registers) are plain VALU operations;
+// __shfl_xor compiles to ds_bpermute_b32, an LDS-unit instruction with LDS latency.
+__device__ __forceinline__ float lane_sum_bit3(float x) {
+    return x + __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(x), 0x128 /* row_ror:8 */, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float lane_sum_bit4(float x) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float lane_sum_bit5(float x) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
 __device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 

@@ -420,12 +420,11 @@ __device__ __forceinline__ void nt_epilogue_store(const char* mine, int P, char*
         // rows beyond M were gathered as zeros -> contribute 0.  Reduce over the lanes that share `chunk`.
 #pragma unroll
         for (int e = 0; e < EPV; ++e) {
-#pragma unroll
-            for (int d = LPR; d < 64; d <<= 1) {
-                s1[e] += __shfl_xor(s1[e], d);
-                s2[e] += __shfl_xor(s2[e], d);
-            }
+            if constexpr (LPR <= 8) { s1[e] = lane_sum_bit3(s1[e]); s2[e] = lane_sum_bit3(s2[e]); }
+            if constexpr (LPR <= 16) { s1[e] = lane_sum_bit4(s1[e]); s2[e] = lane_sum_bit4(s2[e]); }
+            s1[e] = lane_sum_bit5(s1[e]); s2[e] = lane_sum_bit5(s2[e]);
         }
+        static_assert(LPR == 8 || LPR == 16, "lanes per 64-channel row");
         __syncthreads();                                // staging area is free again
         float* red = reinterpret_cast<float*>(smem);   // [wave][2][64]
         if (lane < LPR) {
