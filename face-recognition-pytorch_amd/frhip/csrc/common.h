@@ -111,6 +111,22 @@ __device__ __forceinline__ float lane_sum_bit5(float x) {
     const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
     return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
+__device__ __forceinline__ float lane_max_bit4(float x) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float lane_max_bit5(float x) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+// sum over the 16 lanes of a DPP row (lanes with equal lane >> 4): four row rotates
+__device__ __forceinline__ float lane_sum_row16(float x) {
+    x += __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(x), 0x121 /* row_ror:1 */, 0xf, 0xf, false));
+    x += __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(x), 0x122 /* row_ror:2 */, 0xf, 0xf, false));
+    x += __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(x), 0x124 /* row_ror:4 */, 0xf, 0xf, false));
+    x += __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(x), 0x128 /* row_ror:8 */, 0xf, 0xf, false));
+    return x;
+}
 
 __device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }

@@ -119,16 +119,14 @@ __global__ __launch_bounds__(256, 2) void head_kernel(NtGeom g, const void* __re
                 }
             }
         if (FWD) {
-            vmax = fmaxf(vmax, __shfl_xor(vmax, 16));
-            vmax = fmaxf(vmax, __shfl_xor(vmax, 32));
+            vmax = lane_max_bit5(lane_max_bit4(vmax));
             float vs = 0.f;
             const float vref = vmax == -INFINITY ? 0.f : vmax;                  // a fully masked group: sum 0, no NaN
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) vs += __expf(z[nt][e] - vref);      // exp(-inf) = 0 for masked classes
-            vs += __shfl_xor(vs, 16);
-            vs += __shfl_xor(vs, 32);
+            vs = lane_sum_bit5(lane_sum_bit4(vs));
             if (fg == 0 && mrow) {
                 part_max[(size_t)group * g.M + m] = vmax;
                 part_sum[(size_t)group * g.M + m] = vs;

@@ -127,11 +127,7 @@ template <int RB> struct SfFrag<float, RB> {
 __device__ __forceinline__ int sf_chan(int t, int reg) { return t * 16 + 4 * (lane_id() >> 4) + reg; }
 
 // sum v over the 16 pixel lanes that share a channel group (lanes with equal lane >> 4)
-__device__ __forceinline__ float sf_sum16(float v) {
-#pragma unroll
-    for (int d = 1; d < 16; d <<= 1) v += __shfl_xor(v, d);
-    return v;
-}
+__device__ __forceinline__ float sf_sum16(float v) { return lane_sum_row16(v); }
 
 // ---------------------------------------------------------------------------------------------------------------------
 // stats: grid-stride over (image, 8-row band); wave wv takes rows h0 + 2wv, h0 + 2wv + 1

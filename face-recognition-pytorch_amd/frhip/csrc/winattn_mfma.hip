@@ -53,14 +53,8 @@ __device__ __forceinline__ bf16x4_t wm_pack4(const f32x4_t& a) {
     for (int e = 0; e < 4; ++e) v[e] = (bf16_t)a[e];
     return v;
 }
-__device__ __forceinline__ float wm_sum4g(float x) {          // sum over the four lane groups (same lane & 15)
-    x += __shfl_xor(x, 16);
-    return x + __shfl_xor(x, 32);
-}
-__device__ __forceinline__ float wm_max4g(float x) {
-    x = fmaxf(x, __shfl_xor(x, 16));
-    return fmaxf(x, __shfl_xor(x, 32));
-}
+__device__ __forceinline__ float wm_sum4g(float x) { return lane_sum_bit5(lane_sum_bit4(x)); }      // over the four lane groups
+__device__ __forceinline__ float wm_max4g(float x) { return lane_max_bit5(lane_max_bit4(x)); }      // (same lane & 15)
 
 // One token row (32 bf16) per lane: load, optionally l2-normalise, park in the LDS tile.  Returns 1 / max(|x|, eps).
 __device__ __forceinline__ float wm_stage_row(const bf16_t* src, char* tile, int lane, bool active, bool normalise) {
