@@ -232,25 +232,27 @@ def _dgrad_add(dy2d, w2d, residual2d, wt=None, bnred=None):
                           residual=residual2d.view(m, 1, 1, c)).view(m, c)
 
 
-def swin_block_backward(blk, s, dout, dt, bc, next_bn=None):
-    """next_bn=(y, st, relu): the BatchNorm whose upstream gradient the returned dx is (the stem's, for the first block): its
-    backward reduction rides in the last data-gradient and (dx, partial) is returned"""
+def swin_block_backward(blk, s, dout, dt, bc, next_bn=None, part3=None):
+    """next_bn=(y, st, relu): the BatchNorm whose upstream gradient the returned dx is (norm3 of the previous block, or the
+    stem's for the first block): its backward reduction rides in the last data-gradient and (dx, partial) is returned.
+    part3: the partial sums of THIS block's norm3 backward when the producer of dout already reduced them."""
     G = bc.G
     b, h, w, c = s.shape
     m = b * h * w
     at = blk.attn
     d2 = dout.reshape(m, c)
     # ---- MLP branch: x2 = x1 + BN(fc2(gelu(fc1(x1))))
-    dmo = ops.bn_backward(d2, s.mo, s.st3, blk.norm3.weight.data, G(blk.norm3.weight), G(blk.norm3.bias))
+    dmo = ops.bn_backward(d2, s.mo, s.st3, blk.norm3.weight.data, G(blk.norm3.weight), G(blk.norm3.bias), part=part3)
     ops.colsum_accumulate(dmo, G(blk.mlp.fc2.bias))
     bc.on_side(lambda: ops.gemm_tn(dmo, s.act, G(blk.mlp.fc2.weight).view(c, 4 * c)), dmo, s.act)
     # [M, 4C]: fc2's data-gradient with gelu'(hid) and fc1.bias's gradient (column sums) fused into its epilogue
     dhid, db1 = ops.linear_dgrad_gelu(dmo, _transposed(s.w2, s.w2_t), s.hid)
     G(blk.mlp.fc1.bias).add_(db1)
     bc.on_side(lambda: ops.gemm_tn(dhid, s.x1, G(blk.mlp.fc1.weight).view(4 * c, c)), dhid, s.x1)
-    dx1 = _dgrad_add(dhid, s.w1, d2, s.w1_t)
+    # dx1 is the upstream gradient of norm2: its backward reduction over (dx1, po) rides in this data-gradient's epilogue
+    dx1, part2 = _dgrad_add(dhid, s.w1, d2, s.w1_t, bnred=(s.po, s.st2, False))
     # ---- attention branch: x1 = x + BN(proj(attn(qkv(x))))
-    dpo = ops.bn_backward(dx1, s.po, s.st2, blk.norm2.weight.data, G(blk.norm2.weight), G(blk.norm2.bias))
+    dpo = ops.bn_backward(dx1, s.po, s.st2, blk.norm2.weight.data, G(blk.norm2.weight), G(blk.norm2.bias), part=part2)
     ops.colsum_accumulate(dpo, G(at.proj.bias))
     bc.on_side(lambda: ops.gemm_tn(dpo, s.ao, G(at.proj.weight)), dpo, s.ao)
     dao = ops.gemm_nt(dpo, _transposed(s.wproj, s.wproj_t))
@@ -352,12 +354,18 @@ class Swin(nn.Module):
             if isinstance(mod, _Conv):
                 wt = ops.pack_wt(mod.physical(), dt)
                 bc.wgrad(dout, s, phys_grad(bc.G(mod.weight)), 2, 2, 2, 0)
-                dout = ops.conv_dgrad(dout, wt, s.shape, 2, 2, 2, 0)
-            elif i == 0 and stem_reduction_operands(self, sv) is not None:
-                # the gradient leaving the first block enters the stem's pool / ReLU / BN: its sums ride in the block's last kernel
-                dout, part = swin_block_backward(mod, s, dout, dt, bc, next_bn=stem_reduction_operands(self, sv))
+                dout, part = ops.conv_dgrad(dout, wt, s.shape, 2, 2, 2, 0), None
+                continue
+            # the gradient leaving block i enters norm3 of block i-1 (or, for the first block, the stem's pool / ReLU / BN):
+            # that BatchNorm's backward sums ride in block i's last kernel
+            if i == 0:
+                nxt = stem_reduction_operands(self, sv)
+            elif not isinstance(layers[i - 1], _Conv):
+                nxt = (sv.layers[i - 1].mo, sv.layers[i - 1].st3, False)
             else:
-                dout = swin_block_backward(mod, s, dout, dt, bc)
+                nxt = None
+            res = swin_block_backward(mod, s, dout, dt, bc, next_bn=nxt, part3=part)
+            dout, part = res if nxt is not None else (res, None)
         stem_backward(self, sv, dout, bc, part)
         return bc.join()
 
