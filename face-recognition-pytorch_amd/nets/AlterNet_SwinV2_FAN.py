@@ -129,7 +129,7 @@ def attn_block_backward(blk, s, dout, dt, bc):
     d2 = dout.reshape(m, c)
     dbranch = d2 if s.keep is None else (d2.view(b, -1) * s.keep[:, None]).view(m, c).contiguous()
     dpo = ops.bn_backward(dbranch, s.po, s.st2, blk.norm2.weight.data, G(blk.norm2.weight), G(blk.norm2.bias))
-    ops.colsum_accumulate(dpo, G(at.proj.bias))
+    # proj.bias only shifts the input of a training-mode BatchNorm: analytically zero gradient (nets/SwinV2.py), left at zero
     bc.on_side(lambda: ops.gemm_tn(dpo, s.ao, G(at.proj.weight)), dpo, s.ao)
     dao = ops.gemm_nt(dpo, _S._transposed(s.wproj, s.wproj_t))
     dqkv, dbias, dscale, gsum = ops.winattn_bwd(s.qkv, dao, s.bias, s.scale, b, h, w, at.num_heads, blk.window_size,

@@ -243,7 +243,9 @@ def swin_block_backward(blk, s, dout, dt, bc, next_bn=None, part3=None):
     d2 = dout.reshape(m, c)
     # ---- MLP branch: x2 = x1 + BN(fc2(gelu(fc1(x1))))
     dmo = ops.bn_backward(d2, s.mo, s.st3, blk.norm3.weight.data, G(blk.norm3.weight), G(blk.norm3.bias), part=part3)
-    ops.colsum_accumulate(dmo, G(blk.mlp.fc2.bias))
+    # fc2.bias (and proj.bias below) only shift the input of a training-mode BatchNorm: their gradient, the column sums of
+    # that BatchNorm's input gradient, is analytically zero (sum_rows dy = gamma * invstd * (sum d - N mean(d) - mean(d xhat)
+    # * sum xhat) = 0); the reference gets 1e-8-sized round-off there.  Left at the arena's zero: no reduction pass.
     bc.on_side(lambda: ops.gemm_tn(dmo, s.act, G(blk.mlp.fc2.weight).view(c, 4 * c)), dmo, s.act)
     # [M, 4C]: fc2's data-gradient with gelu'(hid) and fc1.bias's gradient (column sums) fused into its epilogue
     dhid, db1 = ops.linear_dgrad_gelu(dmo, _transposed(s.w2, s.w2_t), s.hid)
@@ -253,7 +255,6 @@ def swin_block_backward(blk, s, dout, dt, bc, next_bn=None, part3=None):
     dx1, part2 = _dgrad_add(dhid, s.w1, d2, s.w1_t, bnred=(s.po, s.st2, False))
     # ---- attention branch: x1 = x + BN(proj(attn(qkv(x))))
     dpo = ops.bn_backward(dx1, s.po, s.st2, blk.norm2.weight.data, G(blk.norm2.weight), G(blk.norm2.bias), part=part2)
-    ops.colsum_accumulate(dpo, G(at.proj.bias))
     bc.on_side(lambda: ops.gemm_tn(dpo, s.ao, G(at.proj.weight)), dpo, s.ao)
     dao = ops.gemm_nt(dpo, _transposed(s.wproj, s.wproj_t))
     dqkv, dbias, dscale, gsum = ops.winattn_bwd(s.qkv, dao, s.bias, s.scale, b, h, w, at.num_heads, want_colsum=True)
