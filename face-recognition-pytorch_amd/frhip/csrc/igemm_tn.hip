@@ -782,7 +782,7 @@ static int tn_finish(const TnGeom& g, float* out, int splits, size_t out_elems, 
 
 static int tn_run(int dtype, const void* p, const void* q, float* out, int n, int h, int w, int c, int kc, int ldp,
                   int r, int s, int stride, int pad, int splits, float* ws, size_t ws_bytes, hipStream_t stream,
-                  const char* who) {
+                  const char* who, bool overwrite = false) {
     const int es = dtype == FRHIP_DT_BF16 ? 2 : 4;
     if (dtype != FRHIP_DT_BF16 && dtype != FRHIP_DT_F32) { set_error("%s: bad dtype %d", who, dtype); return FRHIP_EINVAL; }
     const int epv = 16 / es;
@@ -858,6 +858,17 @@ static int tn_run(int dtype, const void* p, const void* q, float* out, int n, in
     splits = (g.ksteps + g.ksteps_per_split - 1) / g.ksteps_per_split;
     const bool linear = g_tn_linear && dtype == FRHIP_DT_BF16 && stride == 1 && g.Ho == h && g.Wo == w && r == s &&
                         1LL * (M + 64 + 2LL * w + 2) * (ldp > c ? ldp : c) * es < 0x7fffffffLL;
+    if (overwrite && splits == 1) {
+        // out = result (not +=) and a single K split: the "slab" store path with slab 0 = out itself -- plain coalesced stores,
+        // no zero fill by the caller and no fp32 atomic read-modify-write pass over the output (the head's 250-MB dW)
+        g.slab_stride = (int)out_elems;
+        if (dtype == FRHIP_DT_BF16) return big ? tn_launch<bf16_t, 256>(g, p, q, out, taps, 1, stream) : tn_launch<bf16_t, 128>(g, p, q, out, taps, 1, stream);
+        return big ? tn_launch<float, 256>(g, p, q, out, taps, 1, stream) : tn_launch<float, 128>(g, p, q, out, taps, 1, stream);
+    }
+    if (overwrite && hipMemsetAsync(out, 0, out_elems * sizeof(float), stream) != hipSuccess) {
+        set_error("%s: cannot clear the output", who);
+        return FRHIP_ELAUNCH;
+    }
     float* dst = tn_pick_dst(g, out, splits, out_elems, ws, ws_bytes);
     if (linear) rc = big ? tn_lin_launch<256>(g, p, q, dst, taps, splits, stream)
                          : tn_lin_launch<128>(g, p, q, dst, taps, splits, stream);
@@ -885,6 +896,13 @@ extern "C" int frhip_conv_wgrad(int dtype, const void* dy, const void* x, float*
     // dw[k][r][s][c] (fp32, caller-zeroed) += sum over output pixels of dy[m][k] * x[pix(m,r,s)][c]
     return tn_run(dtype, dy, x, dw, n, h, w, c, k, k, r, s, stride, pad, splits, workspace, workspace_bytes, stream,
                   "frhip_conv_wgrad");
+}
+
+extern "C" int frhip_gemm_tn_overwrite(int dtype, const void* p, const void* q, float* out, int m, int kc, int ldp, int c,
+                                       float* workspace, size_t workspace_bytes, hipStream_t stream) {
+    // out[kc][c] (fp32, need not be initialised) = sum_m p[m][0..kc) (pitch ldp) * q[m][0..c)
+    return tn_run(dtype, p, q, out, m, 1, 1, c, kc, ldp, 1, 1, 1, 0, 0, workspace, workspace_bytes, stream,
+                  "frhip_gemm_tn_overwrite", true);
 }
 
 extern "C" int frhip_gemm_tn(int dtype, const void* p, const void* q, float* out, int m, int kc, int ldp, int c,

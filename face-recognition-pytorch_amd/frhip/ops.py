@@ -149,12 +149,16 @@ def linear_dgrad_gelu(dy, wt, pre, want_colsum=True):
     return dx, (part[:, 0].sum(0) if want_colsum else None)
 
 
-def gemm_tn(p, q, out, kc=None, splits=0):
-    """out[kc][c] fp32 += sum_m p[m][:kc] * q[m][:c]"""
+def gemm_tn(p, q, out, kc=None, splits=0, overwrite=False):
+    """out[kc][c] fp32 += sum_m p[m][:kc] * q[m][:c]      (overwrite: out = ..., out need not be initialised)"""
     m, ldp = p.shape
     c = q.shape[1]
     kc = ldp if kc is None else kc
     ws = workspace(p.device)
+    if overwrite:
+        check(lib().frhip_gemm_tn_overwrite(dt_of(p), _p(p), _p(q), _p(out), m, kc, ldp, c, _p(ws), ws.numel() * 4, _s()),
+              "frhip_gemm_tn_overwrite")
+        return out
     check(lib().frhip_gemm_tn(dt_of(p), _p(p), _p(q), _p(out), m, kc, ldp, c, splits, _p(ws), ws.numel() * 4, _s()),
           "frhip_gemm_tn")
     return out

@@ -451,8 +451,8 @@ def tail_backward(net, sv, d_emb, bc):
     b, kfc = sv.flat.shape
     wfct = ops.transpose2d(sv.wfc)                                  # [25088][512]
     dflat = ops.gemm_nt(dft, wfct)                                  # [B][25088]
-    dwp = torch.zeros((net.emd_size, kfc), dtype=torch.float32, device=d_emb.device)
-    ops.gemm_tn(dft, sv.flat, dwp)
+    dwp = torch.empty((net.emd_size, kfc), dtype=torch.float32, device=d_emb.device)
+    ops.gemm_tn(dft, sv.flat, dwp, overwrite=True)                  # 51 MB: stored once (no zero fill + atomic pass)
     co = sv.out4.shape[3]
     ops.fc_unpermute_grad(dwp, G(net.fc.weight), co, kfc // co)
     dz = dflat.view(sv.out4.shape)

@@ -106,6 +106,10 @@ int frhip_gemm_nt(int dtype, const void* a, const void* b, void* out, int m, int
 /* out[kc][c] (fp32, caller-zeroed) += sum_m p[m][0..kc) * q[m][0..c);  p has row pitch ldp elements. */
 int frhip_gemm_tn(int dtype, const void* p, const void* q, float* out, int m, int kc, int ldp, int c,
                   int splits, float* workspace, size_t workspace_bytes, frhip_stream_t stream);
+/* the same with out = (not +=): `out` need not be initialised; with a single K split (m <= 512 rows) the tiles are stored
+ * plainly -- no zero fill and no atomic read-modify-write pass (the head's dW = dT^T E is 250 MB, nets/PartialFC.py:201) */
+int frhip_gemm_tn_overwrite(int dtype, const void* p, const void* q, float* out, int m, int kc, int ldp, int c,
+                            float* workspace, size_t workspace_bytes, frhip_stream_t stream);
 
 /* ---- BatchNorm + element-wise glue.  nn.BatchNorm2d/1d: nets/resnet.py:81-86, :187, :196-199 ---- */
 int frhip_colreduce_blocks(int rows, int c, int dtype);   /* number of partial rows frhip_colstats / _bn_bwd_reduce write */

@@ -304,6 +304,19 @@ def test_gemm_tn(dtype, shape):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("shape", [(96, 200, 208, 64), (512, 1000, 1000, 512), (3000, 128, 128, 256)])
+def test_gemm_tn_overwrite(dtype, shape):
+    """out = P^T Q into an UNINITIALISED buffer: plain stores for a single K split (m <= 512), cleared + accumulated beyond"""
+    ops = _ops()
+    m, kc, ldp, c = shape
+    p, qq = q(rnd(17, (m, ldp)), dtype), q(rnd(18, (m, c)), dtype)
+    ref = p[:, :kc].t() @ qq
+    out = torch.full((kc, c), float("nan"), dtype=torch.float32, device="cuda")
+    ops.gemm_tn(p.to(dtype).cuda(), qq.to(dtype).cuda(), out, kc=kc, overwrite=True)
+    np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), rtol=2e-4, atol=2e-4 * ref.abs().max().item())
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("rc", [(300, 64), (4 * 7 * 7, 512), (2000, 128)])
 def test_batchnorm_forward_backward(dtype, rc):
     ops = _ops()
