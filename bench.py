@@ -161,8 +161,14 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    # rehearsal hook (one-GPU boxes): FRHIP_BENCH_BACKEND=gloo runs the N > 1 code path with every rank on cuda:0
+    backend = os.environ.get("FRHIP_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local = 0
     torch.cuda.set_device(local)
-    if world > 1 or args.dist_path:
+    if backend != "nccl" and world > 1:
+        dist.init_process_group(backend)
+    elif world > 1 or args.dist_path:
         if world == 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29533")
