@@ -319,6 +319,18 @@ struct EpiOperands {
     }
 };
 
+// Output rows of the store epilogue go out with non-temporal stores: a conv / linear output is written once and read one
+// kernel later by a streaming pass (which reads it non-temporally as well), so it should not push the weights and the next
+// operand out of L2 on its way.  Step-level A/B (tools/ab_libs.sh, three passes on one box): ResNet50 28.06 / 27.90 / 28.07 ->
+// 27.83 / 27.85 / 27.87 ms, Swin34 19.31 -> 19.0 ms.  -DEPI_NT_STORE=0 builds the plain-store variant.
+#ifndef EPI_NT_STORE
+#define EPI_NT_STORE 1
+#endif
+template <typename T> __device__ __forceinline__ void epi_store_row(T* p, const Vec16<T>& v) {
+    if constexpr (EPI_NT_STORE) __builtin_nontemporal_store(v.v, reinterpret_cast<decltype(v.v)*>(p));
+    else *reinterpret_cast<Vec16<T>*>(p) = v;
+}
+
 // Shared store epilogue: the wave's (WROWS x 64) tile sits in its LDS staging area `mine` as T (row = pixel).
 // Rows are written back as whole 128/256-byte lines (+ optional residual); the same read-back accumulates the
 // per-channel sum / sum of squares of the STORED values -> BN batch-statistic partials [mtile][2][Nout]
@@ -358,7 +370,7 @@ __device__ __forceinline__ void nt_epilogue_store(const char* mine, int P, char*
 #pragma unroll
                     for (int e = 0; e < EPV; ++e) v.set(e, v.get(e) + rr.get(e));
                 }
-                *reinterpret_cast<Vec16<T>*>(o + (size_t)br.map.row(m) * Nout + n) = v;
+                epi_store_row(o + (size_t)br.map.row(m) * Nout + n, v);
                 const Vec16<T> yr = ops.y_row(it);
 #pragma unroll
                 for (int e = 0; e < EPV; ++e) {
@@ -399,7 +411,7 @@ __device__ __forceinline__ void nt_epilogue_store(const char* mine, int P, char*
                     }
                 }
                 const size_t orow = (size_t)br.map.row(m);
-                *reinterpret_cast<Vec16<T>*>(o + orow * Nout + n) = v;
+                epi_store_row(o + orow * Nout + n, v);
                 if (ao) {
                     Vec16<T> ga;
 #pragma unroll
