@@ -11,6 +11,10 @@
 #include "common.h"
 #include "frhip.h"
 
+// TN_SLAB_NT (build-time experiment switch): bit 0 non-temporal slab stores in the nine-tap kernel, bit 1 non-temporal slab loads
+#ifndef TN_SLAB_NT
+#define TN_SLAB_NT 0
+#endif
 #ifndef T9_AUX
 #define T9_AUX 0          // cache policy of the nine-tap kernel's operand loads (experiment switch)
 #endif
@@ -654,7 +658,7 @@ void tn_taps9_kernel(TnGeom g, const void* __restrict__ p_ptr, const void* __res
 #pragma unroll
                 for (int t = 0; t < 9; ++t) {
                     const size_t idx = ((size_t)co * 9 + t) * g.C + ci;
-                    if (g.slab_stride) dst[idx] = acc[t][a][b][e];
+                    if (g.slab_stride) { if constexpr (TN_SLAB_NT & 1) __builtin_nontemporal_store(acc[t][a][b][e], dst + idx); else dst[idx] = acc[t][a][b][e]; }
                     else atomicAdd(dst + idx, acc[t][a][b][e]);
                 }
             }
@@ -683,6 +687,11 @@ static int tn_taps9_launch(const TnGeom& g, const void* p, const void* q, float*
 // Sum of K-split slabs, float4 per thread, no atomics (deterministic).  blockIdx.y = g owns slabs g*per_group ..:
 //   final == 0: their sum overwrites the group's first slab (first level of a two-level tree)
 //   final == 1: out[i] += sum (gridDim.y must be 1)
+__device__ __forceinline__ f32x4_t slab_load(const float* p) {
+    if constexpr (TN_SLAB_NT & 2) return __builtin_nontemporal_load(reinterpret_cast<const f32x4_t*>(p));
+    else return *reinterpret_cast<const f32x4_t*>(p);
+}
+
 __global__ __launch_bounds__(256) void slab_reduce_kernel(float* __restrict__ slabs, int count, int per_group,
                                                           size_t step, float* __restrict__ out, size_t n4, int final) {
     const int s0 = blockIdx.y * per_group, s1 = min(count, s0 + per_group);
@@ -690,10 +699,10 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(float* __restrict__ sl
         f32x4_t a0 = f32x4_t{0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
         int sp = s0;
         for (; sp + 4 <= s1; sp += 4) {
-            const f32x4_t v0 = *reinterpret_cast<const f32x4_t*>(slabs + (size_t)(sp + 0) * step + i * 4);
-            const f32x4_t v1 = *reinterpret_cast<const f32x4_t*>(slabs + (size_t)(sp + 1) * step + i * 4);
-            const f32x4_t v2 = *reinterpret_cast<const f32x4_t*>(slabs + (size_t)(sp + 2) * step + i * 4);
-            const f32x4_t v3 = *reinterpret_cast<const f32x4_t*>(slabs + (size_t)(sp + 3) * step + i * 4);
+            const f32x4_t v0 = slab_load(slabs + (size_t)(sp + 0) * step + i * 4);
+            const f32x4_t v1 = slab_load(slabs + (size_t)(sp + 1) * step + i * 4);
+            const f32x4_t v2 = slab_load(slabs + (size_t)(sp + 2) * step + i * 4);
+            const f32x4_t v3 = slab_load(slabs + (size_t)(sp + 3) * step + i * 4);
             a0 += v0; a1 += v1; a2 += v2; a3 += v3;
         }
         for (; sp < s1; ++sp) a0 += *reinterpret_cast<const f32x4_t*>(slabs + (size_t)sp * step + i * 4);
