@@ -255,8 +255,21 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__
         const size_t o = ((((size_t)n * Hp + ph) * Wp + pw) * VPR + cv) * EPV;
         Vec16<T> ov;
 #pragma unroll
-        for (int e = 0; e < EPV; ++e) { ov.set(e, best[e]); argmax[o + e] = (uint8_t)bi[e]; }
+        for (int e = 0; e < EPV; ++e) ov.set(e, best[e]);
         *reinterpret_cast<Vec16<T>*>(pooled + o) = ov;
+        // the EPV arg-max bytes of this lane as ONE store (o is a multiple of EPV): 64 lanes x 8 B = 512 contiguous bytes
+        // instead of eight instructions of stride-8 single bytes
+        if constexpr (EPV == 8) {
+            uint64_t pk = 0;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) pk |= (uint64_t)(uint32_t)bi[e] << (8 * e);
+            *reinterpret_cast<uint64_t*>(argmax + o) = pk;
+        } else {
+            uint32_t pk = 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) pk |= (uint32_t)bi[e] << (8 * e);
+            *reinterpret_cast<uint32_t*>(argmax + o) = pk;
+        }
     }
 }
 
