@@ -192,6 +192,36 @@ __global__ void head_target_prob_kernel(const float* __restrict__ ztarget, const
     if (m < N) q[m] = labels[m] >= 0 ? __expf(ztarget[m] - rowmax[m]) / rowsum[m] : 0.f;
 }
 
+// Cross-shard merge of the per-row softmax statistics in ONE exchange (reference nets/PartialFC.py:448, :453, :459 issues an
+// all-reduce MAX and two all-reduce SUMs).  Every rank packs {local max, local sum-exp, target logit or -inf} per row; the
+// packed [N][3] blocks of all ranks are all-gathered and every rank folds them in rank order (same result on every rank).
+__global__ void head_pack_stats_kernel(const float* __restrict__ ztarget, const int* __restrict__ labels,
+                                       const float* __restrict__ rowmax, const float* __restrict__ rowsum,
+                                       float* __restrict__ packed, int N) {
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m < N) {
+        packed[3 * m + 0] = rowmax[m];
+        packed[3 * m + 1] = rowsum[m];
+        packed[3 * m + 2] = labels[m] >= 0 ? ztarget[m] : -INFINITY;
+    }
+}
+
+// gathered [ws][N][3] -> global max M, global sum S = sum_r s_r exp(m_r - M), q = exp(z_owner - M) / S (0: nobody owns the row)
+__global__ void head_merge_stats_kernel(const float* __restrict__ gathered, int ws, int N, float* __restrict__ gmax,
+                                        float* __restrict__ gsum, float* __restrict__ q) {
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= N) return;
+    float M = -INFINITY;
+    for (int r = 0; r < ws; ++r) M = fmaxf(M, gathered[((size_t)r * N + m) * 3]);
+    float S = 0.f, num = 0.f;
+    for (int r = 0; r < ws; ++r) {
+        const float* g = gathered + ((size_t)r * N + m) * 3;
+        S += g[1] * __expf(g[0] - M);
+        if (g[2] > -INFINITY) num += __expf(g[2] - M);
+    }
+    gmax[m] = M; gsum[m] = S; q[m] = num / S;
+}
+
 // loss = -mean(log(max(q, 1e-30)))          single block
 __global__ void head_loss_kernel(const float* __restrict__ q, int N, float* __restrict__ loss) {
     __shared__ float red[256];
@@ -293,6 +323,19 @@ extern "C" int frhip_head_target_prob(const float* ztarget, const int* labels, c
                                       float* q, int n, hipStream_t stream) {
     hipLaunchKernelGGL(head_target_prob_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, ztarget, labels, rowmax, rowsum, q, n);
     return check_launch("frhip_head_target_prob");
+}
+
+extern "C" int frhip_head_pack_stats(const float* ztarget, const int* labels, const float* rowmax, const float* rowsum,
+                                     float* packed, int n, hipStream_t stream) {
+    hipLaunchKernelGGL(head_pack_stats_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, ztarget, labels, rowmax, rowsum, packed, n);
+    return check_launch("frhip_head_pack_stats");
+}
+
+extern "C" int frhip_head_merge_stats(const float* gathered, int world_size, int n, float* rowmax, float* rowsum, float* q,
+                                      hipStream_t stream) {
+    if (world_size <= 0 || n <= 0) { set_error("frhip_head_merge_stats: bad shape (ws=%d n=%d)", world_size, n); return FRHIP_EINVAL; }
+    hipLaunchKernelGGL(head_merge_stats_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, gathered, world_size, n, rowmax, rowsum, q);
+    return check_launch("frhip_head_merge_stats");
 }
 
 extern "C" int frhip_head_loss(const float* q, int n, float* loss, hipStream_t stream) {

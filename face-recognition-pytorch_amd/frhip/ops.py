@@ -472,6 +472,22 @@ def head_target_prob(zt, labels_i32, rmax, rsum):
     return q
 
 
+def head_pack_stats(zt, labels_i32, rmax, rsum, out=None):
+    """[N,3] fp32 {local max, local sum-exp, target logit | -inf}: this rank's block of the one-exchange CE merge"""
+    n = zt.numel()
+    out = torch.empty((n, 3), dtype=torch.float32, device=zt.device) if out is None else out
+    check(lib().frhip_head_pack_stats(_p(zt), _p(labels_i32), _p(rmax), _p(rsum), _p(out), n, _s()), "frhip_head_pack_stats")
+    return out
+
+
+def head_merge_stats(gathered):
+    """gathered [ws,N,3] (all-gathered head_pack_stats blocks) -> global (rowmax, rowsum, q)"""
+    ws, n, _ = gathered.shape
+    buf = torch.empty((3, n), dtype=torch.float32, device=gathered.device)
+    check(lib().frhip_head_merge_stats(_p(gathered), ws, n, _p(buf[0]), _p(buf[1]), _p(buf[2]), _s()), "frhip_head_merge_stats")
+    return buf[0], buf[1], buf[2]
+
+
 def head_loss(q):
     loss = torch.empty((1,), dtype=torch.float32, device=q.device)
     check(lib().frhip_head_loss(_p(q), q.numel(), _p(loss), _s()), "frhip_head_loss")

@@ -113,8 +113,9 @@ class SGD(torch.optim.SGD):
             return loss
         clip_sig = None if clip is None else (id(clip[0][0]) if clip[0] else 0, len(clip[0]))
         clip_ids = None
-        # One chunk table per parameter group, cached by the pointer signature of its (parameter, gradient, momentum)
-        # triples: PartialFC swaps the sampled class-centre parameter of the LAST group every step, which then rebuilds a
+        # One chunk table per parameter group, cached by the pointer + size signature of its (parameter, gradient, momentum)
+        # triples (the size matters: the caching allocator hands a freed block to a tensor of another size at the same
+        # address, and PartialFC's `index = positive` branch changes the row count of its parameter from step to step): PartialFC swaps the sampled class-centre parameter of the LAST group every step, which then rebuilds a
         # ~100-chunk table instead of the whole model's.
         hits, keep = [], []
         for gi, g in enumerate(self.param_groups):
@@ -127,7 +128,7 @@ class SGD(torch.optim.SGD):
             if not entries:
                 hits.append(None)
                 continue
-            key = (gi, clip_sig) + tuple((p.data_ptr(), gr.data_ptr(), 0 if m is None else m.data_ptr()) for p, gr, m, _ in entries)
+            key = (gi, clip_sig) + tuple((p.data_ptr(), gr.data_ptr(), 0 if m is None else m.data_ptr(), p.numel()) for p, gr, m, _ in entries)
             hit = self._tables.get(key)
             if hit is None:
                 fixed = []
@@ -147,7 +148,7 @@ class SGD(torch.optim.SGD):
                 hit = (table, n, all(inside), torch.empty(n, dtype=torch.float32, device=device))
                 if len(self._tables) >= 16:
                     self._tables.clear()
-                key = (gi, clip_sig) + tuple((p.data_ptr(), gr.data_ptr(), 0 if m is None else m.data_ptr()) for p, gr, m, _ in entries)
+                key = (gi, clip_sig) + tuple((p.data_ptr(), gr.data_ptr(), 0 if m is None else m.data_ptr(), p.numel()) for p, gr, m, _ in entries)
                 self._tables[key] = hit
                 if self._coef is None or self._coef.device != device:
                     self._coef = torch.ones(2, dtype=torch.float32, device=device)
@@ -273,7 +274,7 @@ class AdamW(torch.optim.AdamW):
             steps.append(gstep)
         if not entries:
             return loss
-        key = tuple((p.data_ptr(), gr.data_ptr(), 0 if m is None else m.data_ptr(), 0 if v is None else v.data_ptr(), gi)
+        key = tuple((p.data_ptr(), gr.data_ptr(), 0 if m is None else m.data_ptr(), 0 if v is None else v.data_ptr(), gi, p.numel())
                     for p, gr, m, v, gi in entries)
         clip_sig = None if clip is None else (id(clip[0][0]) if clip[0] else 0, len(clip[0]))
         hit = self._tables.get((key, clip_sig))
@@ -306,7 +307,7 @@ class AdamW(torch.optim.AdamW):
             hit = (table, n, group_clip, torch.empty(n, dtype=torch.float32, device=device))
             if len(self._tables) >= 8:
                 self._tables.clear()
-            key = tuple((p.data_ptr(), gr.data_ptr(), m.data_ptr(), v.data_ptr(), gi) for p, gr, m, v, gi in entries)
+            key = tuple((p.data_ptr(), gr.data_ptr(), m.data_ptr(), v.data_ptr(), gi, p.numel()) for p, gr, m, v, gi in entries)
             self._tables[(key, clip_sig)] = hit
             if self._coef is None or self._coef.device != device:
                 self._coef = torch.ones(2, dtype=torch.float32, device=device)

@@ -14,9 +14,12 @@ What runs where
     ArcFace margin -> x s -> per-row max / sum-exp (logits never reach HBM), a recompute kernel that emits
     d loss / d cos once, two MFMA TN GEMMs for dW and dE, normalise-backward, and row gather / scatter of the
     sampled class centres;
-  * cross-rank traffic is torch.distributed (backend "nccl" = RCCL over xGMI): one all-gather of embeddings +
-    labels, all-reduce MAX / SUM of the per-row scalars, and a reduce-scatter of dE (the reference issues
-    world_size separate reduce() calls, :510-519).
+  * cross-rank traffic is torch.distributed (backend "nccl" = RCCL over xGMI), FOUR collectives per step on
+    preallocated flat buffers: an all-gather of the labels at the start of the step (prepare(): off the critical
+    path), an all-gather of the embeddings (:182), ONE all-gather of the packed per-row {max, sum-exp, target logit}
+    triples that every rank merges itself (the reference issues all-reduce MAX, SUM, SUM, :448-459), and ONE
+    reduce-scatter of dE issued before the dW GEMM so the two overlap (the reference loops world_size reduce() calls,
+    :510-519).
 The floating-point steps sit behind `HipHeadKernels`; tests on CPU/gloo swap in an oracle-backed double to
 exercise the distributed host logic without a GPU.  There is no built-in CPU fallback.
 """
@@ -59,17 +62,28 @@ class HipHeadKernels:
     def loss(self, q):
         return self.ops.head_loss(q)
 
-    def backward(self, ehat, enorm, what, wnorm, labels_i32, s, m, rmax, rsum, n_global, upstream):
+    def pack_stats(self, zt, labels_i32, rmax, rsum):
+        return self.ops.head_pack_stats(zt, labels_i32, rmax, rsum)
+
+    def merge_stats(self, gathered):
+        return self.ops.head_merge_stats(gathered)                         # global (rowmax, rowsum, q)
+
+    def backward(self, ehat, enorm, what, wnorm, labels_i32, s, m, rmax, rsum, n_global, upstream, e_scale=1.0, on_de=None):
+        """-> (d_emb * e_scale, d_weight).  on_de(d_emb) is called as soon as the embedding gradient is enqueued, before the
+        weight-gradient GEMM: the caller starts the cross-rank reduce-scatter there and the two overlap."""
         ops = self.ops
         n, d = ehat.shape
         classes = what.shape[0]
         dt = ops.head_bwd_dt(ehat, what, labels_i32, s, m, rmax, rsum, 1.0 / n_global, upstream)
-        d_wh = torch.empty((classes, d), dtype=torch.float32, device=ehat.device)
-        ops.gemm_tn(dt, ehat, d_wh, kc=classes, overwrite=True)      # 250 MB at 122 000 classes: stored once, never zero-filled
         dtt = ops.transpose2d(dt, pad_to=8)
         d_eh = torch.zeros((n, d), dtype=torch.float32, device=ehat.device)
         ops.gemm_tn(dtt[:classes], what, d_eh, kc=n)
-        return ops.l2norm_bwd(d_eh, ehat, enorm), ops.l2norm_bwd(d_wh, what, wnorm)
+        d_e = ops.l2norm_bwd(d_eh, ehat, enorm, out_scale=e_scale)
+        if on_de is not None:
+            on_de(d_e)
+        d_wh = torch.empty((classes, d), dtype=torch.float32, device=ehat.device)
+        ops.gemm_tn(dt, ehat, d_wh, kc=classes, overwrite=True)      # 250 MB at 122 000 classes: stored once, never zero-filled
+        return d_e, ops.l2norm_bwd(d_wh, what, wnorm)
 
     def gather_rows(self, table, index):
         return self.ops.gather_rows(table, index)
@@ -88,9 +102,26 @@ def _backend_is_nccl():
     return distributed.get_backend() == "nccl"
 
 
+def _all_gather_flat(out, inp):
+    """all-gather into ONE preallocated buffer (out = [world_size * rows, ...]): no per-rank tensor list, no c10d copies"""
+    distributed.all_gather_into_tensor(out, inp)
+    return out
+
+
+def _reduce_scatter_sum(stacked, rank, rows, async_op=False):
+    """-> (this rank's [rows, ...] slice of the SUM over ranks of `stacked`, work or None)"""
+    if _backend_is_nccl():
+        out = torch.empty_like(stacked[:rows])
+        work = distributed.reduce_scatter_tensor(out, stacked, op=distributed.ReduceOp.SUM, async_op=async_op)
+        return out, (work if async_op else None)
+    distributed.all_reduce(stacked, op=distributed.ReduceOp.SUM)       # gloo (tests) has no reduce_scatter
+    return stacked[rank * rows:(rank + 1) * rows].clone(), None
+
+
 class AllGatherFunc(torch.autograd.Function):
     """all_gather with gradient: backward = reduce-scatter(SUM) of the per-chunk gradients, x world_size
-    (reference :495-525, which loops world_size reduce() calls)."""
+    (reference :495-525, which loops world_size reduce() calls).  Kept for the reference's surface
+    (`AllGather(tensor, *gather_list)`); PartialFC.forward itself gathers inside its fused autograd node."""
 
     @staticmethod
     def forward(ctx, tensor, *gather_list):
@@ -102,13 +133,7 @@ class AllGatherFunc(torch.autograd.Function):
     def backward(ctx, *grads):
         ws, rank = distributed.get_world_size(), distributed.get_rank()
         stacked = torch.cat([g.contiguous() for g in grads])
-        if _backend_is_nccl():
-            out = torch.empty_like(grads[rank])
-            distributed.reduce_scatter_tensor(out, stacked, op=distributed.ReduceOp.SUM)
-        else:                                   # gloo has no reduce_scatter
-            distributed.all_reduce(stacked, op=distributed.ReduceOp.SUM)
-            b = grads[rank].shape[0]
-            out = stacked[rank * b:(rank + 1) * b].clone()
+        out, _ = _reduce_scatter_sum(stacked, rank, grads[rank].shape[0])
         out *= ws
         return (out, *[None for _ in grads])
 
@@ -117,25 +142,29 @@ AllGather = AllGatherFunc.apply
 
 
 class _MarginSoftmaxFn(torch.autograd.Function):
-    """normalise -> cos -> margin -> distributed softmax-CE, as one autograd node over the fused kernels.
-    Arithmetic: SURVEY.md Appendix A steps 1-6 (nets/PartialFC.py:198-207, nets/ArcFace.py:76-91, :441-484)."""
+    """all-gather -> normalise -> cos -> margin -> distributed softmax-CE, as ONE autograd node over the fused kernels,
+    from the rank's LOCAL embeddings to the global loss.
+    Arithmetic: SURVEY.md Appendix A steps 1-7 (nets/PartialFC.py:182, :198-207, nets/ArcFace.py:76-91, :441-484, :504-522)."""
 
     @staticmethod
-    def forward(ctx, embeddings, weight_activated, labels_i32, kern, s, m, world_size):
+    def forward(ctx, local_embeddings, weight_activated, labels_i32, kern, s, m, world_size, collectives):
+        local_embeddings = local_embeddings.contiguous()
+        rows, dim = local_embeddings.shape
+        if collectives:                                                         # :182 (C1)
+            embeddings = _all_gather_flat(local_embeddings.new_empty((world_size * rows, dim)), local_embeddings)
+        else:
+            embeddings = local_embeddings
         ehat, enorm = kern.normalize(embeddings)
         what, wnorm = kern.normalize(weight_activated)
         zt, rmax, rsum = kern.forward_stats(ehat, what, labels_i32, s, m)
-        if world_size > 1:
-            gmax = rmax.clone()
-            distributed.all_reduce(gmax, distributed.ReduceOp.MAX)          # :448
-            kern.rescale(rsum, rmax, gmax)
-            distributed.all_reduce(rsum, distributed.ReduceOp.SUM)          # :453
-            rmax = gmax
-        q = kern.target_prob(zt, labels_i32, rmax, rsum)
-        if world_size > 1:
-            distributed.all_reduce(q, distributed.ReduceOp.SUM)             # :459
+        if collectives:                                                         # :448, :453, :459 (C3-C5) in one exchange
+            mine = kern.pack_stats(zt, labels_i32, rmax, rsum)
+            allst = _all_gather_flat(mine.new_empty((world_size * mine.shape[0], mine.shape[1])), mine)
+            rmax, rsum, q = kern.merge_stats(allst.view(world_size, mine.shape[0], mine.shape[1]))
+        else:
+            q = kern.target_prob(zt, labels_i32, rmax, rsum)
         loss = kern.loss(q)
-        ctx.kern, ctx.s, ctx.m = kern, s, m
+        ctx.kern, ctx.s, ctx.m, ctx.world_size, ctx.collectives, ctx.rows = kern, s, m, world_size, collectives, rows
         ctx.save_for_backward(ehat, enorm, what, wnorm, labels_i32, rmax, rsum)
         return loss.reshape(())
 
@@ -143,9 +172,23 @@ class _MarginSoftmaxFn(torch.autograd.Function):
     def backward(ctx, grad_loss):
         ehat, enorm, what, wnorm, labels_i32, rmax, rsum = ctx.saved_tensors
         up = grad_loss.reshape(1).float().contiguous()
-        d_e, d_w = ctx.kern.backward(ehat, enorm, what, wnorm, labels_i32, ctx.s, ctx.m, rmax, rsum,
-                                     ehat.shape[0], up)
-        return d_e, d_w, None, None, None, None, None
+        if not ctx.collectives:
+            d_e, d_w = ctx.kern.backward(ehat, enorm, what, wnorm, labels_i32, ctx.s, ctx.m, rmax, rsum, ehat.shape[0], up)
+            return d_e, d_w, None, None, None, None, None, None
+        # :504-522 (C6): reduce-scatter(SUM) of dE, x world_size (folded into the normalise-backward's scale); issued as soon
+        # as dE is enqueued so that it runs beside the dW GEMM
+        pending = []
+        rank = distributed.get_rank()
+
+        def start(d_e):
+            pending.append(_reduce_scatter_sum(d_e, rank, ctx.rows, async_op=True))
+
+        _, d_w = ctx.kern.backward(ehat, enorm, what, wnorm, labels_i32, ctx.s, ctx.m, rmax, rsum, ehat.shape[0], up,
+                                   e_scale=float(ctx.world_size), on_de=start)
+        d_local, work = pending[0]
+        if work is not None:
+            work.wait()
+        return d_local, d_w, None, None, None, None, None, None
 
 
 class DistCrossEntropyFunc(torch.autograd.Function):
@@ -226,6 +269,9 @@ class _PartialFCBase(torch.nn.Module):
         self._kernels = kernels
         self._conf = conf
         self.step = 0
+        # CPU generator of the sampling draws.  None = torch's default generator, exactly like the reference (:110); a
+        # dedicated torch.Generator keeps the draws apart from everything else that consumes the default one
+        self.generator = getattr(conf, "sample_generator", None)
 
     # -- subclass hooks
     def _optimizer_state_names(self):
@@ -261,7 +307,7 @@ class _PartialFCBase(torch.nn.Module):
         else:
             positive = torch.unique(labels[index_positive], sorted=True)
             if self.num_sample - positive.size(0) >= 0:
-                perm = torch.rand(size=[self.num_local]).to(dev)
+                perm = torch.rand(size=[self.num_local], generator=self.generator).to(dev)
                 perm[positive] = 2.0
                 index = torch.topk(perm, k=self.num_sample)[1]
                 index = index.sort()[0]
@@ -280,14 +326,14 @@ class _PartialFCBase(torch.nn.Module):
         rotating set of pinned buffers: a pageable host-to-device copy blocks the host until the GPU reaches it, which
         drains the launch queue in the middle of the step."""
         if dev.type != "cuda":
-            return torch.rand(size=[self.num_local]).to(dev)
+            return torch.rand(size=[self.num_local], generator=self.generator).to(dev)
         pins = getattr(self, "_perm_pins", None)
         if pins is None:
             pins = self._perm_pins = [torch.empty(self.num_local, pin_memory=True) for _ in range(4)]
             self._perm_turn = 0
         buf = pins[self._perm_turn % len(pins)]
         self._perm_turn += 1
-        torch.rand(size=[self.num_local], out=buf)
+        torch.rand(size=[self.num_local], generator=self.generator, out=buf)
         return buf.to(dev, non_blocking=True)
 
     @torch.no_grad()
@@ -304,9 +350,7 @@ class _PartialFCBase(torch.nn.Module):
         for ~1.5 ms per step.  At the start of a step the host is ahead of the GPU, so the same work is free."""
         lab = local_labels.view(-1).long()
         if self.world_size > 1 or _FORCE_COLLECTIVES:
-            glabels = [torch.zeros_like(lab) for _ in range(self.world_size)]
-            distributed.all_gather(glabels, lab)
-            labels = torch.cat(glabels)
+            labels = _all_gather_flat(lab.new_empty(self.world_size * lab.numel()), lab.contiguous())     # :183 (C2)
         else:
             labels = lab.clone()
         n_pos, check = None, None
@@ -331,7 +375,7 @@ class _PartialFCBase(torch.nn.Module):
                 pin.copy_(count.to(torch.int64).view(1), non_blocking=True)
                 ev = torch.cuda.Event()
                 ev.record()
-                check = [ev, pin, torch.get_rng_state(), None, None]
+                check = [ev, pin, self._rng_state(), None, None]
                 n_pos = 0                                  # optimistic: the sync-free branch of sample()
             else:
                 n_pos = int(count.item())
@@ -348,6 +392,15 @@ class _PartialFCBase(torch.nn.Module):
             ready = rel.view(-1).to(torch.int32).contiguous()
         self._prep = (local_labels.data_ptr(), labels, n_pos, ready, check)
 
+    def _rng_state(self):
+        return self.generator.get_state() if self.generator is not None else torch.get_rng_state()
+
+    def _set_rng_state(self, state):
+        if self.generator is not None:
+            self.generator.set_state(state)
+        else:
+            torch.set_rng_state(state)
+
     @torch.no_grad()
     def update(self):
         """sampled rows -> full table (reference :133-143)"""
@@ -362,48 +415,40 @@ class _PartialFCBase(torch.nn.Module):
 
     def forward(self, local_embeddings, local_labels, optimizer):
         local_labels.squeeze_()
+        prep, self._prep = getattr(self, "_prep", None), None
+        if prep is not None and prep[0] != local_labels.data_ptr():
+            prep = None                                    # a prepare() left over from another step / other labels: ignore it
         local_labels = local_labels.long()
-        prep = getattr(self, "_prep", None)
-        ready = prep[3] if prep is not None and len(prep) > 3 else None
+        ready = prep[3] if prep is not None else None
         if ready is None:
             self.update()
         elif prep[4] is not None:                          # verify prepare()'s optimistic sampling (never blocks in practice)
             ev, pin, rng_state, rel, index_positive = prep[4]
             ev.synchronize()
             if int(pin[0]) > self.num_sample:              # more distinct positives than sampled rows: the reference's other branch
-                torch.set_rng_state(rng_state)
+                self._set_rng_state(rng_state)             # (it draws nothing; the optimistic draw is handed back)
                 self.step -= 1
                 with torch.no_grad():
                     self.sample(rel, index_positive, optimizer, None)
                 ready = rel.view(-1).to(torch.int32).contiguous()
-                prep = prep[:3] + (ready, None)
         batch_size = local_embeddings.size(0)
         if self.last_batch_size == 0:
             self.last_batch_size = batch_size
         assert self.last_batch_size == batch_size, (
             "last batch size do not equal current batch size: {} vs {}".format(self.last_batch_size, batch_size))
-        dev = local_embeddings.device
-        prep, self._prep = getattr(self, "_prep", None), None
+        collectives = self.world_size > 1 or _FORCE_COLLECTIVES
+        n_global = batch_size * self.world_size
+        s, m = float(self.margin_softmax.scale), float(self.margin_softmax.margin)
+        if ready is not None and ready.numel() == n_global:      # everything label-side was done by prepare()
+            return _MarginSoftmaxFn.apply(local_embeddings, self.weight_activated, ready, self.kernels, s, m,
+                                          self.world_size, collectives)
         n_pos = None
-        if self.world_size > 1 or _FORCE_COLLECTIVES:
-            gathered = [torch.zeros((batch_size, self.embedding_size), device=dev) for _ in range(self.world_size)]
-            embeddings = torch.cat(AllGather(local_embeddings, *gathered))
-            if prep is not None and prep[1].numel() == batch_size * self.world_size:
-                labels, n_pos = prep[1], prep[2]                      # gathered at the start of the step by prepare()
-            else:
-                glabels = [torch.zeros(batch_size, dtype=torch.long, device=dev) for _ in range(self.world_size)]
-                distributed.all_gather(glabels, local_labels)
-                labels = torch.cat(glabels)
+        if prep is not None and prep[1].numel() == n_global:
+            labels, n_pos = prep[1], prep[2]                      # gathered at the start of the step by prepare()
+        elif collectives:
+            labels = _all_gather_flat(local_labels.new_empty(n_global), local_labels.contiguous())      # :183 (C2)
         else:
-            embeddings = local_embeddings
-            if prep is not None and prep[1].numel() == batch_size:
-                labels, n_pos = prep[1], prep[2]
-            else:
-                labels = local_labels.clone()
-        if ready is not None and ready.numel() == embeddings.shape[0]:      # everything label-side was done by prepare()
-            return _MarginSoftmaxFn.apply(embeddings, self.weight_activated, ready, self.kernels,
-                                          float(self.margin_softmax.scale), float(self.margin_softmax.margin),
-                                          2 if (_FORCE_COLLECTIVES and self.world_size == 1) else self.world_size)
+            labels = local_labels.clone()
         labels = labels.view(-1, 1)
         index_positive = (self.class_start <= labels) & (labels < self.class_start + self.num_local)
         # shard-relative label, -1 when another rank owns the class (reference :188-193); written with where()
@@ -411,9 +456,8 @@ class _PartialFCBase(torch.nn.Module):
         labels = torch.where(index_positive, labels - self.class_start, torch.full_like(labels, -1))
         if self.sample_rate < 1:
             self.sample(labels, index_positive, optimizer, n_pos)
-        return _MarginSoftmaxFn.apply(embeddings, self.weight_activated, labels.view(-1).to(torch.int32).contiguous(),
-                                      self.kernels, float(self.margin_softmax.scale), float(self.margin_softmax.margin),
-                                      2 if (_FORCE_COLLECTIVES and self.world_size == 1) else self.world_size)
+        return _MarginSoftmaxFn.apply(local_embeddings, self.weight_activated, labels.view(-1).to(torch.int32).contiguous(),
+                                      self.kernels, s, m, self.world_size, collectives)
 
     def state_dict(self, destination=None, prefix="", keep_vars=False):
         if destination is None:

@@ -180,6 +180,13 @@ int frhip_head_fwd(int dtype, const void* ehat, const void* what, const int* lab
 int frhip_head_rescale(float* rowsum, const float* local_max, const float* global_max, int n, frhip_stream_t stream);
 int frhip_head_target_prob(const float* ztarget, const int* labels, const float* rowmax, const float* rowsum,
                            float* q, int n, frhip_stream_t stream);
+/* the three per-row all-reduces of the distributed CE (nets/PartialFC.py:448 MAX, :453 SUM, :459 SUM) as ONE all-gather:
+ * every rank packs {local max, local sum-exp, target logit | -inf} per row ([n][3] fp32), the blocks of all ranks are
+ * all-gathered ([world_size][n][3]) and merged in rank order -> global max, global sum-exp, target probability q */
+int frhip_head_pack_stats(const float* ztarget, const int* labels, const float* rowmax, const float* rowsum,
+                          float* packed, int n, frhip_stream_t stream);
+int frhip_head_merge_stats(const float* gathered, int world_size, int n, float* rowmax, float* rowsum, float* q,
+                           frhip_stream_t stream);
 int frhip_head_loss(const float* q, int n, float* loss, frhip_stream_t stream);
 /* dT[n][ldt] = d loss / d cos (after clamp/margin/scale chain rule); gscale = 1 / N_global, times the device
  * scalar *upstream when it is not NULL (the reference syncs the host here: loss_gradient.item(), nets/PartialFC.py:484) */

@@ -35,14 +35,25 @@ class OracleHeadKernels:
     def loss(self, q):
         return -(q.clamp_min(1e-30).log().mean()).reshape(1)
 
-    def backward(self, ehat, enorm, what, wnorm, labels_i32, s, m, rmax, rsum, n_global, upstream):
+    def pack_stats(self, zt, labels_i32, rmax, rsum):
+        return torch.stack([rmax, rsum, torch.where(labels_i32 >= 0, zt, torch.full_like(zt, float("-inf")))], dim=1)
+
+    def merge_stats(self, gathered):
+        gmax = gathered[:, :, 0].max(dim=0).values
+        gsum = (gathered[:, :, 1] * torch.exp(gathered[:, :, 0] - gmax)).sum(dim=0)
+        q = torch.exp(gathered[:, :, 2] - gmax).sum(dim=0) / gsum
+        return gmax, gsum, q
+
+    def backward(self, ehat, enorm, what, wnorm, labels_i32, s, m, rmax, rsum, n_global, upstream, e_scale=1.0, on_de=None):
         raw, z, slope = self._logits(ehat, what, labels_i32, s, m)
         dz = torch.exp(z - rmax[:, None]) / rsum[:, None]
         rows = torch.nonzero(labels_i32 >= 0).flatten()
         dz[rows, labels_i32[rows].long()] -= 1.0
         dz = dz / n_global * upstream
         dcos = dz * s * slope * ((raw >= -1.0) & (raw <= 1.0))
-        d_e = head_ref.l2_normalize_bwd(dcos @ what, ehat, enorm[:, None])
+        d_e = head_ref.l2_normalize_bwd(dcos @ what, ehat, enorm[:, None]) * e_scale
+        if on_de is not None:
+            on_de(d_e)
         d_w = head_ref.l2_normalize_bwd(dcos.t() @ ehat, what, wnorm[:, None])
         return d_e, d_w
 

@@ -99,6 +99,40 @@ def test_sgd_honours_swapped_parameter_and_momentum_buffer():
     assert torch.allclose(outs[0][0], outs[1][0]) and torch.allclose(outs[0][1], outs[1][1])
 
 
+@pytest.mark.gpu
+def test_sgd_swapped_parameter_changes_size_at_the_same_address():
+    """PartialFC's `index = positive` branch (/root/reference/nets/PartialFC.py:114) changes the row count of the sampled
+    parameter from step to step while the caching allocator re-issues the same base addresses: the cached chunk table must
+    not be reused for a different size (stale n = rows left un-updated, or writes past the end).  The tensors of the two
+    steps are carved from the same storages so that their addresses coincide by construction."""
+    from frhip.optim import SGD
+    outs = []
+    for cls in (torch.optim.SGD, SGD):
+        dummy = torch.nn.Parameter(torch.ones(4, device="cuda"))
+        opt = cls([{"params": [dummy]}, {"params": [torch.nn.Parameter(torch.ones(1, 4, device="cuda"))]}], lr=0.5, momentum=0.9,
+                  weight_decay=0.1)
+        store_p = torch.zeros(6 * 4 + 8, device="cuda")
+        store_g = torch.zeros(6 * 4 + 8, device="cuda")
+        store_m = torch.zeros(6 * 4 + 8, device="cuda")
+        res = []
+        for rows in (3, 6, 2):
+            store_p.fill_(2.0)
+            store_g.fill_(0.5)
+            store_m.fill_(0.25)
+            sub = torch.nn.Parameter(store_p[:rows * 4].view(rows, 4))
+            mom = store_m[:rows * 4].view(rows, 4)
+            opt.state.pop(opt.param_groups[-1]["params"][0], None)
+            opt.param_groups[-1]["params"][0] = sub
+            opt.state[sub]["momentum_buffer"] = mom
+            sub.grad = store_g[:rows * 4].view(rows, 4)
+            dummy.grad = torch.ones(4, device="cuda")
+            opt.step()
+            res.append((store_p.cpu().clone(), store_m.cpu().clone()))       # whole storages: the tail must stay untouched
+        outs.append(res)
+    for (p0, m0), (p1, m1) in zip(*outs):
+        assert torch.allclose(p0, p1) and torch.allclose(m0, m1)
+
+
 def _run_adamw(opt_cls, device, steps=3, fused_clip=False):
     ps, head = _make(device, 2)
     opt = opt_cls([{"params": ps}, {"params": [head], "weight_decay": 0.0}], lr=1e-2, betas=(0.9, 0.99), eps=1e-8, weight_decay=0.05)
