@@ -88,6 +88,73 @@ class ConvMeter:
         fl = sum(f for _, _, f in self.calls)
         return len(self.calls), ms, fl
 
+    # ---- in-step measurement: every conv launch of the TIMED steps bracketed by two HIP events on the stream it runs on
+    def start_instep(self):
+        self.instep, self._pool, self.collect = [], [], False
+        ops, fwd, dgrad = self.ops, self._fwd, self._dgrad
+
+        def ev():
+            return self._pool.pop() if self._pool else torch.cuda.Event(enable_timing=True)
+
+        def conv_fwd(x, w, stride, pad, want_stats=True):
+            if x.dtype != torch.bfloat16:
+                return fwd(x, w, stride, pad, want_stats)
+            n, h, wd, c = x.shape
+            k, r, s, _ = w.shape
+            ho, wo = ops.conv_out_hw(h, wd, r, s, stride, pad)
+            a, b = ev(), ev()
+            a.record()
+            out = fwd(x, w, stride, pad, want_stats)
+            b.record()
+            self.instep.append((a, b, 2.0 * n * ho * wo * k * r * s * c))
+            return out
+
+        def conv_dgrad(dy, wt, x_shape, r, s, stride, pad, residual=None, out=None, bnred=None, residual_stride=1):
+            if dy.dtype != torch.bfloat16:
+                return dgrad(dy, wt, x_shape, r, s, stride, pad, residual, out, bnred, residual_stride)
+            n, ho, wo, k = dy.shape
+            a, b = ev(), ev()
+            a.record()
+            res = dgrad(dy, wt, x_shape, r, s, stride, pad, residual, out, bnred, residual_stride)
+            b.record()
+            self.instep.append((a, b, 2.0 * n * ho * wo * k * r * s * x_shape[3]))
+            return res
+
+        ops.conv_fwd, ops.conv_dgrad = conv_fwd, conv_dgrad
+
+    def stop_instep(self):
+        """-> (launches, summed kernel ms, algorithmic FLOP) over everything recorded since start_instep()"""
+        self.ops.conv_fwd, self.ops.conv_dgrad = self._fwd, self._dgrad
+        torch.cuda.synchronize()
+        ms = sum(a.elapsed_time(b) for a, b, _ in self.instep)
+        return len(self.instep), ms, sum(f for _, _, f in self.instep)
+
+
+def csrc_digest():
+    """content hash of the kernel sources: ties a committed PMC measurement to the kernels it was taken on"""
+    import hashlib
+    h = hashlib.sha1()
+    d = os.path.join(PKG, "frhip", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.startswith("igemm_"):
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic(args):
+    """HBM bytes per launch of the dominant kernels from the committed rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE in
+    separate runs, tools/pmc_run.sh) -- reported only when that measurement was taken on the kernels of THIS tree."""
+    if args.network != "ResNet50" or args.batch != BATCH:
+        return None, None
+    best = None
+    pdir = os.path.join(ROOT, "profiles")
+    for f in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
+        if f.endswith("_pmc_traffic.json"):
+            rec = json.load(open(os.path.join(pdir, f)))
+            if rec.get("csrc_digest") == csrc_digest():
+                best = (rec.get("hbm_bytes_per_launch"), "profiles/" + f)
+    return best if best is not None else (None, "no committed PMC pass matches the conv kernels of this tree")
+
 
 def host_cores():
     """cores this process may really use: affinity mask capped by the cgroup CPU quota (the GPU box shows 256
@@ -218,30 +285,48 @@ def main():
         model.training_step((img, ids.clone()))
     torch.cuda.synchronize()
     log("warm-up done")
+    instep = rank == 0 and not use_graph and os.environ.get("FRHIP_BENCH_INSTEP", "1") == "1"
+    if instep:
+        meter.start_instep()
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = model.training_step((img, ids.clone()))
     sync()
     dt = time.perf_counter() - t0
+    in_n, in_ms, in_fl = meter.stop_instep() if instep else (0, 0.0, 0.0)
     t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    ones = torch.ones(1, dtype=torch.float32, device="cuda")
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(ones, op=dist.ReduceOp.SUM)      # every rank of the group (RCCL for the default backend) adds one
     dt = float(t.item())
+    n_ranks = int(round(float(ones.item())))             # n_gpus of the JSON line = ranks the collective really reached
+    assert n_ranks == dist.get_world_size() == world, (n_ranks, dist.get_world_size(), world)
     loss = float(out["loss"])
     log("timed region: %.3f s for %d steps" % (dt, args.steps))
 
     if rank == 0:
         n, ms, fl = meter.measure()
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-        if os.path.exists(tpath) and args.network == "ResNet50" and args.batch == BATCH:      # HBM bytes per launch of the same kernels from the committed rocprofv3 --pmc passes
-            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
-        achieved = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        probe = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        # dominant-kernel roofline: measured INSIDE the timed steps (the weight-gradient side stream shares the chip with these
+        # launches there); the back-to-back re-issue of the same launch list after the timed region is kept as `probe`
+        if in_n:
+            launches, achieved = in_n // args.steps, in_fl / (in_ms * 1e-3) / 1e12
+            avg_us, flop_per_launch = in_ms * 1e3 / in_n, in_fl / in_n
+        else:
+            launches, achieved, avg_us, flop_per_launch = n, probe, ms * 1e3 / max(n, 1), fl / max(n, 1)
+        traffic, traffic_src = pmc_traffic(args)
+        flop_img = {"ResNet50": 33.92e9, "ResNet18": 10.3e9, "Swin34": 10.2e9}.get(args.network)
+        value = args.batch * world * args.steps / dt
+        step_frac = None
+        if flop_img is not None:
+            head_flop = 6.0 * 512 * (args.classes * conf.sample_rate if conf.sample_rate < 1 else args.classes)
+            step_frac = round(value / world * (flop_img + head_flop) / 1e12 / BF16_DENSE_PEAK_TFLOPS, 4)
         line = {
             "metric": "train imgs/sec IR-50-layout ResNet50 + ArcFace/PartialFC head, 112x112" if args.network == "ResNet50"
                       else "train imgs/sec %s + ArcFace/PartialFC head, %dx%d" % (args.network, args.img_size, args.img_size),
-            "value": round(args.batch * world * args.steps / dt, 1), "unit": "imgs/sec", "n_gpus": world,
+            "value": round(value, 1), "unit": "imgs/sec", "n_gpus": n_ranks,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "BASELINE cfg %d: %s+%s, %d ids, B=%d/GPU, SGD "
@@ -250,13 +335,18 @@ def main():
                                                                      "ArcFace (PartialFC rate 1.0)" if conf.sample_rate >= 1 else "ArcFace (PartialFC rate %.1f)" % conf.sample_rate,
                                                                      args.classes, args.batch),
                        "global_batch": args.batch * world, "parallelism": "dp%d+class-shard%d" % (world, world),
-                       "launch": "hip-graph" if use_graph else "eager"},
+                       "launch": "hip-graph" if use_graph else "eager",
+                       "collective_backend": dist.get_backend() if world > 1 else "none (1 rank)"},
             "final_loss": round(loss, 4),
             "roofline": {"bound": "mfma", "achieved": round(achieved, 1), "peak": BF16_DENSE_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(achieved / BF16_DENSE_PEAK_TFLOPS, 4), "traffic": traffic,
+                         "traffic_source": traffic_src,
                          "kernel": "frhip::halo_kernel<bf16> + frhip::nt_kernel<bf16> (conv forward + data-gradient implicit GEMM)",
-                         "launches": n, "avg_launch_us": round(ms * 1e3 / max(n, 1), 2),
-                         "flop_per_launch": round(fl / max(n, 1))},
+                         "measured": "HIP events around every launch inside the timed steps" if in_n else "back-to-back re-issue",
+                         "launches": launches, "avg_launch_us": round(avg_us, 2), "flop_per_launch": round(flop_per_launch),
+                         "probe": {"achieved": round(probe, 1), "frac": round(probe / BF16_DENSE_PEAK_TFLOPS, 4),
+                                   "what": "the same launch list re-issued back to back after the timed region (nothing else on the chip)"},
+                         "step_frac": step_frac},
         }
         if world == 1 and not args.no_cpu_baseline and args.network == "ResNet50":
             line["cpu_baseline"] = cpu_baseline(args.classes)

@@ -11,7 +11,7 @@ int halo_stat_rows(int dtype, int m, int c, int k);
 int halo_run(int dtype, const void* a, const void* b, void* out, const void* res, float* stats, const EpiBnRed& br,
              int n, int h, int w, int c, int k, int sign, hipStream_t stream);
 
-enum { EPI_STORE = 0, EPI_ATOMIC = 1 };
+enum { EPI_STORE = 0, EPI_ATOMIC = 1, EPI_SLAB = 2 };    // SLAB: K split y stores its fp32 partial tile to slab y of `out`
 
 template <typename T, int WM, int WN, int MT, int EPI>
 __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void nt_kernel(NtGeom g, const void* __restrict__ a,
@@ -44,10 +44,14 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void nt_kernel(NtGeom 
         const char* mine = ml.template stage_out<float>(smem);
         float* o = reinterpret_cast<float*>(out);
         const int n = n0 + lane;
+        if constexpr (EPI == EPI_SLAB) o += (size_t)blockIdx.y * g.M * g.Nout;
         for (int row = 0; row < WROWS; ++row) {
             const int m = m0 + row;
-            if (m < g.M && n < g.Nout)
-                atomicAdd(o + (size_t)m * g.Nout + n, *reinterpret_cast<const float*>(mine + row * P + lane * 4));
+            if (m < g.M && n < g.Nout) {
+                const float v = *reinterpret_cast<const float*>(mine + row * P + lane * 4);
+                if constexpr (EPI == EPI_SLAB) o[(size_t)m * g.Nout + n] = v;
+                else atomicAdd(o + (size_t)m * g.Nout + n, v);
+            }
         }
     }
 }
@@ -57,7 +61,7 @@ static int nt_launch_cfg(const NtGeom& g, const void* a, const void* b, void* ou
                          float* stats, const EpiBnRed& br, int splits, hipStream_t stream) {
     typedef NtTile<T, WM, WN, MT> Tile;
     const int mtiles = (g.M + Tile::BM - 1) / Tile::BM, ntiles = (g.Nout + Tile::BN - 1) / Tile::BN;
-    const int lds = (EPI == EPI_STORE) ? Tile::template lds_bytes<T>() : Tile::template lds_bytes<float>();
+    const int lds = (EPI == EPI_STORE) ? Tile::template lds_bytes<T>() : Tile::template lds_bytes<float>();     // ATOMIC / SLAB stage fp32
     auto kern = nt_kernel<T, WM, WN, MT, EPI>;
     static bool attr_done = false;
     if (!attr_done) {
@@ -285,6 +289,41 @@ extern "C" int frhip_linear_dgrad_gelu(int dtype, const void* dy, const void* wt
     EpiBnRed br = NO_BNRED;
     br.y = pre; br.gelu_bwd = 1;
     return nt_dispatch(dtype, g, dy, wt, dx, nullptr, stats_partial, br, 1, false, stream);
+}
+
+namespace frhip {
+// out[i] = bias[i % n] + sum over the K splits of slabs[s][i], in split order (deterministic)
+__global__ __launch_bounds__(256) void nt_slab_reduce_kernel(const float* __restrict__ slabs, int splits, size_t elems,
+                                                             const float* __restrict__ bias, int n, float* __restrict__ out) {
+    const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= elems) return;
+    f32x4_t acc = *reinterpret_cast<const f32x4_t*>(slabs + i);
+    for (int s = 1; s < splits; ++s) acc += *reinterpret_cast<const f32x4_t*>(slabs + (size_t)s * elems + i);
+    if (bias) acc += *reinterpret_cast<const f32x4_t*>(bias + (i % (size_t)n));
+    *reinterpret_cast<f32x4_t*>(out + i) = acc;
+}
+}  // namespace frhip
+
+extern "C" int frhip_gemm_nt_splitk(int dtype, const void* a, const void* b, const float* bias, float* out, int m, int n,
+                                    int k, int splits, float* slabs, size_t slab_bytes, hipStream_t stream) {
+    // out[m][n] fp32 = sum_k a[m][k] * b[n][k] + bias[n]: K split `splits` ways, every split stores a private fp32 slab
+    // (plain stores), one pass adds the slabs in split order -> run-to-run identical (no float atomics)
+    NtGeom g;
+    int rc = fill_geom(g, dtype, m, 1, 1, k, 1, 1, n, 1, 1, 1, 0, 0, "frhip_gemm_nt_splitk");
+    if (rc) return rc;
+    if (n % 4) { set_error("frhip_gemm_nt_splitk: n must be a multiple of 4"); return FRHIP_EINVAL; }
+    if (splits < 1) splits = 1;
+    if (splits > g.ksteps) splits = g.ksteps;
+    g.ksteps_per_split = (g.ksteps + splits - 1) / splits;
+    splits = (g.ksteps + g.ksteps_per_split - 1) / g.ksteps_per_split;
+    const size_t elems = (size_t)m * n;
+    if (!slabs || slab_bytes < elems * 4 * (size_t)splits) { set_error("frhip_gemm_nt_splitk: workspace too small (%zu bytes needed)", elems * 4 * (size_t)splits); return FRHIP_EINVAL; }
+    if (dtype == FRHIP_DT_BF16) rc = nt_launch_cfg<bf16_t, 2, 2, 4, EPI_SLAB>(g, a, b, slabs, nullptr, nullptr, NO_BNRED, splits, stream);
+    else if (dtype == FRHIP_DT_F32) rc = nt_launch_cfg<float, 2, 2, 4, EPI_SLAB>(g, a, b, slabs, nullptr, nullptr, NO_BNRED, splits, stream);
+    else { set_error("frhip_gemm_nt_splitk: bad dtype %d", dtype); return FRHIP_EINVAL; }
+    if (rc) return rc;
+    hipLaunchKernelGGL(nt_slab_reduce_kernel, dim3((unsigned)((elems / 4 + 255) / 256)), dim3(256), 0, stream, slabs, splits, elems, bias, n, out);
+    return check_launch("frhip_gemm_nt_splitk/reduce");
 }
 
 extern "C" int frhip_gemm_nt(int dtype, const void* a, const void* b, void* out, int m, int n, int k,

@@ -164,6 +164,31 @@ __global__ void pair_score_kernel(const float* __restrict__ e1, const float* __r
     hist_idx[i] = idx;
     if (idx >= 0 && idx <= 100000) atomicAdd(labels[i] ? hist_genuine + idx : hist_imposter + idx, 1);
 }
+
+// ---- cross-matching scores (/root/reference/utils/eval.py:102-137): every unordered pair (j < i) of one embedding set, in
+// the reference's order l = i (i - 1) / 2 + j; same float64-of-float32-differences arithmetic as pair_score, label 1 where
+// the identities agree.  One thread per pair, 16 x 16 pairs per block.
+__global__ __launch_bounds__(256) void cross_score_kernel(const float* __restrict__ e, const int64_t* __restrict__ labels, int n, int d,
+                                                          double* __restrict__ scores, double* __restrict__ pair_labels,
+                                                          int* __restrict__ hist_idx, int* __restrict__ hist_genuine,
+                                                          int* __restrict__ hist_imposter) {
+    const int i = blockIdx.y * 16 + (threadIdx.x >> 4), j = blockIdx.x * 16 + (threadIdx.x & 15);
+    if (i >= n || j >= i) return;
+    double sum = 0.0;
+    for (int k = 0; k < d; ++k) {
+        const float df = e[(size_t)j * d + k] - e[(size_t)i * d + k];
+        const double dd = (double)df;
+        sum += dd * dd;
+    }
+    const double score = 1.0 - sum / 4.0;
+    const int idx = (int)((1e5 - 1.0) * score);
+    const size_t l = (size_t)i * (i - 1) / 2 + j;
+    const bool genuine = labels[j] == labels[i];
+    scores[l] = score;
+    pair_labels[l] = genuine ? 1.0 : 0.0;
+    hist_idx[l] = idx;
+    if (idx >= 0 && idx <= 100000) atomicAdd(genuine ? hist_genuine + idx : hist_imposter + idx, 1);
+}
 }  // namespace frhip
 
 extern "C" int frhip_pair_score(const float* e1, const float* e2, const int64_t* labels, int n, int d, double* scores,
@@ -172,4 +197,14 @@ extern "C" int frhip_pair_score(const float* e1, const float* e2, const int64_t*
     hipLaunchKernelGGL(frhip::pair_score_kernel, dim3((n + 127) / 128), dim3(128), 0, stream, e1, e2, labels, n, d, scores,
                        hist_idx, hist_genuine, hist_imposter);
     return frhip::check_launch("frhip_pair_score");
+}
+
+extern "C" int frhip_cross_score(const float* e, const int64_t* labels, int n, int d, double* scores, double* pair_labels,
+                                 int* hist_idx, int* hist_genuine, int* hist_imposter, hipStream_t stream) {
+    if (n <= 1) return FRHIP_OK;
+    if (n > 65535 * 16) { frhip::set_error("frhip_cross_score: n = %d too large", n); return FRHIP_EINVAL; }
+    const int t = (n + 15) / 16;
+    hipLaunchKernelGGL(frhip::cross_score_kernel, dim3(t, t), dim3(256), 0, stream, e, labels, n, d, scores, pair_labels,
+                       hist_idx, hist_genuine, hist_imposter);
+    return frhip::check_launch("frhip_cross_score");
 }

@@ -118,6 +118,17 @@ def gemm_nt(a, b, out=None, splits=1, atomic_f32=False):
     return out
 
 
+def gemm_nt_splitk(a, b, bias=None, splits=16):
+    """fp32 out[m][n] = a [m,k] @ b [n,k]^T + bias, K split with per-split slabs added in a fixed order (deterministic)"""
+    m, k = a.shape
+    n = b.shape[0]
+    out = torch.empty((m, n), dtype=torch.float32, device=a.device)
+    ws = workspace(a.device)
+    check(lib().frhip_gemm_nt_splitk(dt_of(a), _p(a), _p(b), _p(bias), _p(out), m, n, k, splits, _p(ws), ws.numel() * 4, _s()),
+          "frhip_gemm_nt_splitk")
+    return out
+
+
 def linear_fwd(a, w, bias=None, want_act=False, want_stats=False):
     """nn.Linear with its epilogue: out = a [M,K] @ w [N,K]^T + bias (fp32 [N]); act = gelu(out) when want_act;
     part = BatchNorm partial sums of out when want_stats.  Returns (out, act, part)."""
@@ -599,3 +610,18 @@ def pair_score(e1, e2, labels_i64):
     check(lib().frhip_pair_score(_p(e1), _p(e2), _p(labels_i64), n, d, _p(scores), _p(idx), _p(hg), _p(hi), _s()),
           "frhip_pair_score")
     return scores, idx, hg, hi
+
+
+def cross_score(e, labels_i64):
+    """all pairs j < i of e [n,d] in the reference's order -> (scores f64 [P], pair labels f64 [P], hist idx i32 [P], hg, hi)"""
+    n, d = e.shape
+    dev = e.device
+    pairs = n * (n - 1) // 2
+    scores = torch.empty((pairs,), dtype=torch.float64, device=dev)
+    plab = torch.empty((pairs,), dtype=torch.float64, device=dev)
+    idx = torch.empty((pairs,), dtype=torch.int32, device=dev)
+    hg = torch.zeros((100001,), dtype=torch.int32, device=dev)
+    hi = torch.zeros((100001,), dtype=torch.int32, device=dev)
+    check(lib().frhip_cross_score(_p(e), _p(labels_i64), n, d, _p(scores), _p(plab), _p(idx), _p(hg), _p(hi), _s()),
+          "frhip_cross_score")
+    return scores, plab, idx, hg, hi

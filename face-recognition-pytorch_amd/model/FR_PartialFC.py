@@ -2,8 +2,8 @@
 
 Kept from /root/reference/model/FR_PartialFC.py: `Model(conf, logger, stage)` with `.encoder`, `.loss`, `.opt`,
 `.sch`, `.forward(x)` (:154-156), `.training_step(batch) -> {'loss': np.ndarray}` (:162-193),
-`.configure_optimizers()` (:434-474, ONE optimizer over param groups [encoder, head], head group last) and
-`.training_epoch_end`.  The step composition is the reference's:
+`.configure_optimizers()` (:434-474, ONE optimizer over param groups [encoder, head], head group last),
+`.training_epoch_end`, `.validation_step/.test_step(+_epoch_end)` (:196-373) and `.cross_test_step/_epoch_end` (:379-427).  The step composition is the reference's:
     opt.zero_grad -> encoder.train() -> feat = normalize(encoder(img)) -> loss = head(feat, id, opt)
     -> loss.backward() -> clip_grad_norm_(encoder, 5) -> opt.step()
 but encoder, normalize and head are the libfrhip kernels (nets.resnet / nets.PartialFC of this package).
@@ -177,6 +177,33 @@ class Model(nn.Module):
 
     validation_epoch_end = _eval_epoch_end
     test_epoch_end = _eval_epoch_end
+
+    # ---- cross-matching test (reference :379-427): one embedding per image, every pair scored
+    def cross_test_step(self, batch, dataset_idx):
+        import time
+        dataset_name = self.conf.cross_test_dataset[dataset_idx]
+        img, label = batch
+        img, label = img.to(self.conf.local_rank), label.to(self.conf.local_rank)
+        start = time.time()
+        self.encoder.eval()
+        with torch.no_grad():
+            embedding = normalize(self.forward(img))
+        torch.cuda.synchronize()
+        infer_time = time.time() - start
+        return {f"{dataset_name}_embedding": embedding.cpu(), f"{dataset_name}_infer_time": infer_time,
+                f"{dataset_name}_label_list": label.cpu(), "dataset_name": dataset_name}
+
+    def cross_test_epoch_end(self, outputs):
+        ev = importlib.import_module("utils.eval")
+        name = outputs[0]["dataset_name"]
+        labels = np.concatenate([np.asarray(o[f"{name}_label_list"]).reshape(-1) for o in outputs])
+        embeds = np.concatenate([np.asarray(o[f"{name}_embedding"]) for o in outputs])
+        hg, hi, scores, pair_labels = ev.cross_score(embeds, labels)
+        roc, eer_th = ev.performance_roc(hg, hi, min_level=getattr(self.conf, "min_level", 3),
+                                         max_level=getattr(self.conf, "max_level", 9))
+        acc = ev.performance_acc(scores, pair_labels, eer_th)
+        return {"dataset_name": name, "acc": acc, "roc": roc, "eer_th": eer_th,
+                "infer_time": float(np.mean([o[f"{name}_infer_time"] for o in outputs]))}
 
     def training_epoch_end(self, outputs, t=None):
         self.sch.step() if self.sch is not None else None

@@ -431,8 +431,7 @@ def tail_forward(net, cur, training, sv, dropout_mask=None, relu=False):
         z = z * dropout_mask
     flat = z.view(bo, ho * wo * co)
     wfc = ops.fc_permute(net.fc.weight.data, co, ho * wo, dt)
-    f = ops.gemm_nt(flat, wfc, splits=16, atomic_f32=True)
-    ops.add_bias(f, net.fc.bias.data)
+    f = ops.gemm_nt_splitk(flat, wfc, net.fc.bias.data, splits=16)       # slabs added in split order: run-to-run identical
     part = ops.colstats(f) if training else None
     st3 = bn_forward_state(net.bn3, part, bo, training)
     emb = ops.bn_apply(f, st3)

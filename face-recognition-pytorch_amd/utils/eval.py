@@ -2,7 +2,8 @@
 
 Same functions / return shapes as /root/reference/utils/eval.py: `pair_score(embedding_1, embedding_2, labels)` ->
 (hist_genuine[100001], hist_imposter[100001], score_list), `performance_roc(hist_genuine, hist_imposter, min_level,
-max_level)` -> (roc report string, eer_threshold), `performance_acc(score_list, label_list, th)` -> accuracy in %.
+max_level)` -> (roc report string, eer_threshold), `performance_acc(score_list, label_list, th)` -> accuracy in %,
+`cross_score(embeddings, labels)` -> (hist_genuine, hist_imposter, score_list, label_list) over all pairs j < i (:102-137).
 pair_score runs on the MI355X (frhip_pair_score: float64 accumulation of float32 differences in the reference's
 order, so `int(99999*score)` is bit-exact); the ROC scan and accuracy are host logic on 100 001-bin histograms
 (the reference runs them on the host too) restated with numpy cumulative sums instead of Python loops.
@@ -21,6 +22,24 @@ def pair_score(embedding_1, embedding_2, labels, metric="euclidean", min_level=3
     lab = torch.as_tensor(np.asarray(labels)).long().cuda().contiguous() if not torch.is_tensor(labels) else labels.long().cuda().contiguous()
     scores, _, hg, hi = ops.pair_score(e1, e2, lab)
     return hg.cpu().numpy().astype(np.float64), hi.cpu().numpy().astype(np.float64), scores.cpu().numpy()
+
+
+def _dev(x, dtype):
+    t = x if torch.is_tensor(x) else torch.as_tensor(np.asarray(x))
+    return t.to(dtype).cuda().contiguous()
+
+
+def cross_score(embeddings, labels, metric="euclidean"):
+    """Cross-matching scores of ONE embedding set (reference utils/eval.py:102-137): every pair j < i in the reference's
+    order l = i(i-1)/2 + j -> (hist_genuine[100001], hist_imposter[100001], score_list[P], label_list[P]), label 1 where the
+    two identities agree.  frhip_cross_score: the reference's float64-of-float32-differences arithmetic, so the histogram
+    bins are bit-exact."""
+    assert metric in ["euclidean", "cosine"], "Invalid metric !!!"
+    from frhip import ops
+    if not torch.cuda.is_available():
+        raise RuntimeError("utils.eval.cross_score (frhip) needs the MI355X; there is no CPU path")
+    scores, plab, _, hg, hi = ops.cross_score(_dev(embeddings, torch.float32), _dev(labels, torch.int64).view(-1))
+    return hg.cpu().numpy().astype(np.float64), hi.cpu().numpy().astype(np.float64), scores.cpu().numpy(), plab.cpu().numpy()
 
 
 def performance_roc(hist_genuine, hist_imposter, min_level=3, max_level=9):

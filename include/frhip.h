@@ -103,6 +103,10 @@ int frhip_linear_dgrad_gelu(int dtype, const void* dy, const void* wt, const voi
  * atomic_f32 = 1: out is fp32, caller-zeroed, K is split `splits` ways and added atomically.  nn.Linear: nets/resnet.py:244 */
 int frhip_gemm_nt(int dtype, const void* a, const void* b, void* out, int m, int n, int k, int splits,
                   int atomic_f32, frhip_stream_t stream);
+/* the same product with a deterministic K split (the fc of nets/resnet.py:244 has M = N = 512, K = 25 088): every split
+ * stores a private fp32 slab into the caller's workspace, one pass adds them in split order and adds bias[n] (or NULL) */
+int frhip_gemm_nt_splitk(int dtype, const void* a, const void* b, const float* bias, float* out, int m, int n, int k,
+                         int splits, float* slabs, size_t slab_bytes, frhip_stream_t stream);
 /* out[kc][c] (fp32, caller-zeroed) += sum_m p[m][0..kc) * q[m][0..c);  p has row pitch ldp elements. */
 int frhip_gemm_tn(int dtype, const void* p, const void* q, float* out, int m, int kc, int ldp, int c,
                   int splits, float* workspace, size_t workspace_bytes, frhip_stream_t stream);
@@ -235,6 +239,10 @@ int frhip_gelu_bwd(int dtype, const void* da, const void* h, void* dh, size_t n,
  * hist_genuine / hist_imposter int32[100001] (caller-zeroed) ---- */
 int frhip_pair_score(const float* e1, const float* e2, const int64_t* labels, int n, int d, double* scores,
                      int* hist_idx, int* hist_genuine, int* hist_imposter, frhip_stream_t stream);
+/* utils/eval.py:102-137 cross_score: all pairs j < i of ONE embedding set e [n][d] in the reference's order
+ * l = i (i - 1) / 2 + j; scores / pair_labels float64 [n (n - 1) / 2] (pair label 1.0 = same identity), hist_idx int32 */
+int frhip_cross_score(const float* e, const int64_t* labels, int n, int d, double* scores, double* pair_labels,
+                      int* hist_idx, int* hist_genuine, int* hist_imposter, frhip_stream_t stream);
 
 /* ---- recompute-style stem (stride 1): conv3x3(3->64) -> BN -> ReLU -> MaxPool(3,2,1) of nets/resnet.py:232-235 without ever
  * writing the conv output map or an im2col matrix; every pass recomputes the conv from x [b,3,h,w] fp32 NCHW and

@@ -3,7 +3,7 @@
 Follows /root/reference/utils/eval.py: pair_score (:68-99: score = 1 - |a-b|^2/4 accumulated in float64 from float32
 differences, hist_idx = int(99999 * score)), performance_roc (:7-51: thresholds 100000 -> 1, FAR / FRR from the
 cumulative histograms, first minimum of |FAR - FRR| = EER threshold, best FRR with FAR <= 1e-level per security
-level), performance_acc (:54-66).  Plain numpy, vectorised where the reference loops.
+level), performance_acc (:54-66), cross_score (:102-137: all pairs j < i, l = i(i-1)/2 + j).  Plain numpy, vectorised where the reference loops.
 """
 import numpy as np
 
@@ -52,3 +52,13 @@ def accuracy(scores, labels, th):
     fr = np.sum((scores <= th / 1e5) & (labels == 1))
     fa = np.sum((scores > th / 1e5) & (labels == 0))
     return (1 - (fa + fr) / len(scores)) * 100
+
+
+def cross_scores(emb, labels):
+    """-> (scores [P], pair labels [P]) over all pairs j < i in the reference's order l = i (i - 1) / 2 + j"""
+    emb = emb.astype(np.float32)
+    n = emb.shape[0]
+    ii, jj = np.tril_indices(n, -1)                         # row-major over (i, j < i): exactly l = i(i-1)/2 + j
+    d = (emb[jj] - emb[ii]).astype(np.float64)
+    labels = np.asarray(labels).reshape(-1)
+    return 1.0 - np.sum(d * d, axis=1) / 4.0, (labels[jj] == labels[ii]).astype(np.float64)

@@ -400,6 +400,27 @@ def gen_eval():
          eer_th=eer_th, acc=acc, roc=np.array(roc))
 
 
+def gen_cross_eval():
+    _ref()
+    nb = types.ModuleType("numba")
+    nb.njit = lambda *a, **k: (lambda f: f)
+    nb.prange = range
+    sys.modules.setdefault("numba", nb)
+    import utils.eval as E
+    ids, per, d = 20, 4, 128
+    centres = recipe.normal(8201, (ids, d))
+    emb = torch.nn.functional.normalize(centres.repeat_interleave(per, 0) * 0.35 + recipe.normal(8202, (ids * per, d)))
+    labels = np.repeat(np.arange(ids), per).astype(np.int64)
+    perm = recipe.rng(8203).permutation(ids * per)
+    emb, labels = emb[torch.from_numpy(perm)], labels[perm]
+    hg, hi, scores, plab = E.cross_score(emb.numpy(), labels)
+    roc, eer_th = E.performance_roc(hg, hi, min_level=1, max_level=3)
+    acc = E.performance_acc(scores, plab, eer_th)
+    idx = np.array([int((1e5 - 1.) * s) for s in scores], dtype=np.int64)
+    save("cross_eval", ids=ids, per=per, d=d, labels=labels, scores=scores, pair_labels=plab, hist_idx=idx, hist_genuine=hg,
+         hist_imposter=hi, eer_th=eer_th, acc=acc, roc=np.array(roc))
+
+
 # ----------------------------------------------------------------------------- lr schedule
 def gen_scheduler():
     _ref()
@@ -425,6 +446,7 @@ GENS = {
     "swin": gen_swin,
     "alternet": gen_alternet,
     "eval": gen_eval,
+    "cross_eval": gen_cross_eval,
     "arcface": gen_arcface_edge,
     "distce": gen_distce,
     "head_ws1_rate10": lambda: gen_head(1, 1.0),
