@@ -120,11 +120,30 @@ class ConvMeter:
             self.instep.append((a, b, 2.0 * n * ho * wo * k * r * s * x_shape[3]))
             return res
 
-        ops.conv_fwd, ops.conv_dgrad = conv_fwd, conv_dgrad
+        f8 = ops.conv_fwd_fp8
+        self._f8, self.instep8 = f8, []
+
+        def conv_fwd_fp8(x8, w8, wscale, stride, pad, want_stats=True):
+            n, h, wd, c = x8.shape
+            k, r, s, _ = w8.shape
+            ho, wo = ops.conv_out_hw(h, wd, r, s, stride, pad)
+            a, b = ev(), ev()
+            a.record()
+            out = f8(x8, w8, wscale, stride, pad, want_stats)
+            b.record()
+            self.instep8.append((a, b, 2.0 * n * ho * wo * k * r * s * c))
+            return out
+
+        ops.conv_fwd, ops.conv_dgrad, ops.conv_fwd_fp8 = conv_fwd, conv_dgrad, conv_fwd_fp8
+
+    def stop_instep8(self):
+        """fp8 forward convolutions recorded since start_instep(): (launches, summed kernel ms, algorithmic FLOP)"""
+        ms = sum(a.elapsed_time(b) for a, b, _ in self.instep8)
+        return len(self.instep8), ms, sum(f for _, _, f in self.instep8)
 
     def stop_instep(self):
         """-> (launches, summed kernel ms, algorithmic FLOP) over everything recorded since start_instep()"""
-        self.ops.conv_fwd, self.ops.conv_dgrad = self._fwd, self._dgrad
+        self.ops.conv_fwd, self.ops.conv_dgrad, self.ops.conv_fwd_fp8 = self._fwd, self._dgrad, self._f8
         torch.cuda.synchronize()
         ms = sum(a.elapsed_time(b) for a, b, _ in self.instep)
         return len(self.instep), ms, sum(f for _, _, f in self.instep)
@@ -217,6 +236,8 @@ def main():
                     help="replay the step as one HIP graph (default: eager launches; eager is GPU-bound at B=512 and "
                          "lets the side-stream weight-gradient GEMMs overlap the main stream)")
     ap.add_argument("--no-graph", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--fp8", action="store_true",
+                    help="BASELINE cfg 5: forward convolutions / linears with >= 128 input channels on the fp8 MFMA path")
     ap.add_argument("--dist-path", action="store_true",
                     help="rehearse the N>1 code path (RCCL group, DDP wrap, PartialFC rate 0.1) in a 1-rank group")
     args = ap.parse_args()
@@ -256,6 +277,7 @@ def main():
 
     log("library built/loaded")
     conf = make_conf(args, local, world)
+    conf.frhip_fp8 = bool(args.fp8)
     if args.dist_path:
         conf.sample_rate, conf.force_ddp = 0.1, True
     torch.manual_seed(1234 + rank)
@@ -295,6 +317,7 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     in_n, in_ms, in_fl = meter.stop_instep() if instep else (0, 0.0, 0.0)
+    f8_n, f8_ms, f8_fl = meter.stop_instep8() if instep else (0, 0.0, 0.0)
     t = torch.tensor([dt], dtype=torch.float64, device="cuda")
     ones = torch.ones(1, dtype=torch.float32, device="cuda")
     if world > 1:
@@ -328,7 +351,7 @@ def main():
                       else "train imgs/sec %s + ArcFace/PartialFC head, %dx%d" % (args.network, args.img_size, args.img_size),
             "value": round(value, 1), "unit": "imgs/sec", "n_gpus": n_ranks,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "fp8-weights" if args.fp8 else "bf16", "data": "synthetic",
             "config": {"workload": "BASELINE cfg %d: %s+%s, %d ids, B=%d/GPU, SGD "
                                    "mom 0.9 wd 5e-4, s=30 m=0.35" % ((2 if world == 1 else 3) if args.network == "ResNet50" else (5 if args.network.startswith("AlterNet") else 4),
                                                                      "ResNet50([3,4,14,4] BasicBlock)" if args.network == "ResNet50" else args.network,
@@ -348,6 +371,12 @@ def main():
                                    "what": "the same launch list re-issued back to back after the timed region (nothing else on the chip)"},
                          "step_frac": step_frac},
         }
+        if f8_n:
+            f8 = f8_fl / (f8_ms * 1e-3) / 1e12
+            line["roofline_fp8"] = {"bound": "mfma", "achieved": round(f8, 1), "peak": 2 * BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                    "frac": round(f8 / (2 * BF16_DENSE_PEAK_TFLOPS), 4), "traffic": None,
+                                    "kernel": "frhip::nt8_kernel (fp8 e4m3 x e4m3 forward convolutions, v_mfma_scale_f32_16x16x128_f8f6f4)",
+                                    "launches": f8_n // args.steps, "avg_launch_us": round(f8_ms * 1e3 / f8_n, 2)}
         if world == 1 and not args.no_cpu_baseline and args.network == "ResNet50":
             line["cpu_baseline"] = cpu_baseline(args.classes)
         print(json.dumps(line), flush=True)

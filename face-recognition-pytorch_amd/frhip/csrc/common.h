@@ -83,6 +83,37 @@ template <> struct Mma<float> {
     }
 };
 
+// fp8 (OCP e4m3fn) operands on the block-scaled MFMA: one v_mfma_scale_f32_16x16x128_f8f6f4 consumes a whole 128-byte LDS
+// row per operand row (32 k-values per lane = two 16-byte reads) at twice the bf16 rate.  Block scales are the unit scale
+// (E8M0 127): real scales are per tensor / per output channel and applied to the fp32 accumulators in the epilogue.
+// Which k-values a lane holds does not matter as long as both operands are read by the same rule (the MFMA sums over k).
+struct fp8_t { uint8_t bits; };
+typedef __attribute__((ext_vector_type(8))) int i32x8_t;
+template <> struct Mma<fp8_t> {
+    typedef i32x8_t Frag;
+    __device__ static __forceinline__ void run(const Frag& a, const Frag& b, f32x4_t& c) {
+        c = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c, 0 /* A: e4m3 */, 0 /* B: e4m3 */, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+    }
+};
+
+// MFMA fragments of one 128-byte LDS row (16-byte chunks XOR-swizzled by sw = row & 7): bf16 / f32 rows hold two K sub-steps
+// of one 16-byte fragment per lane group fg (chunk fg + 4 s), an fp8 row is ONE sub-step of two chunks (fg and fg + 4).
+template <typename T> struct RowFrag {
+    static constexpr int KSUB = 2;
+    __device__ static __forceinline__ typename Mma<T>::Frag load(const char* row, int fg, int sw, int s) {
+        return *reinterpret_cast<const typename Mma<T>::Frag*>(row + (((fg + 4 * s) ^ sw) << 4));
+    }
+};
+template <> struct RowFrag<fp8_t> {
+    static constexpr int KSUB = 1;
+    __device__ static __forceinline__ i32x8_t load(const char* row, int fg, int sw, int) {
+        typedef __attribute__((ext_vector_type(4))) int i32x4_t;
+        const i32x4_t lo = *reinterpret_cast<const i32x4_t*>(row + ((fg ^ sw) << 4));
+        const i32x4_t hi = *reinterpret_cast<const i32x4_t*>(row + (((fg + 4) ^ sw) << 4));
+        return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    }
+};
+
 // GELU (exact erf form, nn.GELU default) pieces for a pre-activation h: cdf = Phi(h), pdf = phi(h).
 // erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, below fp32 round-off of the products it feeds) sharing ONE
 // exponential with the density: erf(h/sqrt2) = 1 - poly(t) * exp(-h^2/2), t = 1/(1 + p*|h|/sqrt2).  About 18 VALU

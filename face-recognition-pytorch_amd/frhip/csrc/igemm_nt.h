@@ -200,13 +200,12 @@ struct NtMainloop {
         auto compute = [&](int buf) {
             const char* base = smem + buf * Tile::STAGE_BYTES;
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const int ch = ((fg + 4 * s) ^ sw) * 16;
+            for (int s = 0; s < RowFrag<T>::KSUB; ++s) {
                 Frag xf[MT], wf[4];
 #pragma unroll
-                for (int t = 0; t < 4; ++t) wf[t] = *reinterpret_cast<const Frag*>(base + woff + t * 16 * NT_ROWB + ch);
+                for (int t = 0; t < 4; ++t) wf[t] = RowFrag<T>::load(base + woff + t * 16 * NT_ROWB, fg, sw, s);
 #pragma unroll
-                for (int t = 0; t < MT; ++t) xf[t] = *reinterpret_cast<const Frag*>(base + xoff + t * 16 * NT_ROWB + ch);
+                for (int t = 0; t < MT; ++t) xf[t] = RowFrag<T>::load(base + xoff + t * 16 * NT_ROWB, fg, sw, s);
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
 #pragma unroll

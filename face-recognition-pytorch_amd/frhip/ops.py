@@ -567,15 +567,16 @@ def winattn_fwd(qkv, bias, scale, b, h, w, heads, ws=7, shift=0):
     return out
 
 
-def winattn_bwd(qkv, dout, bias, scale, b, h, w, heads, ws=7, shift=0, want_colsum=False):
-    """-> dqkv, dbias, dscale [, colsum fp32 [3c] = column sums of dqkv, or None when this dtype / kernel mode cannot fuse them]"""
+def winattn_bwd(qkv, dout, bias, scale, b, h, w, heads, ws=7, shift=0, want_colsum=False, dbias=None, dscale=None):
+    """-> dqkv, dbias, dscale [, colsum fp32 [3c] = column sums of dqkv, or None when this dtype / kernel mode cannot fuse them].
+    dbias / dscale given: the kernel ADDS into them (caller-zeroed accumulators) instead of fresh zero tensors."""
     c = qkv.shape[1] // 3
     dqkv = torch.empty_like(qkv)
-    dbias = torch.zeros_like(bias)
-    dscale = torch.zeros_like(scale)
+    dbias = torch.zeros_like(bias) if dbias is None else dbias
+    dscale = torch.zeros_like(scale) if dscale is None else dscale
     if want_colsum:
         if qkv.dtype != torch.bfloat16 or not lib().frhip_set_winattn_mfma(-1):
-            return winattn_bwd(qkv, dout, bias, scale, b, h, w, heads, ws, shift) + (None,)
+            return winattn_bwd(qkv, dout, bias, scale, b, h, w, heads, ws, shift, dbias=dbias, dscale=dscale) + (None,)
         colsum = torch.zeros(3 * c, dtype=torch.float32, device=qkv.device)
         check(lib().frhip_winattn_bwd_colsum(dt_of(qkv), _p(qkv), _p(dout), _p(bias), _p(scale), _p(dqkv), _p(dbias), _p(dscale),
                                              _p(colsum), b, h, w, c, heads, ws, shift, _s()), "frhip_winattn_bwd_colsum")
@@ -625,3 +626,63 @@ def cross_score(e, labels_i64):
     check(lib().frhip_cross_score(_p(e), _p(labels_i64), n, d, _p(scores), _p(plab), _p(idx), _p(hg), _p(hi), _s()),
           "frhip_cross_score")
     return scores, plab, idx, hg, hi
+
+
+# ------------------------------------------------------------------------------------------ fp8 weight path (BASELINE cfg 5)
+FP8_ACT_SCALE = 1.0        # static per-tensor scale of the fp8 activation copies: post-BatchNorm activations are O(1), e4m3 reaches 448
+
+
+def quant_fp8_weights(w_f32):
+    """fp32 [K, ...] (physical, contiguous) -> (fp8 bytes of the same shape, fp32 scale [K]): per-output-channel amax / 448"""
+    k = w_f32.shape[0]
+    rowlen = w_f32.numel() // k
+    w8 = torch.empty(w_f32.shape, dtype=torch.uint8, device=w_f32.device)
+    scale = torch.empty((k,), dtype=torch.float32, device=w_f32.device)
+    check(lib().frhip_quant_fp8_weights(_p(w_f32), _p(w8), _p(scale), k, rowlen, _s()), "frhip_quant_fp8_weights")
+    return w8, scale
+
+
+def quant_fp8(x, inv_scale=1.0 / FP8_ACT_SCALE):
+    x8 = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
+    check(lib().frhip_quant_fp8(dt_of(x), _p(x), _p(x8), x.numel(), inv_scale, _s()), "frhip_quant_fp8")
+    return x8
+
+
+def bn_apply_q8(y, st, relu=False, res=None, res_st=None):
+    """bn_apply that also returns the fp8 copy of its output (the operand of the next fp8 GEMM)"""
+    c = y.shape[-1]
+    rows = y.numel() // c
+    out = torch.empty_like(y)
+    out8 = torch.empty(y.shape, dtype=torch.uint8, device=y.device)
+    check(lib().frhip_bn_apply_q8(dt_of(y), _p(y), _p(st.scale), _p(st.shift), _p(res),
+                                  _p(res_st.scale) if res_st is not None else None,
+                                  _p(res_st.shift) if res_st is not None else None,
+                                  int(relu), _p(out), _p(out8), 1.0 / FP8_ACT_SCALE, rows, c, _s()), "frhip_bn_apply_q8")
+    return out, out8
+
+
+def conv_fwd_fp8(x8, w8, wscale, stride, pad, want_stats=True):
+    """x8 [N,H,W,C] fp8, w8 [K,R,S,C] fp8 + wscale [K] -> y bf16 [N,Ho,Wo,K], BatchNorm partials or None"""
+    n, h, wd, c = x8.shape
+    k, r, s, c2 = w8.shape
+    assert c == c2 and x8.dtype == torch.uint8 and w8.dtype == torch.uint8
+    ho, wo = conv_out_hw(h, wd, r, s, stride, pad)
+    y = torch.empty((n, ho, wo, k), dtype=torch.bfloat16, device=x8.device)
+    part = None
+    if want_stats:
+        part = torch.empty((lib().frhip_fp8_stat_rows(n * ho * wo, k), 2, k), dtype=torch.float32, device=x8.device)
+    check(lib().frhip_conv_fwd_fp8(_p(x8), _p(w8), _p(wscale), FP8_ACT_SCALE, _p(y), _p(part), n, h, wd, c, k, r, s, stride, pad, _s()),
+          "frhip_conv_fwd_fp8")
+    return y, part
+
+
+def linear_fwd_fp8(a8, w8, wscale, bias=None, want_stats=False):
+    m, k = a8.shape
+    n = w8.shape[0]
+    out = torch.empty((m, n), dtype=torch.bfloat16, device=a8.device)
+    part = None
+    if want_stats:
+        part = torch.empty((lib().frhip_fp8_stat_rows(m, n), 2, n), dtype=torch.float32, device=a8.device)
+    check(lib().frhip_linear_fwd_fp8(_p(a8), _p(w8), _p(wscale), FP8_ACT_SCALE, _p(bias), _p(out), _p(part), m, n, k, _s()),
+          "frhip_linear_fwd_fp8")
+    return out, part

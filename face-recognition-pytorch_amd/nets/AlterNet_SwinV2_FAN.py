@@ -21,10 +21,10 @@ import torch.nn as nn
 from frhip import ops
 
 from . import SwinV2 as _S
-from ._backbone import (BackwardCtx, BasicBlock, Saved, _BN, _Conv, _Linear, basic_block_backward,  # noqa: F401
+from ._backbone import (BackwardCtx, BasicBlock, Fp8Ctx, Saved, _BN, _Conv, _Linear, basic_block_backward,  # noqa: F401
                         basic_block_forward, bn_forward_state, compute_dtype, encoder_call, prepare_conv_weights,
                         stem_backward,
-                        stem_forward, tail_backward, tail_forward)
+                        stem_forward, tail_backward, tail_forward, use_fp8)
 
 conv1x1 = lambda cin, cout, stride=1: _Conv(cin, cout, 1, stride)  # noqa: E731
 
@@ -51,13 +51,6 @@ class WindowAttention(_S.WindowAttention):
         self.q_bias = nn.Parameter(torch.zeros(dim)) if qkv_bias else None
         self.v_bias = nn.Parameter(torch.zeros(dim)) if qkv_bias else None
         self.proj = _Linear(dim, dim)
-
-    def bias_and_scale(self, params):
-        w0, b0, w2, ls = params
-        n = self.window_size[0] * self.window_size[1]
-        t = torch.nn.functional.linear(torch.relu(torch.nn.functional.linear(self.relative_coords_table, w0, b0)), w2).view(-1, self.num_heads)
-        b = t[self.relative_position_index.view(-1)].view(n, n, self.num_heads).permute(2, 0, 1).contiguous()
-        return 16 * torch.sigmoid(b), torch.clamp(ls, max=_S.LN100).exp().reshape(-1)
 
 
 class SwinTransformerBlock(nn.Module):
@@ -89,18 +82,25 @@ class SwinTransformerBlock(nn.Module):
         self.norm2 = _BN(dim)
 
 
-def attn_block_forward(blk, x, dt, training, save, wprep=None):
+def attn_block_forward(blk, x, dt, training, save, wprep=None, q8=None):
     b, h, w, c = x.shape
     m = b * h * w
     at = blk.attn
     x2 = x.view(m, c)
+    fp8 = q8 is not None and dt == torch.bfloat16 and Fp8Ctx.eligible(c)        # qkv / proj with both operands in fp8
     wqkv, wqkv_t = _S._lin_operands(at.qkv, dt, wprep)
     qb = torch.cat([at.q_bias.data, torch.zeros_like(at.v_bias.data), at.v_bias.data])
-    qkv, _, _ = ops.linear_fwd(x2, wqkv, qb)                                  # bias add in the GEMM epilogue
-    cpb, bias_t, scale_t, bias, scale, cpb_on_side = _S.position_bias(blk)
+    if fp8:
+        qkv, _ = ops.linear_fwd_fp8(q8.take(x).view(m, c), *q8.packs[at.qkv], bias=qb)
+    else:
+        qkv, _, _ = ops.linear_fwd(x2, wqkv, qb)                              # bias add in the GEMM epilogue
+    cpb_batch, _, bias, scale, dbias_buf, dscale_buf = _S.position_bias(blk)
     ao = ops.winattn_fwd(qkv, bias, scale, b, h, w, at.num_heads, blk.window_size, blk.shift_size)
     wproj, wproj_t = _S._lin_operands(at.proj, dt, wprep)
-    po, _, part2 = ops.linear_fwd(ao, wproj, at.proj.bias.data, want_stats=training)   # + norm2's batch statistics
+    if fp8:
+        po, part2 = ops.linear_fwd_fp8(ops.quant_fp8(ao), *q8.packs[at.proj], bias=at.proj.bias.data, want_stats=training)
+    else:
+        po, _, part2 = ops.linear_fwd(ao, wproj, at.proj.bias.data, want_stats=training)   # + norm2's batch statistics
     st2 = bn_forward_state(blk.norm2, part2, m, training)
     keep = None
     if training and blk.drop_path_rate > 0:
@@ -109,14 +109,17 @@ def attn_block_forward(blk, x, dt, training, save, wprep=None):
         keep = (torch.rand(b, device=x.device) < kp).to(x.dtype) / kp
         branch = ops.bn_apply(po, st2).view(b, h * w * c) * keep[:, None]
         out = (x.view(b, -1) + branch).view(b, h, w, c)
+    elif fp8:
+        out, out8 = ops.bn_apply_q8(po, st2, res=x2)
+        out = out.view(b, h, w, c)
+        q8.put(out, out8.view(b, h, w, c))
     else:
         out = ops.bn_apply(po, st2, res=x2).view(b, h, w, c)
     s = None
     if save:
         s = Saved()
-        (s.x2, s.wqkv, s.qkv, s.cpb, s.bias_t, s.scale_t, s.bias, s.scale, s.ao, s.wproj, s.po, s.st2, s.keep, s.shape) = (
-            x2, wqkv, qkv, cpb, bias_t, scale_t, bias, scale, ao, wproj, po, st2, keep, (b, h, w, c))
-        s.cpb_on_side = cpb_on_side
+        (s.x2, s.wqkv, s.qkv, s.cpb_batch, s.dbias, s.dscale, s.bias, s.scale, s.ao, s.wproj, s.po, s.st2, s.keep, s.shape) = (
+            x2, wqkv, qkv, cpb_batch, dbias_buf, dscale_buf, bias, scale, ao, wproj, po, st2, keep, (b, h, w, c))
         s.wqkv_t, s.wproj_t = wqkv_t, wproj_t
     return out, s
 
@@ -132,8 +135,8 @@ def attn_block_backward(blk, s, dout, dt, bc):
     # proj.bias only shifts the input of a training-mode BatchNorm: analytically zero gradient (nets/SwinV2.py), left at zero
     bc.on_side(lambda: ops.gemm_tn(dpo, s.ao, G(at.proj.weight)), dpo, s.ao)
     dao = ops.gemm_nt(dpo, _S._transposed(s.wproj, s.wproj_t))
-    dqkv, dbias, dscale, gsum = ops.winattn_bwd(s.qkv, dao, s.bias, s.scale, b, h, w, at.num_heads, blk.window_size,
-                                                blk.shift_size, want_colsum=True)
+    dqkv, _, _, gsum = ops.winattn_bwd(s.qkv, dao, s.bias, s.scale, b, h, w, at.num_heads, blk.window_size,
+                                       blk.shift_size, want_colsum=True, dbias=s.dbias, dscale=s.dscale)
     if gsum is None:                                 # fp32 validation kernels: column sums by a ones-GEMM
         gsum = torch.zeros(3 * c, dtype=torch.float32, device=dout.device)
         _S._colsum_via_gemm(dqkv, gsum)
@@ -141,7 +144,7 @@ def attn_block_backward(blk, s, dout, dt, bc):
     G(at.v_bias).add_(gsum[2 * c:])
     bc.on_side(lambda: ops.gemm_tn(dqkv, s.x2, G(at.qkv.weight)), dqkv, s.x2)
     dx = _S._dgrad_add(dqkv, s.wqkv, d2, s.wqkv_t)
-    _S.position_bias_backward(blk, s, dbias, dscale, bc)
+    _S.position_bias_backward(blk, s, bc)
     return dx.view(b, h, w, c)
 
 
@@ -150,6 +153,7 @@ class AlterNet(nn.Module):
         super().__init__()
         self.emd_size = conf.emd_size
         self.dtype = compute_dtype(conf)
+        self.fp8 = use_fp8(conf)                   # BASELINE cfg 5: forward GEMMs on the fp8 MFMA path (csrc/igemm_fp8.hip)
         res = (conf.img_size, conf.img_size)
         self.inplanes = 64
         self.conv1 = _Conv(3, 64, 3, 2)
@@ -201,20 +205,25 @@ class AlterNet(nn.Module):
         sv = Saved() if save else None
         layers = list(self._layers())
         lprep = None
+        attn = [m for m in layers if not isinstance(m, BasicBlock)]
+        _S.precompute_position_bias(attn, x.device)         # every block's bias table and logit scale: one launch
         if training and save:
-            attn = [m for m in layers if not isinstance(m, BasicBlock)]
-            _S.precompute_position_bias(attn, x.device)
             lprep = _S.prepare_linear_weights([l for b in attn for l in (b.attn.qkv, b.attn.proj)], dt)
         cur = stem_forward(self, x, training, sv)
         saved = []
         convs = [c for b in layers if isinstance(b, BasicBlock)
                  for c in ((b.conv1, b.conv2) + ((b.downsample[0],) if b.downsample is not None else ()))]
         wprep = prepare_conv_weights(convs, dt) if convs else None
+        q8 = None
+        if self.fp8 and dt == torch.bfloat16:
+            lin = [l for b in layers if not isinstance(b, BasicBlock) for l in (b.attn.qkv, b.attn.proj)]
+            q8 = Fp8Ctx([(c, c.physical()) for c in convs if Fp8Ctx.eligible(c.cin)] +
+                        [(l, l.weight.data) for l in lin if Fp8Ctx.eligible(l.weight.shape[1])])
         for mod in layers:
             if isinstance(mod, BasicBlock):
-                cur, s = basic_block_forward(mod, cur, dt, training, save, wprep)
+                cur, s = basic_block_forward(mod, cur, dt, training, save, wprep, q8)
             else:
-                cur, s = attn_block_forward(mod, cur, dt, training, save, lprep)
+                cur, s = attn_block_forward(mod, cur, dt, training, save, lprep, q8)
             saved.append(s)
         if cur.shape[1] != 6 or cur.shape[2] != 6:
             raise NotImplementedError("AdaptiveAvgPool2d((6,6)) is the identity only for 192x192 inputs")

@@ -76,13 +76,6 @@ class WindowAttention(nn.Module):
     def cpb_params(self):
         return [self.cpb_mlp[0].weight, self.cpb_mlp[0].bias, self.cpb_mlp[2].weight, self.logit_scale]
 
-    def bias_and_scale(self, params):
-        """[heads,49,49] fp32 bias = 16*sigmoid(cpb_mlp(table))[index] and [heads] scale = exp(min(logit_scale, ln 100))"""
-        w0, b0, w2, ls = params
-        t = F.linear(F.relu(F.linear(self.relative_coords_table, w0, b0)), w2).view(-1, self.num_heads)
-        b = t[self.relative_position_index.view(-1)].view(49, 49, self.num_heads).permute(2, 0, 1).contiguous()
-        return 16 * torch.sigmoid(b), torch.clamp(ls, max=LN100).exp().reshape(-1)
-
 
 class SwinTransformerBlock(nn.Module):
     """x = x + BN(attn(x)); x = x + BN(mlp(x))  (reference :183-300, shift_size 0): parameter holder."""
@@ -133,58 +126,111 @@ def _colsum_via_gemm(x2d, out_accum):
     out_accum += tmp[:, 0]
 
 
-def precompute_position_bias(attn_blocks, device):
-    """The 169-entry continuous-position-bias MLP and the logit scale of every attention block depend on parameters only
-    (nets/SwinV2.py:150-158): ~8 tiny ATen launches per block forward and ~12 backward.  In a training step they run on the
-    side stream -- forward for all blocks up front (behind the stem), backward deferred behind the weight gradients -- so
-    they stay off the main stream's critical path.  Stashes (cpb, bias_t, scale_t, bias, scale, ready-event) on the block."""
-    from ._backbone import side_stream, _OVERLAP_WGRAD
-    if not _OVERLAP_WGRAD or os.environ.get("FRHIP_CPB_SIDE", "1") != "1":
-        return
-    main, side = torch.cuda.current_stream(device), side_stream(device)
-    side.wait_stream(main)                        # the optimizer's parameter update of the previous step
-    with torch.cuda.stream(side):
-        for blk in attn_blocks:
+class CpbBatch:
+    """Position-bias tables of a group of attention blocks by the libfrhip kernels (csrc/cpb.hip): ONE launch computes
+    16*sigmoid(cpb_mlp(coords)[index]) and exp(min(logit_scale, ln 100)) of every block, ONE launch (queued at the end of the
+    backward pass) turns all d(bias) / d(scale) into the gradients of cpb_mlp.* and logit_scale.  Stands where torch ran
+    ~8 forward and ~12 backward launches per block (tiny rocBLAS GEMMs + element-wise kernels, nets/SwinV2.py:150-158)."""
+
+    _DT = np.dtype([(k, "<u8") for k in ("coords", "index", "w0", "b0", "w2", "ls", "bias", "scale", "dbias", "dscale",
+                                         "dw0", "db0", "dw2", "dls")] + [(k, "<i4") for k in ("entries", "tokens", "heads", "pad")])
+    _PINS, _TURN = None, 0
+
+    def __init__(self, blocks, device):
+        from frhip._abi import check, lib
+        self.blocks = list(blocks)
+        self.check, self.lib = check, lib
+        sizes = []
+        for blk in self.blocks:
             at = blk.attn
-            with torch.enable_grad():
-                cpb = [p.detach().requires_grad_(True) for p in at.cpb_params()]
-                bias_t, scale_t = at.bias_and_scale(cpb)
-            bias, scale = bias_t.detach().contiguous(), scale_t.detach().contiguous()
-            for t in (bias, scale):
-                t.record_stream(main)
-            ev = torch.cuda.Event()
-            ev.record(side)
-            blk._cpb_ready = (cpb, bias_t, scale_t, bias, scale, ev)
+            n = at.window_size[0] * at.window_size[1]
+            sizes.append((at.num_heads * n * n, at.num_heads))
+        pad4 = lambda v: (v + 3) // 4 * 4                     # every view starts 16-byte aligned
+        total = sum(pad4(a) + pad4(b) for a, b in sizes)
+        self.out = torch.empty(total, dtype=torch.float32, device=device)            # bias / scale of every block
+        self.grad = torch.zeros(total, dtype=torch.float32, device=device)           # d bias / d scale (the attention backward adds into them)
+        self.views, off = [], 0
+        for (nb, nh), blk in zip(sizes, self.blocks):
+            at = blk.attn
+            n = at.window_size[0] * at.window_size[1]
+            o2 = off + pad4(nb)
+            self.views.append((self.out[off:off + nb].view(at.num_heads, n, n), self.out[o2:o2 + nh],
+                               self.grad[off:off + nb].view(at.num_heads, n, n), self.grad[o2:o2 + nh]))
+            off = o2 + pad4(nh)
+        self.pending = False
+        self._launch(False, None)
+
+    @classmethod
+    def _pinned(cls, nbytes):
+        if cls._PINS is None or cls._PINS.shape[1] < nbytes:
+            cls._PINS = torch.empty((8, max(nbytes, 8192)), dtype=torch.uint8, pin_memory=True)
+        cls._TURN += 1
+        return cls._PINS[cls._TURN % 8, :nbytes]
+
+    def _launch(self, backward, G):
+        tab = np.zeros(len(self.blocks), dtype=self._DT)
+        for i, blk in enumerate(self.blocks):
+            at = blk.attn
+            w0, b0, w2, ls = at.cpb_params()
+            bias, scale, dbias, dscale = self.views[i]
+            t = tab[i]
+            t["coords"], t["index"] = at.relative_coords_table.data_ptr(), at.relative_position_index.data_ptr()
+            t["w0"], t["b0"], t["w2"], t["ls"] = w0.data_ptr(), b0.data_ptr(), w2.data_ptr(), ls.data_ptr()
+            t["bias"], t["scale"], t["dbias"], t["dscale"] = bias.data_ptr(), scale.data_ptr(), dbias.data_ptr(), dscale.data_ptr()
+            if backward:
+                t["dw0"], t["db0"], t["dw2"], t["dls"] = (G(w0).data_ptr(), G(b0).data_ptr(), G(w2).data_ptr(), G(ls).data_ptr())
+            t["entries"], t["tokens"], t["heads"] = (at.relative_coords_table.numel() // 2,
+                                                     at.window_size[0] * at.window_size[1], at.num_heads)
+        raw = torch.from_numpy(tab.view(np.uint8))
+        pin = self._pinned(raw.numel())
+        pin.copy_(raw)
+        dev = torch.empty(raw.numel(), dtype=torch.uint8, device=self.out.device)
+        dev.copy_(pin, non_blocking=True)
+        fn = self.lib().frhip_cpb_bwd if backward else self.lib().frhip_cpb_fwd
+        self.check(fn(dev.data_ptr(), len(self.blocks), ops._s()), "frhip_cpb_bwd" if backward else "frhip_cpb_fwd")
+        self._table = dev                                    # alive until the kernel has run (stream-ordered free)
+
+    def flush_backward(self, bc):
+        """every block's d(bias), d(scale) -> parameter gradients, one launch (registered to run before bc.join())"""
+        if self.pending:
+            self.pending = False
+            for blk in self.blocks:
+                for p in blk.attn.cpb_params():
+                    if not p.data.is_contiguous() or not bc.G(p).is_contiguous():
+                        raise RuntimeError("frhip: the position-bias parameters and their gradients must be contiguous")
+            self._launch(True, bc.G)
+
+
+def precompute_position_bias(attn_blocks, device):
+    """all position-bias tables of the step in one launch (CpbBatch); each block picks its views up in position_bias()"""
+    attn_blocks = list(attn_blocks)
+    if not attn_blocks:
+        return None
+    batch = CpbBatch(attn_blocks, device)
+    for i, blk in enumerate(attn_blocks):
+        blk._cpb_batch = (batch, i)
+    return batch
 
 
 def position_bias(blk):
-    """(cpb leaves, bias_t, scale_t, bias, scale, on_side): precomputed on the side stream when available, else inline"""
-    at = blk.attn
-    pre = getattr(blk, "_cpb_ready", None)
-    if pre is not None:
-        blk._cpb_ready = None
-        cpb, bias_t, scale_t, bias, scale, ev = pre
-        torch.cuda.current_stream(bias.device).wait_event(ev)
-        return cpb, bias_t, scale_t, bias, scale, True
-    with torch.enable_grad():
-        cpb = [p.detach().requires_grad_(True) for p in at.cpb_params()]
-        bias_t, scale_t = at.bias_and_scale(cpb)
-    return cpb, bias_t, scale_t, bias_t.detach().contiguous(), scale_t.detach().contiguous(), False
+    """(batch, index, bias [heads,n,n], scale [heads], d bias, d scale) of one block; computed on the spot when the block was
+    not part of a precompute_position_bias() group (blocks driven one by one, e.g. from a test)"""
+    hit = getattr(blk, "_cpb_batch", None)
+    if hit is None:
+        hit = (CpbBatch([blk], blk.attn.logit_scale.device), 0)
+    blk._cpb_batch = None
+    batch, i = hit
+    bias, scale, dbias, dscale = batch.views[i]
+    return batch, i, bias, scale, dbias, dscale
 
 
-def position_bias_backward(blk, s, dbias, dscale, bc):
-    """d(bias table), d(logit scale) -> the position-bias MLP's parameters (parameter-space torch autograd).  Autograd runs a
-    node on the stream of its forward op, so the graph built on the side stream is differentiated there as well."""
-    at = blk.attn
-
-    def run():
-        gs = torch.autograd.grad([s.bias_t, s.scale_t], s.cpb, [dbias, dscale])
-        for p, g in zip(at.cpb_params(), gs):
-            bc.G(p).add_(g.reshape(p.shape))
-    if getattr(s, "cpb_on_side", False):
-        bc.on_side(run, dbias, dscale, s.bias_t, s.scale_t)
-    else:
-        run()
+def position_bias_backward(blk, s, bc):
+    """the block's d(bias) / d(scale) sit in the batch's gradient arena (the attention backward kernel added them there):
+    queue the batch's one backward launch behind the whole backward pass"""
+    batch = s.cpb_batch
+    if not batch.pending:
+        batch.pending = True
+        bc.before_join.append(lambda: batch.flush_backward(bc))
 
 
 def swin_block_forward(blk, x, dt, training, save, wprep=None):
@@ -195,7 +241,7 @@ def swin_block_forward(blk, x, dt, training, save, wprep=None):
     wqkv, wqkv_t = _lin_operands(at.qkv, dt, wprep)
     qb = torch.cat([at.q_bias.data, torch.zeros_like(at.v_bias.data), at.v_bias.data])
     qkv, _, _ = ops.linear_fwd(x2, wqkv, qb)                                  # bias add in the GEMM epilogue
-    cpb, bias_t, scale_t, bias, scale, cpb_on_side = position_bias(blk)
+    cpb_batch, _, bias, scale, dbias_buf, dscale_buf = position_bias(blk)
     ao = ops.winattn_fwd(qkv, bias, scale, b, h, w, at.num_heads)
     wproj, wproj_t = _lin_operands(at.proj, dt, wprep)
     po, _, part2 = ops.linear_fwd(ao, wproj, at.proj.bias.data, want_stats=training)   # + norm2's batch statistics
@@ -210,10 +256,9 @@ def swin_block_forward(blk, x, dt, training, save, wprep=None):
     s = None
     if save:
         s = Saved()
-        (s.x2, s.wqkv, s.qkv, s.cpb, s.bias_t, s.scale_t, s.bias, s.scale, s.ao, s.wproj, s.po, s.st2, s.x1, s.w1, s.hid,
-         s.act, s.w2, s.mo, s.st3, s.shape) = (x2, wqkv, qkv, cpb, bias_t, scale_t, bias, scale, ao, wproj, po, st2, x1, w1,
-                                                hid, act, w2, mo, st3, (b, h, w, c))
-        s.cpb_on_side = cpb_on_side
+        (s.x2, s.wqkv, s.qkv, s.cpb_batch, s.dbias, s.dscale, s.bias, s.scale, s.ao, s.wproj, s.po, s.st2, s.x1, s.w1, s.hid,
+         s.act, s.w2, s.mo, s.st3, s.shape) = (x2, wqkv, qkv, cpb_batch, dbias_buf, dscale_buf, bias, scale, ao, wproj, po, st2,
+                                                x1, w1, hid, act, w2, mo, st3, (b, h, w, c))
         s.wqkv_t, s.wproj_t, s.w1_t, s.w2_t = wqkv_t, wproj_t, w1_t, w2_t
     return out, s
 
@@ -257,7 +302,8 @@ def swin_block_backward(blk, s, dout, dt, bc, next_bn=None, part3=None):
     dpo = ops.bn_backward(dx1, s.po, s.st2, blk.norm2.weight.data, G(blk.norm2.weight), G(blk.norm2.bias), part=part2)
     bc.on_side(lambda: ops.gemm_tn(dpo, s.ao, G(at.proj.weight)), dpo, s.ao)
     dao = ops.gemm_nt(dpo, _transposed(s.wproj, s.wproj_t))
-    dqkv, dbias, dscale, gsum = ops.winattn_bwd(s.qkv, dao, s.bias, s.scale, b, h, w, at.num_heads, want_colsum=True)
+    dqkv, _, _, gsum = ops.winattn_bwd(s.qkv, dao, s.bias, s.scale, b, h, w, at.num_heads, want_colsum=True,
+                                       dbias=s.dbias, dscale=s.dscale)      # d(bias), d(scale) accumulate in the batch's arena
     if gsum is None:                                 # fp32 validation kernels: column sums by a ones-GEMM
         gsum = torch.zeros(3 * c, dtype=torch.float32, device=dout.device)
         _colsum_via_gemm(dqkv, gsum)
@@ -269,8 +315,8 @@ def swin_block_backward(blk, s, dout, dt, bc, next_bn=None, part3=None):
         dx, part = _dgrad_add(dqkv, s.wqkv, dx1, s.wqkv_t, bnred=next_bn)
     else:
         dx = _dgrad_add(dqkv, s.wqkv, dx1, s.wqkv_t)
-    # ---- the 169-entry position-bias MLP and the logit scale (parameter space, torch autograd)
-    position_bias_backward(blk, s, dbias, dscale, bc)
+    # ---- the 169-entry position-bias MLP and the logit scale: one batched kernel launch at the end of the backward pass
+    position_bias_backward(blk, s, bc)
     return dx.view(b, h, w, c) if next_bn is None else (dx.view(b, h, w, c), part)
 
 
@@ -318,9 +364,9 @@ class Swin(nn.Module):
         dt = self.dtype
         sv = Saved() if save else None
         wprep = None
+        blocks = [m for m in self._layers() if not isinstance(m, _Conv)]
+        precompute_position_bias(blocks, x.device)         # every block's bias table and logit scale: one launch
         if training and save:
-            blocks = [m for m in self._layers() if not isinstance(m, _Conv)]
-            precompute_position_bias(blocks, x.device)
             wprep = prepare_linear_weights([l for b in blocks for l in (b.attn.qkv, b.attn.proj, b.mlp.fc1, b.mlp.fc2)], dt)
         cur = stem_forward(self, x, training, sv)
         saved = []

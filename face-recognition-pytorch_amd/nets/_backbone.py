@@ -166,6 +166,7 @@ class BackwardCtx:
         self.allreduce = bool(allreduce) and dist.is_available() and dist.is_initialized()
         self.reduced_from = self.flat.numel()          # arena[reduced_from:] has been handed to RCCL
         self.works = []
+        self.before_join = []                          # deferred gradient work (e.g. the batched position-bias backward)
 
     def G(self, p):
         return self.grads[p]
@@ -212,6 +213,9 @@ class BackwardCtx:
             self.reduced_from = lo
 
     def join(self):
+        for fn in self.before_join:
+            fn()
+        self.before_join = []
         if self.allreduce:
             self._reduce(0, self.reduced_from)
             self.reduced_from = 0
@@ -360,23 +364,74 @@ def _operands(conv, dt, wprep):
     return ops.cast_from_f32(conv.physical(), dt), None
 
 
-def basic_block_forward(blk, xin, dt, training, save, wprep=None):
+def use_fp8(conf):
+    """conf.frhip_fp8 / $FRHIP_FP8 = 1: forward GEMMs with >= 128 input channels run on the fp8 MFMA path (BASELINE cfg 5)"""
+    v = getattr(conf, "frhip_fp8", None)
+    return bool(int(os.environ.get("FRHIP_FP8", "0"))) if v is None else bool(v)
+
+
+class Fp8Ctx:
+    """State of the fp8 weight path during ONE forward pass: the fp8 weight packs of the step (per-output-channel scales) and
+    the fp8 copy of the activation tensor the last fused BatchNorm-apply pass wrote (the operand of the next GEMM)."""
+
+    def __init__(self, weights):
+        self.packs = {}
+        for mod, w in weights:                         # w: fp32, physical [K, ...] with the reduction dims contiguous
+            self.packs[mod] = ops.quant_fp8_weights(w)
+        self._of, self._x8 = None, None
+
+    @staticmethod
+    def eligible(cin):
+        return cin % 128 == 0                          # one K step of the fp8 kernels = 128 channels
+
+    def put(self, x, x8):
+        self._of, self._x8 = x, x8
+
+    def take(self, x):
+        """fp8 copy of x: the one its producer wrote, else a quantisation pass"""
+        if self._of is x:
+            return self._x8
+        return ops.quant_fp8(x)
+
+
+def basic_block_forward(blk, xin, dt, training, save, wprep=None, q8=None):
+    """q8 (Fp8Ctx): convolutions whose input width is a multiple of 128 run on the fp8 MFMA kernels; the BatchNorm-apply
+    passes that feed them write the fp8 operand copy themselves.  Everything saved for the backward pass stays as in the
+    bf16 path (the backward kernels read the bf16 tensors)."""
+    cin, planes = blk.conv1.cin, blk.conv2.cout
+    f1 = q8 is not None and dt == torch.bfloat16 and Fp8Ctx.eligible(cin)      # conv1, conv2 and the shortcut conv all read cin channels
+    fo = q8 is not None and dt == torch.bfloat16 and Fp8Ctx.eligible(planes)   # the block output feeds a GEMM of `planes` channels
     w1, w1t = _operands(blk.conv1, dt, wprep)
-    y1, p1 = ops.conv_fwd(xin, w1, 1, 1, want_stats=training)
+    x8 = q8.take(xin) if f1 else None
+    if f1:
+        y1, p1 = ops.conv_fwd_fp8(x8, *q8.packs[blk.conv1], 1, 1, want_stats=training)
+    else:
+        y1, p1 = ops.conv_fwd(xin, w1, 1, 1, want_stats=training)
     st1 = bn_forward_state(blk.bn1, p1, y1.numel() // y1.shape[3], training)
-    a1 = ops.bn_apply(y1, st1, relu=True)
     w2, w2t = _operands(blk.conv2, dt, wprep)
-    y2, p2 = ops.conv_fwd(a1, w2, blk.stride, 1, want_stats=training)
+    if f1:
+        a1, a18 = ops.bn_apply_q8(y1, st1, relu=True)
+        y2, p2 = ops.conv_fwd_fp8(a18, *q8.packs[blk.conv2], blk.stride, 1, want_stats=training)
+    else:
+        a1 = ops.bn_apply(y1, st1, relu=True)
+        y2, p2 = ops.conv_fwd(a1, w2, blk.stride, 1, want_stats=training)
     st2 = bn_forward_state(blk.bn2, p2, y2.numel() // y2.shape[3], training)
     yd = std = wdt = None
+    res, res_st = xin, None
     if blk.downsample is not None:
         dconv, dbn = blk.downsample[0], blk.downsample[1]
         wd, wdt = _operands(dconv, dt, wprep)
-        yd, pd = ops.conv_fwd(xin, wd, dconv.stride, 0, want_stats=training)
+        if f1:
+            yd, pd = ops.conv_fwd_fp8(x8, *q8.packs[dconv], dconv.stride, 0, want_stats=training)
+        else:
+            yd, pd = ops.conv_fwd(xin, wd, dconv.stride, 0, want_stats=training)
         std = bn_forward_state(dbn, pd, yd.numel() // yd.shape[3], training)
-        out = ops.bn_apply(y2, st2, res=yd, res_st=std)
+        res, res_st = yd, std
+    if fo:
+        out, out8 = ops.bn_apply_q8(y2, st2, res=res, res_st=res_st)
+        q8.put(out, out8)
     else:
-        out = ops.bn_apply(y2, st2, res=xin)
+        out = ops.bn_apply(y2, st2, res=res, res_st=res_st)
     s = None
     if save:
         s = Saved()

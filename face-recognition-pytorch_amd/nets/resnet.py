@@ -15,12 +15,13 @@ What is different underneath (nothing is delegated to torch's conv/BN kernels):
     hand-written gradient kernels and returns all parameter gradients.
 There is no CPU / eager fallback: without libfrhip.so or without a GPU tensor, forward raises.
 """
+import torch
 import torch.nn as nn
 
-from ._backbone import (BackwardCtx, BasicBlock, Saved, _BN, _Conv, _Linear, basic_block_backward,
+from ._backbone import (BackwardCtx, BasicBlock, Fp8Ctx, Saved, _BN, _Conv, _Linear, basic_block_backward,
                         basic_block_forward, compute_dtype, encoder_call, prepare_conv_weights, stem_backward,
                         stem_forward, stem_reduction_operands,
-                        tail_backward, tail_forward)
+                        tail_backward, tail_forward, use_fp8)
 
 _BLOCKS = {18: (2, 2, 2, 2), 34: (3, 4, 6, 4), 50: (3, 4, 14, 4), 100: (3, 13, 30, 4), 200: (3, 43, 50, 4)}
 
@@ -31,6 +32,7 @@ class ResNet(nn.Module):
         super().__init__()
         self.emd_size = conf.emd_size
         self.dtype = compute_dtype(conf)
+        self.fp8 = use_fp8(conf)                   # forward GEMMs with >= 128 input channels on the fp8 MFMA path (csrc/igemm_fp8.hip)
         self.inplanes = 64
         self.conv1 = _Conv(3, 64, 3, 1)
         self.bn1 = _BN(64)
@@ -73,8 +75,11 @@ class ResNet(nn.Module):
         blocks = list(self._blocks())
         convs = [c for b in blocks for c in ((b.conv1, b.conv2) + ((b.downsample[0],) if b.downsample is not None else ()))]
         wprep = prepare_conv_weights(convs, self.dtype)          # every conv operand of the step in one launch
+        q8 = None
+        if self.fp8 and self.dtype == torch.bfloat16:
+            q8 = Fp8Ctx([(c, c.physical()) for c in convs if Fp8Ctx.eligible(c.cin)])
         for blk in blocks:
-            cur, s = basic_block_forward(blk, cur, self.dtype, training, save, wprep)
+            cur, s = basic_block_forward(blk, cur, self.dtype, training, save, wprep, q8)
             saved_blocks.append(s)
         emb = tail_forward(self, cur, training, sv)
         if save:

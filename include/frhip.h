@@ -198,6 +198,52 @@ int frhip_head_bwd_dt(int dtype, const void* ehat, const void* what, const int* 
                       int d, float s, float m, const float* rowmax, const float* rowsum, float gscale,
                       const float* upstream, void* dt, int ldt, frhip_stream_t stream);
 
+/* ---- fp8 weight path (BASELINE cfg 5; the reference has no fp8 arithmetic, see csrc/igemm_fp8.hip).  Forward convolutions
+ * (nets/AlterNet_SwinV2_FAN.py:520-568, nets/resnet.py:23-46) and linears (:263-302) with both MFMA operands in OCP fp8
+ * e4m3 on v_mfma_scale_f32_16x16x128_f8f6f4; bf16 output = fp32 accumulator x act_scale x w_scale[k] ---- */
+/* w [k][rowlen] fp32 (a conv weight in its physical [K][R][S][C] order) -> w8 fp8 + scale[k] = amax(row) / 448 */
+int frhip_quant_fp8_weights(const float* w, void* w8, float* scale, int k, int rowlen, frhip_stream_t stream);
+/* x8 = fp8(x * inv_scale), n % 16 == 0 */
+int frhip_quant_fp8(int dtype, const void* x, void* x8, size_t n, float inv_scale, frhip_stream_t stream);
+/* frhip_bn_apply that also writes the fp8 copy out8 = fp8(out * inv_q) the next fp8 GEMM reads (bf16 tensors) */
+int frhip_bn_apply_q8(int dtype, const void* y, const float* scale, const float* shift, const void* res,
+                      const float* res_scale, const float* res_shift, int relu, void* out, void* out8, float inv_q,
+                      int rows, int c, frhip_stream_t stream);
+/* y bf16 [n,ho,wo,k] = conv(x8 [n,h,w,c] fp8, w8 [k,r,s,c] fp8) * act_scale * wscale[k]; c % 128 == 0;
+ * stats_partial: [frhip_fp8_stat_rows(n*ho*wo, k)][2][k] BatchNorm partial sums of the stored values, or NULL */
+int frhip_conv_fwd_fp8(const void* x8, const void* w8, const float* wscale, float act_scale, void* y,
+                       float* stats_partial, int n, int h, int wd, int c, int k, int r, int s, int stride, int pad,
+                       frhip_stream_t stream);
+int frhip_fp8_stat_rows(int m, int k);
+/* out bf16 [m][n] = a8 [m][k] x w8 [n][k]^T * act_scale * wscale[n] + bias[n] */
+int frhip_linear_fwd_fp8(const void* a8, const void* w8, const float* wscale, float act_scale, const float* bias,
+                         void* out, float* stats_partial, int m, int n, int k, frhip_stream_t stream);
+
+/* ---- continuous position bias of the window attention (nets/SwinV2.py:88-125, :150-158; nets/AlterNet_SwinV2_FAN.py:210-283):
+ * bias[h][i][j] = 16 sigmoid(cpb_mlp(coords)[index[i][j]][h]), scale[h] = exp(min(logit_scale[h], ln 100)), and the gradients of
+ * cpb_mlp.0.weight / .0.bias / .2.weight / logit_scale, for ALL attention blocks of a step in one launch each way.
+ * One descriptor per block (device array); every pointer is a device address, fp32 unless noted. ---- */
+typedef struct frhip_cpb_block {
+    const void* coords;        /* [entries][2]  relative_coords_table */
+    const void* index;         /* int64 [tokens*tokens]  relative_position_index */
+    const void* w0;            /* [512][2] */
+    const void* b0;            /* [512] */
+    const void* w2;            /* [heads][512] */
+    const void* logit_scale;   /* [heads] */
+    void* bias;                /* out: [heads][tokens][tokens] */
+    void* scale;               /* out: [heads] */
+    const void* dbias;         /* backward in: [heads][tokens][tokens] */
+    const void* dscale;        /* backward in: [heads] */
+    void* dw0;                 /* backward, accumulated into: same shapes as w0 / b0 / w2 / logit_scale */
+    void* db0;
+    void* dw2;
+    void* dlogit_scale;
+    int entries, tokens, heads, pad_;
+} frhip_cpb_block;
+int frhip_cpb_limits(int* max_entries, int* max_heads, int* hidden);
+int frhip_cpb_fwd(const frhip_cpb_block* blocks_dev, int nblocks, frhip_stream_t stream);
+int frhip_cpb_bwd(const frhip_cpb_block* blocks_dev, int nblocks, frhip_stream_t stream);
+
 /* ---- explicit-logit margin and softmax-CE (stand-alone use of nets/ArcFace.py:76-105, nets/PartialFC.py:441-484) ---- */
 /* logits[n][c] fp32 in place: target entry -> margin (kind 0 ArcFace, 1 CosFace), everything x s; tsave[n] = raw target cos.
  * labels int64 [n], -1 = no target in this shard */

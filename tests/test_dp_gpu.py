@@ -39,22 +39,23 @@ def _worker(rank, ws, path, rate, ret):
     enc = model.encoder.module
     sums = np.array([float(p.detach().double().sum()) for p in enc.parameters()])
     absmax = float(max(p.grad.abs().max() for p in enc.parameters()))
-    ret[rank] = dict(losses=losses, sums=sums, absmax=absmax, wrapped=type(model.encoder).__name__,
-                     head_rows=int(model.loss.num_local))
+    # through a file, not a multiprocessing.Manager: a Manager is a FORKED child of the pytest process, i.e. one more process
+    # holding the GPU open (a box admits 6), and it outlives a failing test for as long as pytest keeps the traceback
+    np.savez(os.path.join(ret, "rank%d.npz" % rank), losses=np.array(losses), sums=sums, absmax=absmax,
+             wrapped=type(model.encoder).__name__, head_rows=int(model.loss.num_local))
     dist.destroy_process_group()
 
 
 @pytest.mark.parametrize("rate", [1.0, 0.5])
 def test_two_ranks_stay_in_step(rate):
     with tempfile.TemporaryDirectory() as td:
-        ret = mp.Manager().dict()
-        mp.spawn(_worker, args=(2, os.path.join(td, "pg"), rate, ret), nprocs=2, join=True)
-        a, b = ret[0], ret[1]
-        assert a["wrapped"] == "DataParallel" and a["head_rows"] == b["head_rows"] == 200
+        mp.spawn(_worker, args=(2, os.path.join(td, "pg"), rate, td), nprocs=2, join=True)
+        a, b = (dict(np.load(os.path.join(td, "rank%d.npz" % r))) for r in range(2))
+        assert str(a["wrapped"]) == "DataParallel" and int(a["head_rows"]) == int(b["head_rows"]) == 200
         # the global margin-softmax loss is the same number on every rank, and it moves
         np.testing.assert_allclose(a["losses"], b["losses"], rtol=1e-6)
         assert a["losses"][1] != a["losses"][0] and np.isfinite(a["losses"]).all()
         # same initial weights (broadcast) + averaged gradients every step => identical backbones after two steps,
         # although the ranks saw different images
         np.testing.assert_allclose(a["sums"], b["sums"], rtol=0, atol=0)
-        assert a["absmax"] > 0
+        assert float(a["absmax"]) > 0

@@ -4,8 +4,8 @@ device tensors, every GPU rank on cuda:0) against the fixtures the real referenc
 shard-relative labels, sampling + optimizer swap, embedding all-gather, the fused margin-softmax kernels of libfrhip, the
 one-exchange merge of the per-row softmax statistics, reduce-scatter of dE.
 
-world_size 8: a GPU box admits at most 6 processes on its card (the pytest process is one of them), so ranks 0-4 run the
-HIP kernels and ranks 5-7 run the oracle-backed double on the CPU in the same gloo group; every rank's outputs are still
+world_size 8: a GPU box admits at most 6 processes on its card (the pytest process is one of them), so ranks 0-3 run the
+HIP kernels and ranks 4-7 run the oracle-backed double on the CPU in the same gloo group; every rank's outputs are still
 compared with the fixture, and the GPU ranks' results depend on the CPU ranks' statistics and vice versa."""
 import os
 import sys
@@ -20,7 +20,7 @@ import torch.multiprocessing as mp
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
-MAX_GPU_RANKS = 5
+MAX_GPU_RANKS = 4          # + the pytest process itself: 5 of the 6 processes a box lets onto its card
 
 
 def _worker(rank, ws, path, name, ret, use_prepare):
@@ -65,8 +65,10 @@ def _worker(rank, ws, path, name, ret, use_prepare):
     ok_opt = opt.param_groups[-1]["params"][0] is pfc.weight_activated
     if rate < 1:
         ok_opt = ok_opt and opt.state[pfc.weight_activated]["momentum_buffer"] is pfc.weight_activated_mom
-    ret[rank] = dict(loss=float(loss), d_emb=emb.grad.cpu().numpy(), d_w=pfc.weight_activated.grad.cpu().numpy(),
-                     index=idx.cpu().numpy(), ok_opt=bool(ok_opt), on_gpu=on_gpu)
+    # results travel through files: a multiprocessing.Manager is a FORKED child of the pytest process and would count as one
+    # more process holding the GPU open
+    np.savez(os.path.join(ret, "rank%d.npz" % rank), loss=float(loss.detach()), d_emb=emb.grad.cpu().numpy(),
+             d_w=pfc.weight_activated.grad.cpu().numpy(), index=idx.cpu().numpy(), ok_opt=bool(ok_opt), on_gpu=on_gpu)
     dist.destroy_process_group()
 
 
@@ -76,15 +78,15 @@ def test_partial_fc_hip_head_multi_rank_vs_reference(golden, name, use_prepare):
     g = golden(name)
     ws = int(g["ws"])
     with tempfile.TemporaryDirectory() as td:
-        ret = mp.Manager().dict()
-        mp.spawn(_worker, args=(ws, os.path.join(td, "pg"), name, ret, use_prepare), nprocs=ws, join=True)
-        assert sum(ret[r]["on_gpu"] for r in range(ws)) == min(ws, MAX_GPU_RANKS)
+        mp.spawn(_worker, args=(ws, os.path.join(td, "pg"), name, td, use_prepare), nprocs=ws, join=True)
+        ret = [dict(np.load(os.path.join(td, "rank%d.npz" % r))) for r in range(ws)]
+        assert sum(bool(ret[r]["on_gpu"]) for r in range(ws)) == min(ws, MAX_GPU_RANKS)
         for r in range(ws):
             out = ret[r]
-            assert out["ok_opt"]
+            assert bool(out["ok_opt"])
             assert np.array_equal(out["index"], g["r%d_index" % r]), "rank %d: sampled rows differ" % r     # bit-exact
             # north_star: fp32 loss / logits within 1e-3 relative of the reference (the fp32-MFMA mode lands near 1e-6)
-            np.testing.assert_allclose(out["loss"], g["r%d_loss" % r], rtol=1e-4, err_msg="rank %d loss" % r)
+            np.testing.assert_allclose(float(out["loss"]), g["r%d_loss" % r], rtol=1e-4, err_msg="rank %d loss" % r)
             for key, ref in (("d_emb", g["r%d_d_emb" % r]), ("d_w", g["r%d_d_w_act" % r])):
                 np.testing.assert_allclose(out[key], ref, rtol=1e-3, atol=1e-3 * float(np.abs(ref).max()) * 1e-2,
                                            err_msg="rank %d %s" % (r, key))

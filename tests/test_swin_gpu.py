@@ -173,3 +173,47 @@ def test_swin34_fp32_eval_and_bf16_train_step(golden):
     y = net16(recipe.images(6301, 4).cuda())
     y.sum().backward()
     assert torch.isfinite(y).all() and all(torch.isfinite(p.grad).all() for p in net16.parameters())
+
+
+@pytest.mark.parametrize("ws,heads", [(7, 4), (6, 8), (3, 16)])
+def test_position_bias_kernel_matches_torch_formula(ws, heads):
+    """csrc/cpb.hip (one launch for a group of blocks, forward and backward) against the reference's formula in torch ops:
+    16 * sigmoid(cpb_mlp(coords_table)[relative_position_index]) and exp(min(logit_scale, ln 100))
+    (/root/reference/nets/SwinV2.py:150-158, nets/AlterNet_SwinV2_FAN.py:276-283), fp32, 1e-5."""
+    import math
+    import torch.nn.functional as F
+    import nets.AlterNet_SwinV2_FAN as A
+    import nets.SwinV2 as S
+    from nets._backbone import BackwardCtx
+    torch.manual_seed(ws)
+    blks = []
+    for i in range(3):
+        blk = A.SwinTransformerBlock(heads * 32, heads * 32, heads=heads, input_resolution=(2 * ws, 2 * ws), window_size=ws).cuda()
+        with torch.no_grad():
+            blk.attn.logit_scale.add_(torch.randn_like(blk.attn.logit_scale))        # some heads beyond the ln(100) clamp
+            blk.attn.logit_scale[0] = 5.0
+        blks.append(blk)
+    batch = S.precompute_position_bias(blks, torch.device("cuda"))
+    params = [p for b in blks for p in b.attn.cpb_params()]
+    bc = BackwardCtx(params, torch.device("cuda"))
+    n = ws * ws
+    for i, blk in enumerate(blks):
+        at = blk.attn
+        w0, b0, w2, ls = [p.detach().clone().requires_grad_(True) for p in at.cpb_params()]
+        t = F.linear(F.relu(F.linear(at.relative_coords_table, w0, b0)), w2).view(-1, heads)
+        bias_ref = 16 * torch.sigmoid(t[at.relative_position_index.view(-1)].view(n, n, heads).permute(2, 0, 1).contiguous())
+        scale_ref = torch.clamp(ls, max=math.log(100.0)).exp().reshape(-1)
+        _, _, bias, scale, dbias, dscale = S.position_bias(blk)
+        np.testing.assert_allclose(bias.cpu().numpy(), bias_ref.detach().cpu().numpy(), rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(scale.cpu().numpy(), scale_ref.detach().cpu().numpy(), rtol=1e-6)
+        gb, gs = torch.randn_like(bias_ref), torch.randn_like(scale_ref)
+        dbias.copy_(gb)
+        dscale.copy_(gs)
+        want = torch.autograd.grad([bias_ref, scale_ref], [w0, b0, w2, ls], [gb, gs])
+        s = types.SimpleNamespace(cpb_batch=batch)
+        S.position_bias_backward(blk, s, bc)
+        blk._want = want
+    grads = bc.join()
+    for blk in blks:
+        for p, w in zip(blk.attn.cpb_params(), blk._want):
+            np.testing.assert_allclose(grads[p].cpu().numpy(), w.cpu().numpy(), rtol=2e-4, atol=2e-5 * float(w.abs().max()) + 1e-7)
