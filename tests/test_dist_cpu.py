@@ -60,7 +60,8 @@ def _worker(rank, ws, path, name, ret, use_prepare=False):
 
 @pytest.mark.parametrize("name,use_prepare", [("head_ws2_rate10", False), ("head_ws2_rate03", False), ("head_ws8_rate01", False),
                                               ("head_ws2_rate03", True), ("head_ws2_rate10", True),
-                                              ("head_ws2_rate03", "full"), ("head_ws2_rate10", "full"), ("head_ws8_rate01", "full")])
+                                              ("head_ws2_rate03", "full"), ("head_ws2_rate10", "full"), ("head_ws8_rate01", "full"),
+                                              ("head_ws4_rate01", "full")])
 def test_partial_fc_host_logic_multi_rank(golden, name, use_prepare):
     g = golden(name)
     ws = int(g["ws"])

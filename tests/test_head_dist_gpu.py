@@ -1,12 +1,14 @@
 """BASELINE cfg 3 on the HIP kernels: the class-sharded PartialFC head with REAL ranks (one process each, gloo collectives on
-device tensors, every GPU rank on cuda:0) against the fixtures the real reference produced at the same world sizes
-(tools/make_golden.py: head_ws2_rate10, head_ws2_rate03, head_ws8_rate01).  Product code end to end: label all-gather,
+device tensors, every rank on cuda:0) against the fixtures the real reference produced at the same world sizes
+(tools/make_golden.py: head_ws2_rate10, head_ws2_rate03, head_ws4_rate01).  Product code end to end: label all-gather,
 shard-relative labels, sampling + optimizer swap, embedding all-gather, the fused margin-softmax kernels of libfrhip, the
 one-exchange merge of the per-row softmax statistics, reduce-scatter of dE.
 
-world_size 8: a GPU box admits at most 6 processes on its card (the pytest process is one of them), so ranks 0-3 run the
-HIP kernels and ranks 4-7 run the oracle-backed double on the CPU in the same gloo group; every rank's outputs are still
-compared with the fixture, and the GPU ranks' results depend on the CPU ranks' statistics and vice versa."""
+Why world_size 4 and not 8 here: a GPU box admits at most 6 processes that hold its card open, the pytest process is one of
+them, and EVERY torch process that runs an autograd backward opens the card (the engine asks the HIP runtime for its device
+count) -- also a rank that computes on the CPU.  The world_size-8 fixture (head_ws8_rate01) therefore runs the same product
+host logic on gloo/CPU with the oracle-backed kernel double (tests/test_dist_cpu.py); sample rate 0.1 and a class count that
+does not divide by the world size (4003) are covered here at world_size 4."""
 import os
 import sys
 import tempfile
@@ -20,7 +22,6 @@ import torch.multiprocessing as mp
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
-MAX_GPU_RANKS = 4          # + the pytest process itself: 5 of the 6 processes a box lets onto its card
 
 
 def _worker(rank, ws, path, name, ret, use_prepare):
@@ -30,21 +31,15 @@ def _worker(rank, ws, path, name, ret, use_prepare):
     from oracle import recipe
     import nets.PartialFC as P
     torch.set_num_threads(1)
-    on_gpu = rank < MAX_GPU_RANKS
-    dev = torch.device("cuda", 0) if on_gpu else torch.device("cpu")
-    if on_gpu:
-        torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
     g = dict(np.load(os.path.join(ROOT, "tests", "golden", name + ".npz")))
     dist.init_process_group("gloo", init_method="file://" + path, rank=rank, world_size=ws)
     C, B, D, rate = int(g["C"]), int(g["B"]), int(g["D"]), float(g["rate"])
     conf = types.SimpleNamespace(emd_size=D, sample_rate=rate, mixed_precision=False, loss_s=float(g["s"]),
                                  loss_m=float(g["m"]), frhip_dtype="fp32")
-    if on_gpu:
-        pfc = P.PartialFC(conf, C).to(dev)                  # HipHeadKernels: raises if libfrhip.so is missing
-        assert type(pfc.kernels).__name__ == "HipHeadKernels"
-    else:
-        from head_double import OracleHeadKernels
-        pfc = P.PartialFC(conf, C, kernels=OracleHeadKernels())
+    pfc = P.PartialFC(conf, C).to(dev)                      # HipHeadKernels: raises if libfrhip.so is missing
+    assert type(pfc.kernels).__name__ == "HipHeadKernels"
     W = recipe.normal(500 + rank, (pfc.num_local, D), 0.05).to(dev)
     with torch.no_grad():
         (pfc.weight if rate < 1 else pfc.weight_activated.data).copy_(W)
@@ -68,19 +63,18 @@ def _worker(rank, ws, path, name, ret, use_prepare):
     # results travel through files: a multiprocessing.Manager is a FORKED child of the pytest process and would count as one
     # more process holding the GPU open
     np.savez(os.path.join(ret, "rank%d.npz" % rank), loss=float(loss.detach()), d_emb=emb.grad.cpu().numpy(),
-             d_w=pfc.weight_activated.grad.cpu().numpy(), index=idx.cpu().numpy(), ok_opt=bool(ok_opt), on_gpu=on_gpu)
+             d_w=pfc.weight_activated.grad.cpu().numpy(), index=idx.cpu().numpy(), ok_opt=bool(ok_opt))
     dist.destroy_process_group()
 
 
 @pytest.mark.parametrize("name,use_prepare", [("head_ws2_rate10", False), ("head_ws2_rate03", False), ("head_ws2_rate03", True),
-                                              ("head_ws2_rate10", True), ("head_ws8_rate01", True), ("head_ws8_rate01", False)])
+                                              ("head_ws2_rate10", True), ("head_ws4_rate01", True), ("head_ws4_rate01", False)])
 def test_partial_fc_hip_head_multi_rank_vs_reference(golden, name, use_prepare):
     g = golden(name)
     ws = int(g["ws"])
     with tempfile.TemporaryDirectory() as td:
         mp.spawn(_worker, args=(ws, os.path.join(td, "pg"), name, td, use_prepare), nprocs=ws, join=True)
         ret = [dict(np.load(os.path.join(td, "rank%d.npz" % r))) for r in range(ws)]
-        assert sum(bool(ret[r]["on_gpu"]) for r in range(ws)) == min(ws, MAX_GPU_RANKS)
         for r in range(ws):
             out = ret[r]
             assert bool(out["ok_opt"])

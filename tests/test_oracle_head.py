@@ -43,7 +43,7 @@ def _head_inputs(g):
 
 
 @pytest.mark.parametrize("name", ["head_ws1_rate10", "head_ws1_rate03", "head_ws2_rate10",
-                                  "head_ws2_rate03", "head_ws8_rate01"])
+                                  "head_ws2_rate03", "head_ws8_rate01", "head_ws4_rate01"])
 def test_head_matches_reference(golden, name):
     g = golden(name)
     embs, labs, weights, us = _head_inputs(g)

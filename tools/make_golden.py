@@ -454,6 +454,7 @@ GENS = {
     "head_ws2_rate10": lambda: gen_head(2, 1.0),
     "head_ws2_rate03": lambda: gen_head(2, 0.3),
     "head_ws8_rate01": lambda: gen_head(8, 0.1, C=4003, B=4),
+    "head_ws4_rate01": lambda: gen_head(4, 0.1, C=4003, B=8),
     "basicblock": gen_basicblock,
     "resnet": gen_resnet,
     "train": gen_train_steps,
