@@ -354,6 +354,7 @@ class _PartialFCBase(torch.nn.Module):
         else:
             labels = lab.clone()
         n_pos, check = None, None
+        rng_before = self._rng_state() if (self.sample_rate < 1 and optimizer is not None) else None
         if self.sample_rate < 1:
             mask = (self.class_start <= labels) & (labels < self.class_start + self.num_local)
             hits = torch.zeros(self.num_local + 1, dtype=torch.int32, device=labels.device)
@@ -375,7 +376,7 @@ class _PartialFCBase(torch.nn.Module):
                 pin.copy_(count.to(torch.int64).view(1), non_blocking=True)
                 ev = torch.cuda.Event()
                 ev.record()
-                check = [ev, pin, self._rng_state(), None, None]
+                check = [ev, pin, rng_before, None, None]
                 n_pos = 0                                  # optimistic: the sync-free branch of sample()
             else:
                 n_pos = int(count.item())
@@ -390,7 +391,7 @@ class _PartialFCBase(torch.nn.Module):
                     check[3], check[4] = rel.clone(), index_positive
                 self.sample(rel, index_positive, optimizer, n_pos)
             ready = rel.view(-1).to(torch.int32).contiguous()
-        self._prep = (local_labels.data_ptr(), labels, n_pos, ready, check)
+        self._prep = (local_labels.data_ptr(), labels, n_pos, ready, check, rng_before)
 
     def _rng_state(self):
         return self.generator.get_state() if self.generator is not None else torch.get_rng_state()
@@ -417,7 +418,12 @@ class _PartialFCBase(torch.nn.Module):
         local_labels.squeeze_()
         prep, self._prep = getattr(self, "_prep", None), None
         if prep is not None and prep[0] != local_labels.data_ptr():
-            prep = None                                    # a prepare() left over from another step / other labels: ignore it
+            # a prepare() left over from another step / made for other labels: ignore it.  If it already sampled, hand its
+            # draw back to the CPU generator so the sampling below consumes what the reference would
+            if prep[3] is not None and self.sample_rate < 1 and prep[5] is not None:
+                self._set_rng_state(prep[5])
+                self.step -= 1
+            prep = None
         local_labels = local_labels.long()
         ready = prep[3] if prep is not None else None
         if ready is None:

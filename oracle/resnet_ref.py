@@ -78,29 +78,55 @@ def _bn(sd, prefix, x, training):
     return y
 
 
-def basic_block(sd, p, x, stride, has_ds, training):
-    y = F.conv2d(x, sd[p + ".conv1.weight"], None, 1, 1)
-    y = F.relu(_bn(sd, p + ".bn1", y, training))
-    y = F.conv2d(y, sd[p + ".conv2.weight"], None, stride, 1)
+class _StorageCast(torch.autograd.Function):
+    """straight-through rounding to a storage dtype: the value AND its gradient pass through that dtype"""
+
+    @staticmethod
+    def forward(ctx, x, dtype):
+        ctx.dtype = dtype
+        return x.to(dtype).float()
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(ctx.dtype).float(), None
+
+
+def storage_cast(dtype):
+    """q for resnet_forward(..., q=): emulates tensors kept in `dtype` (e.g. torch.bfloat16) between fp32-accumulating ops --
+    what a mixed-precision implementation of the same network does by construction.  Isolates the error that comes from the
+    STORAGE precision (which any such implementation has) from the error of a particular kernel."""
+    return lambda t: _StorageCast.apply(t, dtype)
+
+
+def _id(t):
+    return t
+
+
+def basic_block(sd, p, x, stride, has_ds, training, q=_id):
+    y = q(F.conv2d(x, q(sd[p + ".conv1.weight"]), None, 1, 1))
+    y = q(F.relu(_bn(sd, p + ".bn1", y, training)))
+    y = q(F.conv2d(y, q(sd[p + ".conv2.weight"]), None, stride, 1))
     y = _bn(sd, p + ".bn2", y, training)
     if has_ds:
-        r = F.conv2d(x, sd[p + ".downsample.0.weight"], None, stride, 0)
+        r = q(F.conv2d(x, q(sd[p + ".downsample.0.weight"]), None, stride, 0))
         r = _bn(sd, p + ".downsample.1", r, training)
     else:
         r = x
-    return y + r
+    return q(y + r)
 
 
-def resnet_forward(sd, x, blocks, training, emd_size=512):
-    """x float32 [B,3,H,W] -> [B, emd_size]; running stats in `sd` updated in place when training."""
-    y = F.conv2d(x, sd["conv1.weight"], None, 1, 1)
+def resnet_forward(sd, x, blocks, training, emd_size=512, q=_id):
+    """x float32 [B,3,H,W] -> [B, emd_size]; running stats in `sd` updated in place when training.
+    q: storage cast applied where a mixed-precision implementation keeps a tensor (conv outputs, activation outputs, block
+    outputs, weights as GEMM operands); identity = the reference's fp32 arithmetic."""
+    y = F.conv2d(q(x), q(sd["conv1.weight"]), None, 1, 1)
     y = F.relu(_bn(sd, "bn1", y, training))
-    y = F.max_pool2d(y, 3, 2, 1)
+    y = q(F.max_pool2d(y, 3, 2, 1))
     for si, bi, cin, cout, s, ds in stage_plan(blocks, emd_size):
-        y = basic_block(sd, "layer%d.%d" % (si, bi), y, s, ds, training)
-    y = _bn(sd, "bn2", y, training)
+        y = basic_block(sd, "layer%d.%d" % (si, bi), y, s, ds, training, q)
+    y = q(_bn(sd, "bn2", y, training))
     y = y.reshape(y.shape[0], -1)
-    y = F.linear(y, sd["fc.weight"], sd["fc.bias"])
+    y = F.linear(y, q(sd["fc.weight"]), sd["fc.bias"])
     y = _bn(sd, "bn3", y, training)
     return y
 

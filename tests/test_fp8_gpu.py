@@ -140,8 +140,10 @@ def test_alternet50_fp8_training_step_vs_bf16(pg):
         torch.manual_seed(11)
         model = Model(conf, None, "train")
         if sd is None:
-            sd = {k: v.clone() for k, v in model.state_dict().items()}
-        model.load_state_dict(sd)
+            sd = ({k: v.clone() for k, v in model.encoder.state_dict().items()}, model.loss.weight_activated.data.clone())
+        model.encoder.load_state_dict(sd[0], strict=True)
+        with torch.no_grad():
+            model.loss.weight_activated.data.copy_(sd[1])
         for m in model.encoder.modules():                        # deterministic step: no dropout / stochastic depth
             if hasattr(m, "drop_path_rate"):
                 m.drop_path_rate = 0.0

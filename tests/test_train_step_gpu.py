@@ -101,9 +101,10 @@ def test_prepare_optimistic_sampling_falls_back_to_the_reference_branch(pg, dist
         emb = recipe.normal(4102, (16, 512), 1.0).cuda().requires_grad_(True)
         lab = (torch.arange(16) % distinct * 7 + 3).cuda()
         torch.manual_seed(4103)
+        lab_in = lab.clone()                         # prepare() and forward() get the SAME tensor, as Model._step passes it
         if use_prepare:
-            head.prepare(lab, opt)
-        loss = head(emb, lab.clone(), opt)
+            head.prepare(lab_in, opt)
+        loss = head(emb, lab_in, opt)
         loss.backward()
         res.append((float(loss.detach()), head.weight_index.cpu().clone(), emb.grad.cpu().clone(), torch.rand(1).item(), head.step))
     (la, ia, ga, ra, sa), (lb, ib, gb, rb, sb) = res
@@ -112,3 +113,32 @@ def test_prepare_optimistic_sampling_falls_back_to_the_reference_branch(pg, dist
     np.testing.assert_allclose(la, lb, rtol=1e-6)
     np.testing.assert_allclose(ga.numpy(), gb.numpy(), rtol=1e-5, atol=1e-7)
     assert ra == rb                                  # the CPU generator is where the reference would have left it
+
+
+def test_stale_prepare_is_discarded(pg):
+    """A prepare() made for OTHER labels (a step that never ran its forward) must not be applied: forward() recognises it by
+    the label tensor's address, hands the optimistic sampling draw back to the CPU generator and does the label side itself --
+    result and generator state equal a run without that prepare()."""
+    import nets.PartialFC as P
+    torch.cuda.set_device(0)
+    conf = _conf(0.25, "fp32")
+    res = []
+    for stale in (True, False):
+        torch.manual_seed(4200)
+        head = P.PartialFC(conf, 256).cuda()
+        with torch.no_grad():
+            head.weight.copy_(recipe.normal(4201, (256, 512), 0.01).cuda())
+        opt = torch.optim.SGD([{"params": [head.weight_activated]}], lr=0.1, momentum=0.9)
+        emb = recipe.normal(4202, (16, 512), 1.0).cuda().requires_grad_(True)
+        lab = recipe.labels(4203, 16, 256).cuda()
+        other = recipe.labels(4204, 16, 256).cuda()
+        torch.manual_seed(4205)
+        if stale:
+            head.prepare(other, opt)                 # left over: its forward never comes
+        loss = head(emb, lab, opt)
+        loss.backward()
+        res.append((float(loss.detach()), head.weight_index.cpu().clone(), emb.grad.cpu().clone(), torch.rand(1).item(), head.step))
+    (la, ia, ga, ra, sa), (lb, ib, gb, rb, sb) = res
+    assert torch.equal(ia, ib) and sa == sb == 1 and ra == rb
+    np.testing.assert_allclose(la, lb, rtol=1e-6)
+    np.testing.assert_allclose(ga.numpy(), gb.numpy(), rtol=1e-5, atol=1e-7)
