@@ -408,10 +408,13 @@ __global__ __launch_bounds__(TN_THREADS, 2) void tn_lin_kernel(TnGeom g, const v
 #define FRHIP_ABL 0
 #endif
 #ifndef T9_DEPTH
-#define T9_DEPTH 4
+#define T9_DEPTH 6        // window-fragment look-ahead (tools/ablate.py ABL_DEFS sweep, round 2: 4 -> 6 with the stagger below: -3.5 %)
 #endif
 #ifndef T9_PIN
 #define T9_PIN 0
+#endif
+#ifndef T9_STAGGER
+#define T9_STAGGER 8      // experiment: waves 4-7 of the 8-wave tile start every K step T9_STAGGER x 64 clocks late (MI355X_MICROARCH "two waves per SIMD", item 9)
 #endif
 constexpr int T9_MAXW = 56;
 constexpr int T9_QROWS = 192;                               // 24 pieces of 8 rows >= 64 + 2*56 + 2
@@ -540,6 +543,12 @@ void tn_taps9_kernel(TnGeom g, const void* __restrict__ p_ptr, const void* __res
 
     auto compute = [&](auto buf_c) {
         typedef std::integral_constant<int, decltype(buf_c)::value * Cfg::STAGE> Off;
+        if constexpr (T9_STAGGER > 0 && Cfg::NW == 8) {
+            if (wave >= 4) {
+#pragma unroll
+                for (int z = 0; z < T9_STAGGER; ++z) __builtin_amdgcn_s_sleep(1);
+            }
+        }
         // rows past M need no mask: their dy rows were zero-filled and every window row read is finite data or zero
         bool up[4], dn[4], lf[4], rt[4];
 #pragma unroll
@@ -644,7 +653,33 @@ void tn_taps9_kernel(TnGeom g, const void* __restrict__ p_ptr, const void* __res
             return;
         }
     }
-    float* dst = out + (g.slab_stride ? (size_t)slot.split * g.slab_stride : 0);
+    if (g.slab_stride) {
+        // Private slab of this K split, in a layout made for the WRITER: [co / 4][j = 0..8][ci][4 floats], where the 36 values a
+        // lane holds for four consecutive output channels (e) and the nine taps (t) are numbered k = 9 e + t = 4 j + r.  A lane
+        // then issues nine 16-byte stores per accumulator group instead of thirty-six 4-byte ones, sixteen lanes cover 256
+        // contiguous bytes, and the final reduce pass (slab9_final_kernel) converts to dw[co][tap][ci] while it sums the splits.
+        float* dst = out + (size_t)slot.split * g.slab_stride;
+#pragma unroll
+        for (int a = 0; a < COF; ++a) {
+            const int q = (co0 + wco * COF * 16 + a * 16 + 4 * fg) >> 2;           // co / 4 of this lane's four rows
+            if (q * 4 >= g.Kc) continue;
+#pragma unroll
+            for (int b = 0; b < CIF; ++b) {
+                const int ci = ci0 + wci * CIF * 16 + b * 16 + fi;
+                if (ci >= g.C) continue;
+#pragma unroll
+                for (int j = 0; j < 9; ++j) {
+                    f32x4_t v;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { const int k = 4 * j + r; v[r] = acc[k % 9][a][b][k / 9]; }
+                    float* p = dst + (((size_t)q * 9 + j) * g.C + ci) * 4;
+                    if constexpr (TN_SLAB_NT & 1) __builtin_nontemporal_store(v, reinterpret_cast<f32x4_t*>(p));
+                    else *reinterpret_cast<f32x4_t*>(p) = v;
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int a = 0; a < COF; ++a)
 #pragma unroll
@@ -656,11 +691,7 @@ void tn_taps9_kernel(TnGeom g, const void* __restrict__ p_ptr, const void* __res
                 const int ci = ci0 + wci * CIF * 16 + b * 16 + fi;
                 if (ci >= g.C) continue;
 #pragma unroll
-                for (int t = 0; t < 9; ++t) {
-                    const size_t idx = ((size_t)co * 9 + t) * g.C + ci;
-                    if (g.slab_stride) { if constexpr (TN_SLAB_NT & 1) __builtin_nontemporal_store(acc[t][a][b][e], dst + idx); else dst[idx] = acc[t][a][b][e]; }
-                    else atomicAdd(dst + idx, acc[t][a][b][e]);
-                }
+                for (int t = 0; t < 9; ++t) atomicAdd(out + ((size_t)co * 9 + t) * g.C + ci, acc[t][a][b][e]);
             }
         }
 }
@@ -712,6 +743,36 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(float* __restrict__ sl
             reinterpret_cast<f32x4_t*>(out)[i] = acc;
         } else {
             *reinterpret_cast<f32x4_t*>(slabs + (size_t)s0 * step + i * 4) = acc;
+        }
+    }
+}
+
+// Final level of the nine-tap split-K reduction: sums `count` slabs in the writer's layout ([co/4][j][ci][4], k = 4 j + r = 9 e + t)
+// and ADDS the result to dw[co][tap][ci].  One thread per (co/4, j, ci) float4; lanes = consecutive ci, so slab reads are
+// 16 bytes per lane contiguous and the four output writes of a lane are each coalesced over the wave.
+__global__ __launch_bounds__(256) void slab9_final_kernel(const float* __restrict__ slabs, int count, size_t step,
+                                                          float* __restrict__ out, int kc4, int C) {
+    const size_t n4 = (size_t)kc4 * 9 * C;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        f32x4_t a0 = f32x4_t{0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
+        int sp = 0;
+        for (; sp + 4 <= count; sp += 4) {
+            const f32x4_t v0 = slab_load(slabs + (size_t)(sp + 0) * step + i * 4);
+            const f32x4_t v1 = slab_load(slabs + (size_t)(sp + 1) * step + i * 4);
+            const f32x4_t v2 = slab_load(slabs + (size_t)(sp + 2) * step + i * 4);
+            const f32x4_t v3 = slab_load(slabs + (size_t)(sp + 3) * step + i * 4);
+            a0 += v0; a1 += v1; a2 += v2; a3 += v3;
+        }
+        for (; sp < count; ++sp) a0 += *reinterpret_cast<const f32x4_t*>(slabs + (size_t)sp * step + i * 4);
+        const f32x4_t acc = (a0 + a1) + (a2 + a3);
+        const int ci = (int)(i % (size_t)C);
+        const size_t qj = i / (size_t)C;
+        const int j = (int)(qj % 9), q = (int)(qj / 9);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int k = 4 * j + r, e = k / 9, t = k - 9 * e;
+            float* o = out + ((size_t)(4 * q + e) * 9 + t) * C + ci;
+            *o += acc[r];
         }
     }
 }
@@ -789,6 +850,26 @@ static int tn_finish(const TnGeom& g, float* out, int splits, size_t out_elems, 
     return check_launch("igemm_tn(slab reduce)");
 }
 
+// nine-tap kernel: its slabs are in the writer's layout (see tn_taps9_kernel); groups of slabs are pre-summed in that layout
+// by the generic kernel, the final level converts to dw[co][tap][ci]
+static int t9_finish(const TnGeom& g, float* out, int splits, size_t out_elems, float* ws, hipStream_t stream) {
+    if (!g.slab_stride) return FRHIP_OK;
+    const size_t n4 = out_elems / 4;
+    int blocks = (int)((n4 + 255) / 256); if (blocks > 2048) blocks = 2048;
+    int groups = 1;
+    while (splits > 32 * groups && blocks * groups < 512) groups *= 2;
+    int count = splits; size_t step = out_elems;
+    if (groups > 1) {
+        const int per_group = (splits + groups - 1) / groups;
+        groups = (splits + per_group - 1) / per_group;
+        hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks, groups), dim3(256), 0, stream, ws, splits, per_group,
+                           out_elems, (float*)nullptr, n4, 0);
+        count = groups; step = (size_t)per_group * out_elems;
+    }
+    hipLaunchKernelGGL(slab9_final_kernel, dim3(blocks), dim3(256), 0, stream, ws, count, step, out, g.Kc / 4, g.C);
+    return check_launch("igemm_tn(nine-tap slab reduce)");
+}
+
 static int tn_run(int dtype, const void* p, const void* q, float* out, int n, int h, int w, int c, int kc, int ldp,
                   int r, int s, int stride, int pad, int splits, float* ws, size_t ws_bytes, hipStream_t stream,
                   const char* who, bool overwrite = false) {
@@ -835,10 +916,10 @@ static int tn_run(int dtype, const void* p, const void* q, float* out, int n, in
         if (splits > g.ksteps) splits = g.ksteps;
         g.ksteps_per_split = (g.ksteps + splits - 1) / splits;
         splits = (g.ksteps + g.ksteps_per_split - 1) / g.ksteps_per_split;
-        float* dst = tn_pick_dst(g, out, splits, out_elems, ws, ws_bytes);
+        float* dst = (kc % 4 == 0) ? tn_pick_dst(g, out, splits, out_elems, ws, ws_bytes) : out;      // slab layout packs co in fours
         rc = wide ? tn_taps9_launch<2, 4, 4, 1>(g, p, q, dst, splits, stream)
                   : tn_taps9_launch<1, 4, 4, 1>(g, p, q, dst, splits, stream);
-        return rc ? rc : tn_finish(g, out, splits, out_elems, ws, stream);
+        return rc ? rc : t9_finish(g, out, splits, out_elems, ws, stream);
     }
     const bool big = (c * es >= 256) && (kc * es >= 256);
     if (splits <= 0) {
