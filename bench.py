@@ -70,7 +70,17 @@ class ConvMeter:
                                    2.0 * n * ho * wo * k * r * s * x_shape[3]))    # algorithmic MACs = forward's
             return self._dgrad(dy, wt, x_shape, r, s, stride, pad, residual, out, bnred, residual_stride)
 
-        ops.conv_fwd, ops.conv_dgrad = conv_fwd, conv_dgrad
+        self._fwdx = ops.conv_fwd_bnrelu
+
+        def conv_fwd_bnrelu(x, st, w, stride, pad, want_stats=True):
+            if self.collect and x.dtype == torch.bfloat16:
+                n, h, wd, c = x.shape
+                k, r, s, _ = w.shape
+                ho, wo = ops.conv_out_hw(h, wd, r, s, stride, pad)
+                self.calls.append((self._fwdx, (x, st, w, stride, pad, want_stats), 2.0 * n * ho * wo * k * r * s * c))
+            return self._fwdx(x, st, w, stride, pad, want_stats)
+
+        ops.conv_fwd, ops.conv_dgrad, ops.conv_fwd_bnrelu = conv_fwd, conv_dgrad, conv_fwd_bnrelu
 
     def measure(self, repeats=3):
         torch.cuda.synchronize()
@@ -120,6 +130,20 @@ class ConvMeter:
             self.instep.append((a, b, 2.0 * n * ho * wo * k * r * s * x_shape[3]))
             return res
 
+        fwdx = self._fwdx
+
+        def conv_fwd_bnrelu(x, st, w, stride, pad, want_stats=True):
+            n, h, wd, c = x.shape
+            k, r, s, _ = w.shape
+            ho, wo = ops.conv_out_hw(h, wd, r, s, stride, pad)
+            a, b = ev(), ev()
+            a.record()
+            out = fwdx(x, st, w, stride, pad, want_stats)
+            b.record()
+            self.instep.append((a, b, 2.0 * n * ho * wo * k * r * s * c))
+            return out
+
+        ops.conv_fwd_bnrelu = conv_fwd_bnrelu
         f8 = ops.conv_fwd_fp8
         self._f8, self.instep8 = f8, []
 
@@ -143,7 +167,7 @@ class ConvMeter:
 
     def stop_instep(self):
         """-> (launches, summed kernel ms, algorithmic FLOP) over everything recorded since start_instep()"""
-        self.ops.conv_fwd, self.ops.conv_dgrad, self.ops.conv_fwd_fp8 = self._fwd, self._dgrad, self._f8
+        self.ops.conv_fwd, self.ops.conv_dgrad, self.ops.conv_fwd_fp8, self.ops.conv_fwd_bnrelu = self._fwd, self._dgrad, self._f8, self._fwdx
         torch.cuda.synchronize()
         ms = sum(a.elapsed_time(b) for a, b, _ in self.instep)
         return len(self.instep), ms, sum(f for _, _, f in self.instep)

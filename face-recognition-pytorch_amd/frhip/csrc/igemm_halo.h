@@ -34,6 +34,11 @@ struct HaloGeom {
     int m_origin;           // first output pixel of m-tile 0 of THIS launch (tail launches start behind the full tiles)
     int stat_row0;          // row of the BN-partial buffer that m-tile 0 of this launch writes
     uint32_t a_bytes, b_bytes;
+    // operand transform (XF kernels only): the gathered tensor is the INPUT of a BatchNorm + ReLU and the convolution wants
+    // their output -- a = relu(x * xf_scale[c] + xf_shift[c]) is formed in LDS, per 64-channel chunk, right after the window
+    // has landed; the activated tensor never exists in HBM (nets/resnet.py:91-93: bn1 -> relu -> conv2)
+    const float* xf_scale;
+    const float* xf_shift;
 };
 
 template <typename T, int WM, int WN, int MT, int HBUFS>
@@ -59,8 +64,9 @@ struct HaloTile {
     }
 };
 
-template <typename T, int WM, int WN, int MT, int HBUFS>
+template <typename T, int WM, int WN, int MT, int HBUFS, bool XF = false>
 struct HaloMainloop {
+    static_assert(!XF || (HBUFS == 1 && std::is_same<T, bf16_t>::value), "operand transform: single-buffer bf16 tile only");
     typedef HaloTile<T, WM, WN, MT, HBUFS> Tile;
     typedef typename Mma<T>::Frag Frag;
     static constexpr int BM = Tile::BM, BN = Tile::BN, BKE = Tile::BKE;
@@ -92,6 +98,28 @@ struct HaloMainloop {
             const int p = p_lo + r;
             const uint32_t off = (p >= 0 && p < g.M) ? (uint32_t)(p * g.C + c0) * (uint32_t)sizeof(T) + chunk_bytes : OOB_OFFSET;
             glds16<HALO_A_AUX>(ra, smem + hb * Tile::HALO_BYTES + piece * 1024, off);
+        };
+        // XF: BatchNorm + ReLU of the pieces THIS wave loaded (after its own vmcnt(0), before the barrier that publishes them).
+        // Rows outside the tensor were zero-filled by the DMA and stay zero: the convolution pads the ACTIVATED tensor.
+        // Same expression and rounding as bn_apply_kernel, so the result is bit-identical to the materialised tensor.
+        auto xform_chunk = [&](int c0) {
+            if constexpr (XF) {
+                const int lc = (lane & 7) ^ sub;                     // logical 16-byte chunk this lane holds of its row
+                float sc[8], sh[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { sc[e] = g.xf_scale[c0 + 8 * lc + e]; sh[e] = g.xf_shift[c0 + 8 * lc + e]; }
+                for (int piece = wave; piece < npieces; piece += Tile::WAVES) {
+                    const int p = p_lo + piece * 8 + sub;
+                    if (p >= 0 && p < g.M) {
+                        bf16x8_t* a = reinterpret_cast<bf16x8_t*>(smem + piece * 1024 + lane * 16);
+                        bf16x8_t v = *a;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) { const float o = (float)v[e] * sc[e] + sh[e]; v[e] = (bf16_t)fmaxf(o, 0.f); }
+                        *a = v;
+                    }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
         };
         uint32_t brow_off[Tile::B_PIECES];
 #pragma unroll
@@ -220,6 +248,7 @@ struct HaloMainloop {
         weights(0);
         weights(1);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        xform_chunk(0);
         __syncthreads();
         load_frags(I0{}, I0{}, I0{}, I0{}, I0{});
 
@@ -269,6 +298,7 @@ struct HaloMainloop {
                 __builtin_amdgcn_s_barrier();
                 for (int piece = wave; piece < npieces; piece += Tile::WAVES) halo_piece(0, piece, c0 + BKE);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                xform_chunk(c0 + BKE);
                 __builtin_amdgcn_s_barrier();
                 load_frags(I0{}, I0{}, I0{}, I0{}, I0{});
             }

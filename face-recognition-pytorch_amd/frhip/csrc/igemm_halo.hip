@@ -6,7 +6,7 @@
 
 namespace frhip {
 
-template <typename T, int WM, int WN, int MT, int HBUFS>
+template <typename T, int WM, int WN, int MT, int HBUFS, bool XF = false>
 __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void halo_kernel(HaloGeom g, const void* __restrict__ a,
                                                                          const void* __restrict__ b, void* __restrict__ out,
                                                                          const void* __restrict__ res, float* __restrict__ stats,
@@ -15,7 +15,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void halo_kernel(HaloG
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const uint32_t lin = xcd_remap(blockIdx.x, gridDim.x);
     const int ntile = (int)(lin % (uint32_t)ntiles), mtile = (int)(lin / (uint32_t)ntiles);
-    HaloMainloop<T, WM, WN, MT, HBUFS> ml;
+    HaloMainloop<T, WM, WN, MT, HBUFS, XF> ml;
     ml.run(g, a, b, smem, mtile, ntile);
     if constexpr (FRHIP_ABL & 16) {
         if (g.M >= 0) {
@@ -63,13 +63,13 @@ static HaloPlan halo_plan(int M, int ntiles, int slots, bool allow_tail) {
     return p;
 }
 
-template <typename T, int WM, int WN, int MT, int HBUFS>
+template <typename T, int WM, int WN, int MT, int HBUFS, bool XF = false>
 static int halo_launch_one(HaloGeom g, const void* a, const void* b, void* out, const void* res, float* stats,
                            const EpiBnRed& br, int mtiles, int m_origin, int stat_row0, hipStream_t stream) {
     typedef HaloTile<T, WM, WN, MT, HBUFS> Tile;
     const int ntiles = (g.Nout + Tile::BN - 1) / Tile::BN;
     const int lds = Tile::template lds_bytes<T>();
-    auto kern = halo_kernel<T, WM, WN, MT, HBUFS>;
+    auto kern = halo_kernel<T, WM, WN, MT, HBUFS, XF>;
     static bool attr_done = false;
     if (!attr_done) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
@@ -141,8 +141,13 @@ int halo_stat_rows(int dtype, int m, int c, int k) {
 }
 
 // a: activations [n,h,w,c] (forward: x, data-gradient: dy), b: [k][3][3][c] K-contiguous pack, out [n,h,w,k]
+// bn1 -> relu -> conv2 with the BatchNorm-apply + ReLU folded into the operand path: bf16, the 4-wave single-buffer tile only
+bool halo_xf_applicable(int dtype, int h, int w, int c, int k, int r, int s, int stride, int pad) {
+    return dtype == FRHIP_DT_BF16 && halo_applicable(dtype, h, w, c, k, r, s, stride, pad) && halo_config(dtype, c, k) == 0;
+}
+
 int halo_run(int dtype, const void* a, const void* b, void* out, const void* res, float* stats, const EpiBnRed& br,
-             int n, int h, int w, int c, int k, int sign, hipStream_t stream) {
+             int n, int h, int w, int c, int k, int sign, hipStream_t stream, const float* xf_scale, const float* xf_shift) {
     const int es = dtype == FRHIP_DT_BF16 ? 2 : 4;
     const long long ab = 1LL * n * h * w * c * es, bb = 1LL * k * 9 * c * es;
     if (ab > 0x7fffffffLL || bb > 0x7fffffffLL) { set_error("igemm_halo: tensor exceeds the 2 GiB buffer window"); return FRHIP_EINVAL; }
@@ -150,7 +155,12 @@ int halo_run(int dtype, const void* a, const void* b, void* out, const void* res
     g.H = h; g.W = w; g.C = c; g.M = n * h * w; g.Nout = k; g.Ktot = 9 * c; g.sign = sign;
     g.m_origin = 0; g.stat_row0 = 0;
     g.a_bytes = (uint32_t)ab; g.b_bytes = (uint32_t)bb;
+    g.xf_scale = xf_scale; g.xf_shift = xf_shift;
     const int cfg = halo_config(dtype, c, k);
+    if (xf_scale) {
+        if (dtype != FRHIP_DT_BF16 || cfg != 0 || g_halo_tail) { set_error("igemm_halo: operand transform not available for this shape"); return FRHIP_EINVAL; }
+        return halo_launch_one<bf16_t, 4, 1, 4, 1, true>(g, a, b, out, res, stats, br, (g.M + 255) / 256, 0, 0, stream);
+    }
     if (dtype == FRHIP_DT_BF16) {
         if (cfg == 0) return halo_launch<bf16_t, 4, 1, 1, 2>(g, a, b, out, res, stats, br, stream);
         if (cfg == 1) return halo_launch_one<bf16_t, 8, 1, 2, 2>(g, a, b, out, res, stats, br, (g.M + 255) / 256, 0, 0, stream);

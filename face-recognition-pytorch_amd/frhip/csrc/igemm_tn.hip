@@ -42,6 +42,10 @@ struct TnGeom {
     int slab_stride;             // 0: add into `out` with fp32 atomics; > 0: each K split stores its tiles into out + split*slab_stride
     int adv_wo, adv_ho, adv_n;   // 64 pixels = adv_n images + adv_ho rows + adv_wo columns (mixed-radix step per K step)
     uint32_t p_bytes, q_bytes;
+    // operand transform of the nine-tap kernel (XF instantiations): Q is the INPUT of a BatchNorm + ReLU and the weight
+    // gradient wants their output; relu(q * xf_scale[ci] + xf_shift[ci]) is formed in LDS after every window stage has landed
+    const float* xf_scale;
+    const float* xf_shift;
 };
 
 constexpr int TN_THREADS = 256;
@@ -438,7 +442,7 @@ struct T9Cfg {
     static_assert(2 * STAGE <= 65536 + STAGE && STAGE < 65536, "stage base must fit the 16-bit DS offset field");
 };
 
-template <int WCO, int WCI, int COF, int CIF>
+template <int WCO, int WCI, int COF, int CIF, bool XF = false>
 __global__ __launch_bounds__(64 * WCO * WCI, (WCO * WCI > 4 ? 1 : 2))
 void tn_taps9_kernel(TnGeom g, const void* __restrict__ p_ptr, const void* __restrict__ q_ptr, float* __restrict__ out,
                      int co_tiles, int ci_tiles) {
@@ -499,6 +503,38 @@ void tn_taps9_kernel(TnGeom g, const void* __restrict__ p_ptr, const void* __res
         for (int j = 0; j < Cfg::QPW_MAX; ++j) {
             if (j < qpw) glds16<T9_AUX>(rq, sq + (wave + Cfg::NW * j) * 1024, okq[j] ? offq[j] : OOB_OFFSET);
             offq[j] += incq;
+        }
+    };
+
+    // XF: BatchNorm + ReLU of the window pieces THIS wave loaded into stage `buf` for K step `ks` (called after the wave's own
+    // vmcnt(0), before the barrier that publishes the stage).  A lane's logical 16-byte chunk of a window row depends on the
+    // row's swizzle bits 1 and 3 only -- bit 1 of (lane >> 3) and bit 0 of the wave -- so it is the same for every piece and the
+    // lane's eight (scale, shift) pairs are loaded once.  Rows outside the tensor stay zero (the conv pads the ACTIVATED tensor).
+    float xsc[8], xsh[8];
+    if constexpr (XF) {
+        const int row0 = wave * 8 + (lane >> 3);
+        const int ce = ((lane & 7) ^ tn_swz<128>(row0)) * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { xsc[e] = g.xf_scale[ci0 + ce + e]; xsh[e] = g.xf_shift[ci0 + ce + e]; }
+    }
+    auto xform_stage = [&](int buf, int ks) {
+        if constexpr (XF) {
+            char* sq = smem + buf * Cfg::STAGE + Cfg::P_BYTES;
+#pragma unroll
+            for (int j = 0; j < Cfg::QPW_MAX; ++j) {
+                if (j < qpw) {
+                    const int row = (wave + Cfg::NW * j) * 8 + (lane >> 3);
+                    const long long pix = (long long)ks * TN_KP - g.W - 1 + row;
+                    if (pix >= 0 && pix < (long long)g.M) {
+                        bf16x8_t* a = reinterpret_cast<bf16x8_t*>(sq + (wave + Cfg::NW * j) * 1024 + lane * 16);
+                        bf16x8_t v = *a;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) { const float o = (float)v[e] * xsc[e] + xsh[e]; v[e] = (bf16_t)fmaxf(o, 0.f); }
+                        *a = v;
+                    }
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
     };
 
@@ -623,6 +659,7 @@ void tn_taps9_kernel(TnGeom g, const void* __restrict__ p_ptr, const void* __res
         const int nks = ks_end - ks_begin;
         stage(0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        xform_stage(0, ks_begin);
         __syncthreads();
         auto step = [&](auto buf_c, int it) {
             constexpr int BUF = decltype(buf_c)::value;
@@ -630,6 +667,7 @@ void tn_taps9_kernel(TnGeom g, const void* __restrict__ p_ptr, const void* __res
             compute(buf_c);
             if (it + 1 < nks) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                xform_stage(BUF ^ 1, ks_begin + it + 1);
                 if constexpr (!(FRHIP_ABL & 1)) __builtin_amdgcn_s_barrier();
             }
         };
@@ -698,11 +736,11 @@ void tn_taps9_kernel(TnGeom g, const void* __restrict__ p_ptr, const void* __res
 
 static int g_tn_taps9 = 1;
 
-template <int WCO, int WCI, int COF, int CIF>
+template <int WCO, int WCI, int COF, int CIF, bool XF = false>
 static int tn_taps9_launch(const TnGeom& g, const void* p, const void* q, float* out, int splits, hipStream_t stream) {
     typedef T9Cfg<WCO, WCI, COF, CIF> Cfg;
     const int co_tiles = (g.Kc + Cfg::CO_T - 1) / Cfg::CO_T, ci_tiles = (g.C + 63) / 64;
-    auto kern = tn_taps9_kernel<WCO, WCI, COF, CIF>;
+    auto kern = tn_taps9_kernel<WCO, WCI, COF, CIF, XF>;
     static bool attr_done = false;
     if (!attr_done) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS) != hipSuccess) {
@@ -870,9 +908,15 @@ static int t9_finish(const TnGeom& g, float* out, int splits, size_t out_elems, 
     return check_launch("igemm_tn(nine-tap slab reduce)");
 }
 
+static bool t9_applicable(int dtype, int w, int c, int r, int s, int stride, int pad, long long M, int ldp) {
+    const int es = 2;
+    return g_tn_taps9 && dtype == FRHIP_DT_BF16 && r == 3 && s == 3 && stride == 1 && pad == 1 && w <= T9_MAXW &&
+           1LL * (M + 64 + 2LL * w + 2) * (ldp > c ? ldp : c) * es < 0x7fffffffLL;
+}
+
 static int tn_run(int dtype, const void* p, const void* q, float* out, int n, int h, int w, int c, int kc, int ldp,
                   int r, int s, int stride, int pad, int splits, float* ws, size_t ws_bytes, hipStream_t stream,
-                  const char* who, bool overwrite = false) {
+                  const char* who, bool overwrite = false, const float* xf_scale = nullptr, const float* xf_shift = nullptr) {
     const int es = dtype == FRHIP_DT_BF16 ? 2 : 4;
     if (dtype != FRHIP_DT_BF16 && dtype != FRHIP_DT_F32) { set_error("%s: bad dtype %d", who, dtype); return FRHIP_EINVAL; }
     const int epv = 16 / es;
@@ -894,13 +938,17 @@ static int tn_run(int dtype, const void* p, const void* q, float* out, int n, in
     g.adv_wo = TN_KP % g.Wo;
     g.ksteps = (g.M + TN_KP - 1) / TN_KP;
     g.slab_stride = 0;
+    g.xf_scale = xf_scale; g.xf_shift = xf_shift;
+    if (xf_scale && !(t9_applicable(dtype, w, c, r, s, stride, pad, M, ldp) && (c % 64) == 0)) {
+        set_error("%s: operand transform needs the nine-tap kernel (bf16 3x3 stride 1, c %% 64 == 0)", who);
+        return FRHIP_EINVAL;
+    }
     const int taps = r * s;
     const size_t out_elems = (size_t)kc * taps * c;
     if (out_elems > 0x7fffffffULL) { set_error("%s: output too large", who); return FRHIP_EINVAL; }
     int rc;
     // The nine-tap kernel covers every 3x3/s1/p1 bf16 layer (g_tn_taps9: 0 off, 1/2 on); wide = 128-co tiles.
-    if (g_tn_taps9 && dtype == FRHIP_DT_BF16 && r == 3 && s == 3 && stride == 1 && pad == 1 && w <= T9_MAXW &&
-        1LL * (M + 64 + 2LL * w + 2) * (ldp > c ? ldp : c) * es < 0x7fffffffLL) {
+    if (t9_applicable(dtype, w, c, r, s, stride, pad, M, ldp)) {
         const bool wide = kc > 64;
         const int co_t = wide ? 128 : 64;
         const long long tiles = 1LL * ((kc + co_t - 1) / co_t) * ((c + 63) / 64);
@@ -917,8 +965,10 @@ static int tn_run(int dtype, const void* p, const void* q, float* out, int n, in
         g.ksteps_per_split = (g.ksteps + splits - 1) / splits;
         splits = (g.ksteps + g.ksteps_per_split - 1) / g.ksteps_per_split;
         float* dst = (kc % 4 == 0) ? tn_pick_dst(g, out, splits, out_elems, ws, ws_bytes) : out;      // slab layout packs co in fours
-        rc = wide ? tn_taps9_launch<2, 4, 4, 1>(g, p, q, dst, splits, stream)
-                  : tn_taps9_launch<1, 4, 4, 1>(g, p, q, dst, splits, stream);
+        if (xf_scale) rc = wide ? tn_taps9_launch<2, 4, 4, 1, true>(g, p, q, dst, splits, stream)
+                                : tn_taps9_launch<1, 4, 4, 1, true>(g, p, q, dst, splits, stream);
+        else rc = wide ? tn_taps9_launch<2, 4, 4, 1>(g, p, q, dst, splits, stream)
+                       : tn_taps9_launch<1, 4, 4, 1>(g, p, q, dst, splits, stream);
         return rc ? rc : t9_finish(g, out, splits, out_elems, ws, stream);
     }
     const bool big = (c * es >= 256) && (kc * es >= 256);
@@ -1000,4 +1050,18 @@ extern "C" int frhip_gemm_tn(int dtype, const void* p, const void* q, float* out
     // out[kc][c] (fp32, caller-zeroed) += sum_m p[m][0..kc) (pitch ldp) * q[m][0..c)
     return tn_run(dtype, p, q, out, m, 1, 1, c, kc, ldp, 1, 1, 1, 0, splits, workspace, workspace_bytes, stream,
                   "frhip_gemm_tn");
+}
+
+extern "C" int frhip_conv_wgrad_bnrelu_fusable(int dtype, int n, int h, int w, int c, int k, int r, int s, int stride, int pad) {
+    return (frhip::t9_applicable(dtype, w, c, r, s, stride, pad, 1LL * n * h * w, k) && (c % 64) == 0) ? 1 : 0;
+}
+
+extern "C" int frhip_conv_wgrad_bnrelu(int dtype, const void* dy, const void* x, const float* in_scale, const float* in_shift,
+                                       float* dw, int n, int h, int w, int c, int k, int r, int s, int stride, int pad, int splits,
+                                       float* workspace, size_t workspace_bytes, hipStream_t stream) {
+    // dw += wgrad(dy, relu(x * in_scale[c] + in_shift[c])): weight gradient of the convolution behind a BatchNorm + ReLU whose
+    // output was never materialised (frhip_conv_fwd_bnrelu); the activation is re-formed in LDS from the saved BatchNorm input
+    if (!in_scale || !in_shift) { frhip::set_error("frhip_conv_wgrad_bnrelu: scale / shift required"); return FRHIP_EINVAL; }
+    return tn_run(dtype, dy, x, dw, n, h, w, c, k, k, r, s, stride, pad, splits, workspace, workspace_bytes, stream,
+                  "frhip_conv_wgrad_bnrelu", false, in_scale, in_shift);
 }

@@ -85,6 +85,38 @@ def conv_dgrad(dy, wt, x_shape, r, s, stride, pad, residual=None, out=None, bnre
     return dx if bnred is None else (dx, part)
 
 
+_FUSABLE = {}
+
+
+def conv_bnrelu_fusable(x, w, stride, pad):
+    """can conv(relu(bn(x)), w) run with the BatchNorm-apply + ReLU folded into the operand path (forward AND weight gradient)?"""
+    n, h, wd, c = x.shape
+    k, r, s, _ = w.shape
+    key = (x.dtype, n, h, wd, c, k, r, s, stride, pad)
+    hit = _FUSABLE.get(key)
+    if hit is None:
+        hit = _FUSABLE[key] = x.dtype in _DT and \
+            bool(lib().frhip_conv_bnrelu_fusable(dt_of(x), h, wd, c, k, r, s, stride, pad)) and \
+            bool(lib().frhip_conv_wgrad_bnrelu_fusable(dt_of(x), n, h, wd, c, k, r, s, stride, pad))
+    return hit
+
+
+def conv_fwd_bnrelu(x, st, w, stride, pad, want_stats=True):
+    """y = conv(relu(x * st.scale + st.shift), w) without materialising the activated tensor (x = the BatchNorm's input)"""
+    n, h, wd, c = x.shape
+    k, r, s, c2 = w.shape
+    assert c == c2 and x.dtype == w.dtype
+    ho, wo = conv_out_hw(h, wd, r, s, stride, pad)
+    y = torch.empty((n, ho, wo, k), dtype=x.dtype, device=x.device)
+    part = None
+    if want_stats:
+        rows = lib().frhip_conv_stat_rows(dt_of(x), n * ho * wo, k, h, wd, c, r, s, stride, pad)
+        part = torch.empty((rows, 2, k), dtype=torch.float32, device=x.device)
+    check(lib().frhip_conv_fwd_bnrelu(dt_of(x), _p(x), _p(st.scale), _p(st.shift), _p(w), _p(y), _p(part), n, h, wd, c, k, r, s,
+                                      stride, pad, _s()), "frhip_conv_fwd_bnrelu")
+    return y, part
+
+
 _WORKSPACES = {}
 WORKSPACE_BYTES = 160 << 20
 
@@ -105,6 +137,16 @@ def conv_wgrad(dy, x, dw, r, s, stride, pad, splits=0):
     ws = workspace(x.device)
     check(lib().frhip_conv_wgrad(dt_of(x), _p(dy), _p(x), _p(dw), n, h, wd, c, k, r, s, stride, pad, splits,
                                  _p(ws), ws.numel() * 4, _s()), "frhip_conv_wgrad")
+    return dw
+
+
+def conv_wgrad_bnrelu(dy, x, st, dw, r, s, stride, pad, splits=0):
+    """dw += wgrad(dy, relu(x * st.scale + st.shift)): x is the saved BatchNorm input, the activation is re-formed in LDS"""
+    n, h, wd, c = x.shape
+    k = dy.shape[3]
+    ws = workspace(x.device)
+    check(lib().frhip_conv_wgrad_bnrelu(dt_of(x), _p(dy), _p(x), _p(st.scale), _p(st.shift), _p(dw), n, h, wd, c, k, r, s, stride, pad,
+                                        splits, _p(ws), ws.numel() * 4, _s()), "frhip_conv_wgrad_bnrelu")
     return dw
 
 

@@ -13,6 +13,7 @@ from frhip import ops
 
 _OVERLAP_WGRAD = os.environ.get("FRHIP_OVERLAP_WGRAD", "1") == "1"
 _STEM_FUSED_REDUCE = os.environ.get("FRHIP_STEM_FUSED_REDUCE", "1") == "1"     # 0: the stem's own recompute reduction pass
+_FUSE_BN1 = os.environ.get("FRHIP_FUSE_BN1", "1") == "1"       # bn1-apply + ReLU folded into conv2's operand path (0: separate bn_apply pass)
 _DTYPES = {"bf16": torch.bfloat16, "bfloat16": torch.bfloat16, "fp32": torch.float32, "float32": torch.float32}
 
 
@@ -181,8 +182,13 @@ class BackwardCtx:
         with torch.cuda.stream(self.side):
             fn()
 
-    def wgrad(self, dy, x, gview, r, s, stride, pad):
-        self.on_side(lambda: ops.conv_wgrad(dy, x, gview, r, s, stride, pad), dy, x, gview)
+    def wgrad(self, dy, x, gview, r, s, stride, pad, bnrelu=None):
+        """bnrelu = BN state: x is the INPUT of a BatchNorm + ReLU whose output (the convolution's real operand) was never
+        materialised; the weight-gradient kernel re-forms it in LDS"""
+        if bnrelu is not None:
+            self.on_side(lambda: ops.conv_wgrad_bnrelu(dy, x, bnrelu, gview, r, s, stride, pad), dy, x, gview, bnrelu)
+        else:
+            self.on_side(lambda: ops.conv_wgrad(dy, x, gview, r, s, stride, pad), dy, x, gview)
 
     def _reduce(self, lo, hi):
         if hi <= lo:
@@ -412,6 +418,10 @@ def basic_block_forward(blk, xin, dt, training, save, wprep=None, q8=None):
     if f1:
         a1, a18 = ops.bn_apply_q8(y1, st1, relu=True)
         y2, p2 = ops.conv_fwd_fp8(a18, *q8.packs[blk.conv2], blk.stride, 1, want_stats=training)
+    elif _FUSE_BN1 and ops.conv_bnrelu_fusable(y1, w2, blk.stride, 1):
+        # a1 = relu(bn1(y1)) is never written: conv2 (and, in the backward pass, its weight gradient) form it in LDS from y1
+        a1 = None
+        y2, p2 = ops.conv_fwd_bnrelu(y1, st1, w2, blk.stride, 1, want_stats=training)
     else:
         a1 = ops.bn_apply(y1, st1, relu=True)
         y2, p2 = ops.conv_fwd(a1, w2, blk.stride, 1, want_stats=training)
@@ -460,8 +470,11 @@ def basic_block_backward(blk, s, dout, dt, bc, part2=None, next_bn=None):
         bc.wgrad(dyd, s.x, phys_grad(G(dconv.weight)), 1, 1, dconv.stride, 0)
     w2t = s.w2t if getattr(s, "w2t", None) is not None else ops.pack_wt(blk.conv2.physical(), dt)
     # the BN1 (+ReLU) backward reduction over (da1, y1) rides in the epilogue of conv2's data-gradient
-    da1, part1 = ops.conv_dgrad(dy2, w2t, s.a1.shape, 3, 3, blk.stride, 1, bnred=(s.y1, s.st1, True))
-    bc.wgrad(dy2, s.a1, phys_grad(G(blk.conv2.weight)), 3, 3, blk.stride, 1)
+    da1, part1 = ops.conv_dgrad(dy2, w2t, s.y1.shape, 3, 3, blk.stride, 1, bnred=(s.y1, s.st1, True))
+    if s.a1 is None:        # bn1 + ReLU were folded into conv2's operand path: the weight gradient re-forms a1 from y1 as well
+        bc.wgrad(dy2, s.y1, phys_grad(G(blk.conv2.weight)), 3, 3, blk.stride, 1, bnrelu=s.st1)
+    else:
+        bc.wgrad(dy2, s.a1, phys_grad(G(blk.conv2.weight)), 3, 3, blk.stride, 1)
     dy1 = ops.bn_backward(da1, s.y1, s.st1, blk.bn1.weight.data, G(blk.bn1.weight), G(blk.bn1.bias), relu_mask=True,
                           part=part1)
     w1t = s.w1t if getattr(s, "w1t", None) is not None else ops.pack_wt(blk.conv1.physical(), dt)

@@ -198,6 +198,19 @@ int frhip_head_bwd_dt(int dtype, const void* ehat, const void* what, const int* 
                       int d, float s, float m, const float* rowmax, const float* rowsum, float gscale,
                       const float* upstream, void* dt, int ldt, frhip_stream_t stream);
 
+/* ---- bn1 -> relu -> conv2 of a BasicBlock (nets/resnet.py:91-93) WITHOUT the activated tensor: the BatchNorm-apply + ReLU
+ * is folded into the operand path of the convolution (forward) and of its weight gradient, which read the saved BatchNorm
+ * INPUT x and form relu(x * in_scale[c] + in_shift[c]) in LDS.  bf16, 3x3 / stride 1 / pad 1; *_fusable() tells whether a
+ * shape is served (otherwise use frhip_bn_apply + the plain entry points).  Results are bit-identical to the unfused pair. ---- */
+int frhip_conv_bnrelu_fusable(int dtype, int h, int wd, int c, int k, int r, int s, int stride, int pad);
+int frhip_conv_fwd_bnrelu(int dtype, const void* x, const float* in_scale, const float* in_shift, const void* w, void* y,
+                          float* stats_partial, int n, int h, int wd, int c, int k, int r, int s, int stride, int pad,
+                          frhip_stream_t stream);
+int frhip_conv_wgrad_bnrelu_fusable(int dtype, int n, int h, int w, int c, int k, int r, int s, int stride, int pad);
+int frhip_conv_wgrad_bnrelu(int dtype, const void* dy, const void* x, const float* in_scale, const float* in_shift,
+                            float* dw, int n, int h, int w, int c, int k, int r, int s, int stride, int pad, int splits,
+                            float* workspace, size_t workspace_bytes, frhip_stream_t stream);
+
 /* ---- fp8 weight path (BASELINE cfg 5; the reference has no fp8 arithmetic, see csrc/igemm_fp8.hip).  Forward convolutions
  * (nets/AlterNet_SwinV2_FAN.py:520-568, nets/resnet.py:23-46) and linears (:263-302) with both MFMA operands in OCP fp8
  * e4m3 on v_mfma_scale_f32_16x16x128_f8f6f4; bf16 output = fp32 accumulator x act_scale x w_scale[k] ---- */

@@ -466,3 +466,35 @@ def test_packs_roundtrip():
     dst = torch.zeros((12, 64)).cuda()
     ops.scatter_rows(got.cuda(), idx.cuda(), dst)
     assert torch.equal(dst.cpu()[idx], src[idx])
+
+
+@pytest.mark.parametrize("shape", [(8, 56, 56, 64, 64), (8, 28, 28, 128, 128), (16, 14, 14, 256, 256), (3, 14, 14, 256, 128),
+                                   (5, 7, 9, 192, 64), (2, 56, 56, 64, 128)])
+def test_conv_with_folded_bn_relu_is_bit_identical_to_the_separate_pass(shape):
+    """bn1 -> relu -> conv2 with the BatchNorm-apply + ReLU folded into the operand path of the convolution (forward: LDS-halo
+    kernel) and of its weight gradient (nine-tap kernel): the activated tensor is never written.  Same arithmetic and rounding
+    as the separate bn_apply pass, so outputs, BatchNorm partial sums and weight gradients must be BIT-identical."""
+    from frhip import ops
+    n, h, w, c, k = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    y1 = (torch.randn((n, h, w, c), generator=g) * 1.5 + 0.3).cuda().bfloat16()
+    wt = (torch.randn((k, 3, 3, c), generator=g) * 0.05).cuda().bfloat16()
+    dy = torch.randn((n, h, w, k), generator=g).cuda().bfloat16()
+    st = ops.bn_eval_affine((torch.rand(c, generator=g) + 0.5).cuda(), (torch.randn(c, generator=g) * 0.3).cuda(),
+                            (torch.randn(c, generator=g) * 0.3).cuda(), (torch.rand(c, generator=g) + 0.5).cuda())
+    if not ops.conv_bnrelu_fusable(y1, wt, 1, 1):
+        pytest.skip("shape not served by the fused kernels (the caller then runs bn_apply + the plain kernels)")
+    a1 = ops.bn_apply(y1, st, relu=True)
+    y_ref, p_ref = ops.conv_fwd(a1, wt, 1, 1, want_stats=True)
+    y_fus, p_fus = ops.conv_fwd_bnrelu(y1, st, wt, 1, 1, want_stats=True)
+    assert torch.equal(y_fus, y_ref)
+    assert p_fus.shape == p_ref.shape and torch.equal(p_fus, p_ref)
+    dw_ref = torch.zeros((k, 3, 3, c), device="cuda")
+    dw_fus = torch.zeros((k, 3, 3, c), device="cuda")
+    ops.conv_wgrad(dy, a1, dw_ref, 3, 3, 1, 1)
+    ops.conv_wgrad_bnrelu(dy, y1, st, dw_fus, 3, 3, 1, 1)
+    assert torch.equal(dw_fus, dw_ref)
+    # and against plain fp32 arithmetic (independent of the library's own unfused path)
+    a_ref = torch.relu(y1.float().cpu() * st.scale.cpu() + st.shift.cpu()).bfloat16().float()
+    ref = torch.nn.functional.conv2d(a_ref.permute(0, 3, 1, 2), wt.float().cpu().permute(0, 3, 1, 2), None, 1, 1).permute(0, 2, 3, 1)
+    assert float((y_fus.float().cpu() - ref).abs().max()) <= 2e-2 * float(ref.abs().max())
