@@ -13,7 +13,13 @@ from frhip import ops
 
 _OVERLAP_WGRAD = os.environ.get("FRHIP_OVERLAP_WGRAD", "1") == "1"
 _STEM_FUSED_REDUCE = os.environ.get("FRHIP_STEM_FUSED_REDUCE", "1") == "1"     # 0: the stem's own recompute reduction pass
-_FUSE_BN1 = os.environ.get("FRHIP_FUSE_BN1", "1") == "1"       # bn1-apply + ReLU folded into conv2's operand path (0: separate bn_apply pass)
+# bn1-apply + ReLU folded into conv2's operand path (forward and weight gradient; the activated tensor is never written).
+# Built, bit-identical to the separate pass, and OFF by default: measured on the ResNet50 step (B = 512, same box, two A/B
+# rounds) 29.5 ms fused vs 28.8 ms separate.  The in-LDS transform is ~3.5 VALU operations per element in kernels whose
+# matrix pipe already waits on instruction issue; it costs more (+15 us per forward conv2, +20 us per weight gradient) than
+# the 23-91 us HBM pass it removes wherever that pass is short, and the long passes (64 channels) sit on the layers whose
+# weight-gradient K step is shortest.  DESIGN.md section 4.8.
+_FUSE_BN1 = os.environ.get("FRHIP_FUSE_BN1", "0") == "1"
 _DTYPES = {"bf16": torch.bfloat16, "bfloat16": torch.bfloat16, "fp32": torch.float32, "float32": torch.float32}
 
 

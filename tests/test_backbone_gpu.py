@@ -187,3 +187,26 @@ def test_data_parallel_wrapper_has_ddp_surface(tmp_path):
         assert dp(recipe.images(1, 2).cuda()).shape == (2, 512)
     with pytest.raises(TypeError):
         BB.DataParallel(torch.nn.Linear(2, 2))
+
+
+def test_folded_bn1_relu_whole_net_is_bit_identical(monkeypatch):
+    """nets._backbone._FUSE_BN1 (bn1-apply + ReLU inside conv2's forward kernel and inside its weight-gradient kernel, a1 never
+    written) against the default separate pass: a ResNet18 bf16 training step must give bit-identical embeddings, parameter
+    gradients and BatchNorm buffers."""
+    import nets._backbone as bb
+    import nets.resnet as R
+    conf = types.SimpleNamespace(network="ResNet18", emd_size=512, frhip_dtype="bf16")
+    x = recipe.images(4401, 8).cuda()
+    gy = recipe.normal(4402, (8, 512)).cuda()
+    outs = []
+    for fuse in (False, True):
+        monkeypatch.setattr(bb, "_FUSE_BN1", fuse)
+        torch.manual_seed(4403)
+        net = R.ResNet18(conf).cuda().train()
+        y = net(x)
+        y.backward(gy)
+        outs.append((y.detach().clone(), [p.grad.clone() for p in net.parameters()], [b.clone() for b in net.buffers()]))
+    (y0, g0, b0), (y1, g1, b1) = outs
+    assert torch.equal(y0, y1)
+    for a, b in zip(g0 + b0, g1 + b1):
+        assert torch.equal(a, b)
