@@ -39,6 +39,7 @@ struct HaloGeom {
     // has landed; the activated tensor never exists in HBM (nets/resnet.py:91-93: bn1 -> relu -> conv2)
     const float* xf_scale;
     const float* xf_shift;
+    int wave_prio;          // > 0: s_setprio for the whole kernel (the critical-path convolutions outrank a co-resident weight gradient)
 };
 
 template <typename T, int WM, int WN, int MT, int HBUFS>
@@ -77,6 +78,9 @@ struct HaloMainloop {
                                         const void* __restrict__ b_ptr, char* smem, int mtile, int ntile) {
         const int lane = lane_id(), wave = wave_id();
         const int wm = wave / WN, wn = wave % WN;
+        if (g.wave_prio == 1) __builtin_amdgcn_s_setprio(1);
+        else if (g.wave_prio == 2) __builtin_amdgcn_s_setprio(2);
+        else if (g.wave_prio >= 3) __builtin_amdgcn_s_setprio(3);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll

@@ -156,6 +156,8 @@ int halo_run(int dtype, const void* a, const void* b, void* out, const void* res
     g.m_origin = 0; g.stat_row0 = 0;
     g.a_bytes = (uint32_t)ab; g.b_bytes = (uint32_t)bb;
     g.xf_scale = xf_scale; g.xf_shift = xf_shift;
+    static const int prio = getenv("FRHIP_HALO_PRIO") ? atoi(getenv("FRHIP_HALO_PRIO")) : 0;
+    g.wave_prio = prio;
     const int cfg = halo_config(dtype, c, k);
     if (xf_scale) {
         if (dtype != FRHIP_DT_BF16 || cfg != 0 || g_halo_tail) { set_error("igemm_halo: operand transform not available for this shape"); return FRHIP_EINVAL; }

@@ -8,6 +8,7 @@
 // reads are bank-conflict free.  Split-K over pixel ranges; results are added with fp32 atomics in whole
 // 256-byte rows staged through LDS.
 // Reference counterpart: autograd of nn.Conv2d / F.linear (cuDNN wgrad), nets/resnet.py:23-46, nets/PartialFC.py:201.
+#include <cstdlib>
 #include "common.h"
 #include "frhip.h"
 
@@ -735,7 +736,19 @@ void tn_taps9_kernel(TnGeom g, const void* __restrict__ p_ptr, const void* __res
 }
 
 static int g_tn_taps9 = 1;
-
+// Which tile the nine-tap weight gradients run on.  The weight gradients live on the side stream next to the main stream's
+// forward / data-gradient / BatchNorm kernels, and what counts is what the two streams can do on one CU AT THE SAME TIME:
+//   * the 8-wave 128 x 64 tile is the faster kernel on an empty chip (-10 %), but its 8 x 256 registers fill the CU's register
+//     file: nothing of the other stream fits beside it, the streams alternate workgroup by workgroup, and the HBM-bound
+//     BatchNorm passes of the main stream never overlap a weight gradient;
+//   * the 4-wave 64 x 64 tile takes one wave slot per SIMD and half the registers.  With its dynamic-LDS request raised to 82 KB
+//     at most ONE of its workgroups fits a CU, and beside it fit one 73-KB forward / data-gradient workgroup (4 waves) or the
+//     BatchNorm passes' waves: the weight gradient then runs in the shadow of whatever the main stream is doing.
+// Measured on the ResNet50 step (B = 512, two A/B rounds on one box): 29.0 ms (8-wave) -> 28.5 (4-wave) -> 28.2 ms (4-wave, one
+// per CU); the gain from having a side stream at all grows from 0.9 to 1.7 ms.  FRHIP_T9_NARROW=0 / FRHIP_T9_LDS_PAD=0 restore
+// the stand-alone-fastest choice (kernel micro-benchmarks use it).
+static int g_t9_narrow = getenv("FRHIP_T9_NARROW") ? atoi(getenv("FRHIP_T9_NARROW")) : 1;
+static int g_t9_lds_pad = getenv("FRHIP_T9_LDS_PAD") ? atoi(getenv("FRHIP_T9_LDS_PAD")) : 83968;
 template <int WCO, int WCI, int COF, int CIF, bool XF = false>
 static int tn_taps9_launch(const TnGeom& g, const void* p, const void* q, float* out, int splits, hipStream_t stream) {
     typedef T9Cfg<WCO, WCI, COF, CIF> Cfg;
@@ -743,13 +756,15 @@ static int tn_taps9_launch(const TnGeom& g, const void* p, const void* q, float*
     auto kern = tn_taps9_kernel<WCO, WCI, COF, CIF, XF>;
     static bool attr_done = false;
     if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS) != hipSuccess) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (Cfg::NW == 4 && g_t9_lds_pad > Cfg::LDS) ? g_t9_lds_pad : Cfg::LDS) != hipSuccess) {
             set_error("igemm_tn(taps9): cannot raise dynamic LDS to %d bytes", Cfg::LDS);
             return FRHIP_ELAUNCH;
         }
         attr_done = true;
     }
-    hipLaunchKernelGGL(kern, dim3(co_tiles * ci_tiles * splits), dim3(64 * Cfg::NW), Cfg::LDS, stream, g, p, q, out, co_tiles, ci_tiles);
+    const int lds = (Cfg::NW == 4 && g_t9_lds_pad > Cfg::LDS) ? g_t9_lds_pad : Cfg::LDS;
+    hipLaunchKernelGGL(kern, dim3(co_tiles * ci_tiles * splits), dim3(64 * Cfg::NW), lds, stream, g, p, q, out, co_tiles, ci_tiles);
     return check_launch("igemm_tn(taps9)");
 }
 
@@ -949,10 +964,10 @@ static int tn_run(int dtype, const void* p, const void* q, float* out, int n, in
     int rc;
     // The nine-tap kernel covers every 3x3/s1/p1 bf16 layer (g_tn_taps9: 0 off, 1/2 on); wide = 128-co tiles.
     if (t9_applicable(dtype, w, c, r, s, stride, pad, M, ldp)) {
-        const bool wide = kc > 64;
+        const bool wide = kc > 64 && !g_t9_narrow;
         const int co_t = wide ? 128 : 64;
         const long long tiles = 1LL * ((kc + co_t - 1) / co_t) * ((c + 63) / 64);
-        const int slots = 256 * (wide ? 1 : 2);
+        const int slots = 256 * ((wide || g_t9_lds_pad > 81920) ? 1 : 2);
         int best = 1; double best_t = 1e30;
         const int max_splits = g.ksteps / 8 > 0 ? g.ksteps / 8 : 1;
         for (int sp = 1; sp <= max_splits && sp <= 1024; ++sp) {
