@@ -20,6 +20,11 @@ _STEM_FUSED_REDUCE = os.environ.get("FRHIP_STEM_FUSED_REDUCE", "1") == "1"     #
 # the 23-91 us HBM pass it removes wherever that pass is short, and the long passes (64 channels) sit on the layers whose
 # weight-gradient K step is shortest.  DESIGN.md section 4.8.
 _FUSE_BN1 = os.environ.get("FRHIP_FUSE_BN1", "0") == "1"
+# hand a weight gradient to the side stream BEFORE the data-gradient of the same dy is enqueued (the side stream waits for what
+# the main stream holds at the hand-over): 27.16 -> 26.9 ms on the ResNet50 step.  One hand-over per block instead of one per
+# weight gradient (fewer barrier packets, but conv2's weight gradient starts a data-gradient later) measured 27.3 -> 27.7: off.
+_WGRAD_EARLY = os.environ.get("FRHIP_WGRAD_EARLY", "1") == "1"
+_BATCH_WGRAD = os.environ.get("FRHIP_BATCH_WGRAD", "0") == "1"
 _DTYPES = {"bf16": torch.bfloat16, "bfloat16": torch.bfloat16, "fp32": torch.float32, "float32": torch.float32}
 
 
@@ -174,6 +179,7 @@ class BackwardCtx:
         self.reduced_from = self.flat.numel()          # arena[reduced_from:] has been handed to RCCL
         self.works = []
         self.before_join = []                          # deferred gradient work (e.g. the batched position-bias backward)
+        self.pending = []                              # weight gradients waiting for flush_wgrads()
 
     def G(self, p):
         return self.grads[p]
@@ -192,9 +198,25 @@ class BackwardCtx:
         """bnrelu = BN state: x is the INPUT of a BatchNorm + ReLU whose output (the convolution's real operand) was never
         materialised; the weight-gradient kernel re-forms it in LDS"""
         if bnrelu is not None:
-            self.on_side(lambda: ops.conv_wgrad_bnrelu(dy, x, bnrelu, gview, r, s, stride, pad), dy, x, gview, bnrelu)
+            fn = lambda: ops.conv_wgrad_bnrelu(dy, x, bnrelu, gview, r, s, stride, pad)       # noqa: E731
         else:
-            self.on_side(lambda: ops.conv_wgrad(dy, x, gview, r, s, stride, pad), dy, x, gview)
+            fn = lambda: ops.conv_wgrad(dy, x, gview, r, s, stride, pad)                      # noqa: E731
+        if _BATCH_WGRAD and self.side is not None:
+            self.pending.append((fn, (dy, x, gview, bnrelu)))       # launched by flush_wgrads(): one stream hand-over per block
+        else:
+            self.on_side(fn, dy, x, gview, bnrelu)
+
+    def flush_wgrads(self):
+        """launch the weight gradients queued since the last flush on the side stream, behind ONE event of the main stream
+        (every cross-stream hand-over is a barrier packet in the main queue: two per block add up over 25 blocks)"""
+        if not self.pending:
+            return
+        todo, self.pending = self.pending, []
+        self.keep.extend(t for _, t in todo)
+        self.side.wait_stream(self.main)
+        with torch.cuda.stream(self.side):
+            for fn, _ in todo:
+                fn()
 
     def _reduce(self, lo, hi):
         if hi <= lo:
@@ -225,6 +247,7 @@ class BackwardCtx:
             self.reduced_from = lo
 
     def join(self):
+        self.flush_wgrads()
         for fn in self.before_join:
             fn()
         self.before_join = []
@@ -476,20 +499,31 @@ def basic_block_backward(blk, s, dout, dt, bc, part2=None, next_bn=None):
         bc.wgrad(dyd, s.x, phys_grad(G(dconv.weight)), 1, 1, dconv.stride, 0)
     w2t = s.w2t if getattr(s, "w2t", None) is not None else ops.pack_wt(blk.conv2.physical(), dt)
     # the BN1 (+ReLU) backward reduction over (da1, y1) rides in the epilogue of conv2's data-gradient
+    def wgrad2():
+        if s.a1 is None:    # bn1 + ReLU were folded into conv2's operand path: the weight gradient re-forms a1 from y1 as well
+            bc.wgrad(dy2, s.y1, phys_grad(G(blk.conv2.weight)), 3, 3, blk.stride, 1, bnrelu=s.st1)
+        else:
+            bc.wgrad(dy2, s.a1, phys_grad(G(blk.conv2.weight)), 3, 3, blk.stride, 1)
+    # the side stream waits for what the main stream has enqueued at the moment of the hand-over: hand a weight gradient
+    # over as soon as its operands are enqueued, i.e. BEFORE the data-gradient that reads the same dy
+    if _WGRAD_EARLY:
+        wgrad2()
     da1, part1 = ops.conv_dgrad(dy2, w2t, s.y1.shape, 3, 3, blk.stride, 1, bnred=(s.y1, s.st1, True))
-    if s.a1 is None:        # bn1 + ReLU were folded into conv2's operand path: the weight gradient re-forms a1 from y1 as well
-        bc.wgrad(dy2, s.y1, phys_grad(G(blk.conv2.weight)), 3, 3, blk.stride, 1, bnrelu=s.st1)
-    else:
-        bc.wgrad(dy2, s.a1, phys_grad(G(blk.conv2.weight)), 3, 3, blk.stride, 1)
+    if not _WGRAD_EARLY:
+        wgrad2()
     dy1 = ops.bn_backward(da1, s.y1, s.st1, blk.bn1.weight.data, G(blk.bn1.weight), G(blk.bn1.bias), relu_mask=True,
                           part=part1)
     w1t = s.w1t if getattr(s, "w1t", None) is not None else ops.pack_wt(blk.conv1.physical(), dt)
+    if _WGRAD_EARLY:
+        bc.wgrad(dy1, s.x, phys_grad(G(blk.conv1.weight)), 3, 3, 1, 1)
     if next_bn is not None:
         dx = ops.conv_dgrad(dy1, w1t, s.x.shape, 3, 3, 1, 1, residual=shortcut, bnred=(next_bn[0], next_bn[1], len(next_bn) > 2 and bool(next_bn[2])),
                             residual_stride=sc_stride)
     else:
         dx = ops.conv_dgrad(dy1, w1t, s.x.shape, 3, 3, 1, 1, residual=shortcut, residual_stride=sc_stride)
-    bc.wgrad(dy1, s.x, phys_grad(G(blk.conv1.weight)), 3, 3, 1, 1)
+    if not _WGRAD_EARLY:
+        bc.wgrad(dy1, s.x, phys_grad(G(blk.conv1.weight)), 3, 3, 1, 1)
+    bc.flush_wgrads()
     return dx
 
 
