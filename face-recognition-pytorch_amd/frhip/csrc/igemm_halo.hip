@@ -105,7 +105,7 @@ static int halo_launch(const HaloGeom& g, const void* a, const void* b, void* ou
     }
 }
 
-static int g_halo_enabled = 1;
+static int g_halo_enabled = getenv("FRHIP_HALO_MODE") ? atoi(getenv("FRHIP_HALO_MODE")) & 3 : 1;     // 2 / 3: force the 4-wave / 8-wave tile
 
 bool halo_applicable(int dtype, int h, int w, int c, int k, int r, int s, int stride, int pad) {
     const int bke = NT_ROWB / (dtype == FRHIP_DT_BF16 ? 2 : 4);
@@ -124,8 +124,10 @@ static int halo_config(int dtype, int c, int k) {
         // workgroups per CU wins (117 vs 144 us at 128 ch, 106 vs 124 us at 256 ch): the second workgroup's MFMAs cover
         // the first one's prologue, halo reloads, barriers and store epilogue.  From 512 channels the 8-wave 256x128
         // tile with the double-buffered halo is level or ahead.  g_halo_enabled: 2 forces the former, 3 the latter.
+        // Round 2: inside the training step the 4-wave tile also wins at 512 channels (27.6 -> 27.35 ms, two A/B rounds): a
+        // 73-KB workgroup fits a CU beside the side stream's 82-KB weight-gradient workgroup, the 142-KB 8-wave tile does not.
         const int mode = g_halo_enabled & 3;
-        const bool two_per_cu = mode == 2 || (mode != 3 && nchunks <= 4);
+        const bool two_per_cu = mode == 2 || (mode != 3 && nchunks <= 8);
         if (two_per_cu || narrow) return (nchunks == 1 || two_per_cu) ? 0 : 1;
         return 2;
     }
