@@ -1,20 +1,32 @@
 #!/bin/bash
-# End-of-round evidence on the GPU box: bench line, rocprofv3 kernel stats of the same command, serial step anatomy,
-# PMC traffic passes.  Everything lands under gpurun_out/final/ ; copy the summaries into profiles/ afterwards.
+# End-of-round evidence on the GPU box: bench line, rocprofv3 kernel stats of the same command, serial step anatomy (weight
+# gradients on the main stream so durations add up), the overlapped anatomy (what the step really runs), Swin34 / AlterNet50
+# anatomies, PMC traffic passes and the MFMA-utilisation counters of the dominant kernels.
+# Everything lands under gpurun_out/final/ ; tools/collect_profiles.py <tag> copies the summaries into profiles/.
 set -e
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/final
-mkdir -p $OUT
+rm -rf $OUT; mkdir -p $OUT
 cd $R
 python bench.py > $OUT/bench.json 2> $OUT/bench.log
 tail -1 $OUT/bench.json | cut -c1-200
+export FRHIP_BENCH_INSTEP=0
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o r50 -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline > $OUT/stats.log 2>&1
+cp $(ls $OUT/stats/*kernel_trace.csv | head -1) $OUT/overlap_trace.csv
 FRHIP_OVERLAP_WGRAD=0 rocprofv3 --kernel-trace --output-format csv -d $OUT/serial -o r50 -- python3 $R/bench.py --steps 6 --warmup 3 --no-cpu-baseline > $OUT/serial.log 2>&1
 FRHIP_OVERLAP_WGRAD=0 rocprofv3 --kernel-trace --output-format csv -d $OUT/swin -o swin -- python3 $R/bench.py --network Swin34 --steps 6 --warmup 3 --no-cpu-baseline > $OUT/swin.log 2>&1
+FRHIP_OVERLAP_WGRAD=0 rocprofv3 --kernel-trace --output-format csv -d $OUT/alt -o alt -- python3 $R/bench.py --network AlterNet50 --fp8 --steps 6 --warmup 3 --no-cpu-baseline > $OUT/alt.log 2>&1
 cd $R
 python tools/trace_summary.py $(ls $OUT/serial/*kernel_trace.csv | head -1) > $OUT/step_anatomy.txt
+python tools/trace_summary.py $OUT/overlap_trace.csv > $OUT/step_anatomy_overlapped.txt
 python tools/trace_summary.py $(ls $OUT/swin/*kernel_trace.csv | head -1) > $OUT/swin_step_anatomy.txt
-rm -f $OUT/serial/*kernel_trace.csv $OUT/swin/*kernel_trace.csv $OUT/stats/*kernel_trace.csv
+python tools/trace_summary.py $(ls $OUT/alt/*kernel_trace.csv | head -1) > $OUT/alt_step_anatomy.txt
+rm -f $OUT/serial/*kernel_trace.csv $OUT/swin/*kernel_trace.csv $OUT/alt/*kernel_trace.csv $OUT/stats/*kernel_trace.csv $OUT/overlap_trace.csv
 bash tools/pmc_traffic.sh > $OUT/pmc.log 2>&1
-ls $OUT $OUT/stats | head -30
+# MFMA utilisation / LDS counters of the dominant kernels (256-channel 14x14 layer, B = 512), one rocprofv3 pass per counter group
+for what in fwd dgrad wgrad; do
+  bash tools/pmc_run.sh $OUT/pmc_$what $what 14 256 256 > $OUT/pmc_$what.log 2>&1 || true
+  python tools/pmc_show.py $OUT/pmc_$what > $OUT/pmc_$what.txt 2>/dev/null || true
+done
+ls $OUT | head -40
