@@ -2,6 +2,7 @@
 # usage: tools/pmc_run.sh <outdir> <what> <h> <c> <k>   (GPU box; one rocprofv3 pass per counter group)
 set -e
 out=$1; shift
+mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 i=0
 for grp in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY" \
