@@ -187,7 +187,8 @@ class CpbBatch:
         dev = torch.empty(raw.numel(), dtype=torch.uint8, device=self.out.device)
         dev.copy_(pin, non_blocking=True)
         fn = self.lib().frhip_cpb_bwd if backward else self.lib().frhip_cpb_fwd
-        self.check(fn(dev.data_ptr(), len(self.blocks), ops._s()), "frhip_cpb_bwd" if backward else "frhip_cpb_fwd")
+        scratch = torch.empty(self.lib().frhip_cpb_scratch_floats(len(self.blocks)), dtype=torch.float32, device=self.out.device)
+        self.check(fn(dev.data_ptr(), len(self.blocks), scratch.data_ptr(), ops._s()), "frhip_cpb_bwd" if backward else "frhip_cpb_fwd")
         self._table = dev                                    # alive until the kernel has run (stream-ordered free)
 
     def flush_backward(self, bc):

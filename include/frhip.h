@@ -254,8 +254,9 @@ typedef struct frhip_cpb_block {
     int entries, tokens, heads, pad_;
 } frhip_cpb_block;
 int frhip_cpb_limits(int* max_entries, int* max_heads, int* hidden);
-int frhip_cpb_fwd(const frhip_cpb_block* blocks_dev, int nblocks, frhip_stream_t stream);
-int frhip_cpb_bwd(const frhip_cpb_block* blocks_dev, int nblocks, frhip_stream_t stream);
+int frhip_cpb_scratch_floats(int nblocks);      /* size of the caller-owned scratch both calls need (keep it from fwd to bwd: not required) */
+int frhip_cpb_fwd(const frhip_cpb_block* blocks_dev, int nblocks, float* scratch, frhip_stream_t stream);
+int frhip_cpb_bwd(const frhip_cpb_block* blocks_dev, int nblocks, float* scratch, frhip_stream_t stream);
 
 /* ---- explicit-logit margin and softmax-CE (stand-alone use of nets/ArcFace.py:76-105, nets/PartialFC.py:441-484) ---- */
 /* logits[n][c] fp32 in place: target entry -> margin (kind 0 ArcFace, 1 CosFace), everything x s; tsave[n] = raw target cos.
