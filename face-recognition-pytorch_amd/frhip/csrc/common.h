@@ -96,6 +96,20 @@ template <> struct Mma<fp8_t> {
     }
 };
 
+// fp8 operands on the NON-scaled MFMA (v_mfma_f32_16x16x32_fp8_fp8, bf16 rate): a 16-byte fragment feeds two instructions,
+// so a 128-byte row is two K sub-steps of 64 channels like a bf16 row is of 32 -- the software pipeline of the LDS-halo
+// kernel (two K halves per tap) applies unchanged, at half the bytes per MAC.
+struct fp8n_t { uint8_t bits; };
+template <> struct Mma<fp8n_t> {
+    typedef __attribute__((ext_vector_type(4))) int Frag;
+    __device__ static __forceinline__ void run(const Frag& a, const Frag& b, f32x4_t& c) {
+        const long a0 = ((long)(uint32_t)a[1] << 32) | (uint32_t)a[0], a1 = ((long)(uint32_t)a[3] << 32) | (uint32_t)a[2];
+        const long b0 = ((long)(uint32_t)b[1] << 32) | (uint32_t)b[0], b1 = ((long)(uint32_t)b[3] << 32) | (uint32_t)b[2];
+        c = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(a0, b0, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(a1, b1, c, 0, 0, 0);
+    }
+};
+
 // MFMA fragments of one 128-byte LDS row (16-byte chunks XOR-swizzled by sw = row & 7): bf16 / f32 rows hold two K sub-steps
 // of one 16-byte fragment per lane group fg (chunk fg + 4 s), an fp8 row is ONE sub-step of two chunks (fg and fg + 4).
 template <typename T> struct RowFrag {

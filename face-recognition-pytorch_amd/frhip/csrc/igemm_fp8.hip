@@ -8,7 +8,7 @@
 //   same store epilogue as in the bf16 kernels.  Backward passes stay on the bf16 kernels (they read the bf16 tensors).
 // The reference has no fp8 arithmetic: parity is stated against the bf16 path of this library.
 // Reference call sites served: nets/AlterNet_SwinV2_FAN.py:520-568 (BasicBlock convs), :263-302 (qkv / proj), nets/resnet.py:23-46.
-#include "igemm_nt.h"
+#include "igemm_halo.h"
 #include "frhip.h"
 
 namespace frhip {
@@ -152,6 +152,72 @@ static int nt8_launch(const NtGeom& g, const void* a, const void* b, const float
     return check_launch("igemm_fp8");
 }
 
+// ---- 3x3 / stride-1 / pad-1 fp8 convolution on the LDS-halo main loop (igemm_halo.h): activation window resident in LDS per
+//      128-channel chunk, weights streamed per tap; non-scaled fp8 MFMA (see Mma<fp8n_t>): half the L2 -> LDS bytes per MAC of the
+//      bf16 kernel, which is what bounds it.
+template <int WM, int WN, int MT, int HBUFS>
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void halo8_kernel(HaloGeom g, const void* __restrict__ a,
+                                                                           const void* __restrict__ b, const float* __restrict__ wscale,
+                                                                           float ascale, void* __restrict__ out, float* __restrict__ stats,
+                                                                           EpiBnRed br, int mtiles, int ntiles) {
+    typedef HaloTile<fp8n_t, WM, WN, MT, HBUFS> Tile;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const uint32_t lin = xcd_remap(blockIdx.x, gridDim.x);
+    const int ntile = (int)(lin % (uint32_t)ntiles), mtile = (int)(lin / (uint32_t)ntiles);
+    HaloMainloop<fp8n_t, WM, WN, MT, HBUFS> ml;
+    ml.run(g, a, b, smem, mtile, ntile);
+    const int lane = lane_id(), wave = wave_id();
+    const int wm = wave / WN, wn = wave % WN;
+    const int m0 = g.m_origin + mtile * Tile::BM + wm * Tile::WROWS, n0 = ntile * Tile::BN + wn * 64;
+    const int fg = lane >> 4;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        float sc[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const int n = n0 + nt * 16 + 4 * fg + e; sc[e] = n < g.Nout ? ascale * wscale[n] : 0.f; }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) ml.acc[nt][mt][e] *= sc[e];
+    }
+    EpiOperands<bf16_t, Tile::WROWS> eo;
+    eo.fetch(nullptr, nullptr, g.M, g.Nout, m0, n0, 0, 0, &br.map);
+    const char* mine = ml.template stage_out<bf16_t>(smem);
+    nt_epilogue_store<bf16_t, WM, WN, Tile::WROWS, Tile::THREADS, Tile::BN>(mine, Tile::template stage_pitch<bf16_t>(), smem, g.M, g.Nout,
+                                                                            out, false, stats, br, eo, g.stat_row0 + mtile, ntile, m0, n0);
+}
+
+static int g_fp8_halo = 1;      // 3x3 / stride-1 layers on the halo main loop (0: generic NT kernel; test hook frhip_set_fp8_halo)
+
+static bool halo8_applicable(int h, int w, int c, int k, int r, int s, int stride, int pad) {
+    return r == 3 && s == 3 && stride == 1 && pad == 1 && w <= 56 && (c % 128) == 0 && (k % 8) == 0;
+}
+
+static int halo8_run(const void* x8, const void* w8, const float* wscale, float ascale, void* y, float* stats, int n, int h, int w,
+                     int c, int k, hipStream_t stream) {
+    typedef HaloTile<fp8n_t, 4, 1, 4, 1> Tile;
+    const long long ab = 1LL * n * h * w * c, bb = 1LL * k * 9 * c;
+    if (ab > 0x7fffffffLL || bb > 0x7fffffffLL) { set_error("igemm_fp8(halo): tensor exceeds the 2 GiB buffer window"); return FRHIP_EINVAL; }
+    HaloGeom g;
+    g.H = h; g.W = w; g.C = c; g.M = n * h * w; g.Nout = k; g.Ktot = 9 * c; g.sign = +1;
+    g.m_origin = 0; g.stat_row0 = 0; g.a_bytes = (uint32_t)ab; g.b_bytes = (uint32_t)bb;
+    g.xf_scale = nullptr; g.xf_shift = nullptr; g.wave_prio = 0;
+    const int mtiles = (g.M + Tile::BM - 1) / Tile::BM, ntiles = (k + Tile::BN - 1) / Tile::BN;
+    const int lds = Tile::template lds_bytes<bf16_t>();
+    auto kern = halo8_kernel<4, 1, 4, 1>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
+            set_error("igemm_fp8(halo): cannot raise dynamic LDS to %d bytes", lds);
+            return FRHIP_ELAUNCH;
+        }
+        attr_done = true;
+    }
+    static const EpiBnRed none = {nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, {0, 0, 0, 0, 0, 0}, nullptr, nullptr, 0};
+    hipLaunchKernelGGL(kern, dim3(mtiles * ntiles), dim3(Tile::THREADS), lds, stream, g, x8, w8, wscale, ascale, y, stats, none, mtiles, ntiles);
+    return check_launch("igemm_fp8(halo)");
+}
+
 static bool fp8_wide(const NtGeom& g) { return (g.Nout % 256) == 0 && g.M >= 256 * 64; }
 
 static int fp8_geom(NtGeom& g, int n, int h, int w, int c, int k, int r, int s, int stride, int pad, const char* who) {
@@ -224,7 +290,16 @@ extern "C" int frhip_conv_fwd_fp8(const void* x8, const void* w8, const float* w
     NtGeom g;
     int rc = fp8_geom(g, n, h, wd, c, k, r, s, stride, pad, "frhip_conv_fwd_fp8");
     if (rc) return rc;
+    if (g_fp8_halo && halo8_applicable(h, wd, c, k, r, s, stride, pad))
+        return halo8_run(x8, w8, wscale, act_scale, y, stats_partial, n, h, wd, c, k, stream);
     return fp8_run(g, x8, w8, wscale, act_scale, y, stats_partial, NO_EPI, stream);
+}
+
+extern "C" int frhip_set_fp8_halo(int enabled) { const int old = g_fp8_halo; if (enabled >= 0) g_fp8_halo = enabled; return old; }
+
+extern "C" int frhip_fp8_conv_stat_rows(int m, int k, int h, int w, int c, int r, int s, int stride, int pad) {
+    if (g_fp8_halo && halo8_applicable(h, w, c, k, r, s, stride, pad)) return (m + 255) / 256;
+    return frhip_fp8_stat_rows(m, k);
 }
 
 extern "C" int frhip_fp8_stat_rows(int m, int k) {

@@ -232,7 +232,7 @@ struct HaloMainloop {
         };
         // ask the scheduler to spread the (4 + MT) fragment reads of a half between its 4*MT MFMAs
         auto interleave = [&]() {
-            constexpr int NREAD = (4 + MT) * (int)(sizeof(Frag) / 16), NMFMA = 4 * MT * (sizeof(T) == 2 ? 1 : 4);
+            constexpr int NREAD = (4 + MT) * (int)(sizeof(Frag) / 16), NMFMA = 4 * MT * (sizeof(T) == 2 ? 1 : (sizeof(T) == 1 ? 2 : 4));
             constexpr int PER = NMFMA / NREAD > 0 ? NMFMA / NREAD : 1;
 #pragma unroll
             for (int i = 0; i < NREAD; ++i) {

@@ -712,7 +712,8 @@ def conv_fwd_fp8(x8, w8, wscale, stride, pad, want_stats=True):
     y = torch.empty((n, ho, wo, k), dtype=torch.bfloat16, device=x8.device)
     part = None
     if want_stats:
-        part = torch.empty((lib().frhip_fp8_stat_rows(n * ho * wo, k), 2, k), dtype=torch.float32, device=x8.device)
+        rows = lib().frhip_fp8_conv_stat_rows(n * ho * wo, k, h, wd, c, r, s, stride, pad)
+        part = torch.empty((rows, 2, k), dtype=torch.float32, device=x8.device)
     check(lib().frhip_conv_fwd_fp8(_p(x8), _p(w8), _p(wscale), FP8_ACT_SCALE, _p(y), _p(part), n, h, wd, c, k, r, s, stride, pad, _s()),
           "frhip_conv_fwd_fp8")
     return y, part

@@ -227,7 +227,9 @@ int frhip_bn_apply_q8(int dtype, const void* y, const float* scale, const float*
 int frhip_conv_fwd_fp8(const void* x8, const void* w8, const float* wscale, float act_scale, void* y,
                        float* stats_partial, int n, int h, int wd, int c, int k, int r, int s, int stride, int pad,
                        frhip_stream_t stream);
-int frhip_fp8_stat_rows(int m, int k);
+int frhip_fp8_stat_rows(int m, int k);                                               /* linears / generic kernel */
+int frhip_fp8_conv_stat_rows(int m, int k, int h, int w, int c, int r, int s, int stride, int pad);   /* convolutions */
+int frhip_set_fp8_halo(int enabled);     /* test hook: 3x3 stride-1 fp8 convs on the LDS-halo kernel (1, default) or the generic one (0); < 0: query */
 /* out bf16 [m][n] = a8 [m][k] x w8 [n][k]^T * act_scale * wscale[n] + bias[n] */
 int frhip_linear_fwd_fp8(const void* a8, const void* w8, const float* wscale, float act_scale, const float* bias,
                          void* out, float* stats_partial, int m, int n, int k, frhip_stream_t stream);

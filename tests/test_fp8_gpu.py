@@ -64,7 +64,14 @@ def test_fp8_conv_matches_dequantised_reference(shape):
     wt = recipe.normal(9720 + k, (k, r, r, c), 0.05).cuda()
     x8 = ops.quant_fp8(x)
     w8, ws = ops.quant_fp8_weights(wt)
-    y, part = ops.conv_fwd_fp8(x8, w8, ws, stride, pad, want_stats=True)
+    from frhip._abi import lib
+    old = lib().frhip_set_fp8_halo(0)                    # generic NT kernel (block-scaled MFMA) ...
+    try:
+        y_nt, part_nt = ops.conv_fwd_fp8(x8, w8, ws, stride, pad, want_stats=True)
+    finally:
+        lib().frhip_set_fp8_halo(old)
+    y, part = ops.conv_fwd_fp8(x8, w8, ws, stride, pad, want_stats=True)       # ... and the default (LDS-halo kernel for 3x3 / s1)
+    assert float((y.float() - y_nt.float()).abs().max()) <= 2.0 ** -7 * float(y_nt.float().abs().max())    # fp32 summation order + bf16 rounding
     xd = _e4m3_decode(x8.cpu()).permute(0, 3, 1, 2)
     wd = (_e4m3_decode(w8.cpu()) * ws.cpu().view(-1, 1, 1, 1)).permute(0, 3, 1, 2)
     ref = torch.nn.functional.conv2d(xd.double(), wd.double(), None, stride, pad).permute(0, 2, 3, 1).float()
