@@ -419,7 +419,7 @@ def main():
             f8 = f8_fl / (f8_ms * 1e-3) / 1e12
             line["roofline_fp8"] = {"bound": "mfma", "achieved": round(f8, 1), "peak": 2 * BF16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
                                     "frac": round(f8 / (2 * BF16_DENSE_PEAK_TFLOPS), 4), "traffic": None,
-                                    "kernel": "frhip::nt8_kernel (fp8 e4m3 x e4m3 forward convolutions, v_mfma_scale_f32_16x16x128_f8f6f4)",
+                                    "kernel": "frhip::halo8_kernel (3x3 stride 1: v_mfma_f32_16x16x32_fp8_fp8) + frhip::nt8_kernel (other convs: v_mfma_scale_f32_16x16x128_f8f6f4), fp8 e4m3 x e4m3 forward convolutions",
                                     "launches": f8_n // in_steps, "avg_launch_us": round(f8_ms * 1e3 / f8_n, 2)}
         if world == 1 and not args.no_cpu_baseline and args.network == "ResNet50":
             line["cpu_baseline"] = cpu_baseline(args.classes)

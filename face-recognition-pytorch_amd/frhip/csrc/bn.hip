@@ -319,7 +319,12 @@ static bool shape_ok(int dtype, int C, const char* who) {
 using namespace frhip;
 
 extern "C" int frhip_colreduce_blocks(int rows, int c, int dtype) {
+    // 0 = this (dtype, width) is not served by the element-wise kernels (the same condition shape_ok() reports with a message);
+    // callers size their partial-sum buffer with the result, so it must never divide by zero or come out as zero rows silently
     const int epv = dtype == FRHIP_DT_BF16 ? 8 : 4;
+    if ((dtype != FRHIP_DT_BF16 && dtype != FRHIP_DT_F32) || rows <= 0 || c < epv || (c % epv) || c / epv > EW_THREADS ||
+        (EW_THREADS % (c / epv)))
+        return 0;
     const int rlanes = EW_THREADS / (c / epv);
     int b = (rows + rlanes * 8 - 1) / (rlanes * 8);
     if (b > 1024) b = 1024;

@@ -83,7 +83,9 @@ static int nt_launch_cfg(const NtGeom& g, const void* a, const void* b, void* ou
 static int g_nt_tile = 0;
 
 static int nt_pick_tile(int dtype, const NtGeom& g) {
-    if (g_nt_tile) return (g_nt_tile == 4 && dtype != FRHIP_DT_BF16) ? 3 : g_nt_tile;
+    // fp32 has the 128x128 and 256x64 tiles only: a forced 3 / 4 resolves to the tile nt_dispatch really launches (1), so that
+    // the BM the callers size their partial-sum buffers with is the dispatched one
+    if (g_nt_tile) return (dtype != FRHIP_DT_BF16 && g_nt_tile >= 3) ? 1 : g_nt_tile;
     if ((g.Nout % 128) != 0 && g.Nout <= 256) return 2;
     // measured on MI355X (tools/bench_kernels.py, B=512): 256x256 beats 128x128 by 15-25 % once Cout % 256 == 0
     if (dtype == FRHIP_DT_BF16 && (g.Nout % 256) == 0 && g.M >= 256 * 64) return 4;

@@ -218,9 +218,16 @@ def gemm_tn(p, q, out, kc=None, splits=0, overwrite=False):
 
 
 # ------------------------------------------------------------------------------------------ batch norm
+def _colreduce_blocks(rows, c, dtype_code):
+    nb = lib().frhip_colreduce_blocks(rows, c, dtype_code)
+    if nb <= 0:
+        raise _abi.FrhipError("frhip: the element-wise kernels do not serve %d channels in this dtype" % c)
+    return nb
+
+
 def colstats(x2d):
     rows, c = x2d.shape
-    nb = lib().frhip_colreduce_blocks(rows, c, dt_of(x2d))
+    nb = _colreduce_blocks(rows, c, dt_of(x2d))
     part = torch.empty((nb, 2, c), dtype=torch.float32, device=x2d.device)
     check(lib().frhip_colstats(dt_of(x2d), _p(x2d), rows, c, _p(part), _s()), "frhip_colstats")
     return part
@@ -278,7 +285,7 @@ def bn_backward(dout, y, st, gamma, dgamma, dbeta, relu_mask=False, out=None, sc
     ms = _p(st.scale) if relu_mask else None
     mb = _p(st.shift) if relu_mask else None
     if part is None:
-        nb = lib().frhip_colreduce_blocks(rows, c, dt_of(y))
+        nb = _colreduce_blocks(rows, c, dt_of(y))
         part = torch.empty((nb, 2, c), dtype=torch.float32, device=dev)
         check(lib().frhip_bn_bwd_reduce(dt_of(y), _p(dout), _p(y), _p(st.mean), _p(st.invstd), ms, mb, rows, c, _p(part), _s()),
               "frhip_bn_bwd_reduce")
