@@ -26,6 +26,40 @@ shutil.copy(os.path.join(F, "stats", "r50_kernel_stats.csv"), os.path.join(P, TA
 hdr = ("# one training step, weight gradients on the main stream (FRHIP_OVERLAP_WGRAD=0) so kernel durations add up to the step:\n"
        "# rocprofv3 --kernel-trace -- python3 bench.py --steps 6 --warmup 3 --no-cpu-baseline ; tools/trace_summary.py\n")
 open(os.path.join(P, TAG + "_final_step_anatomy.txt"), "w").write(hdr + open(os.path.join(F, "step_anatomy.txt")).read())
+hdr_o = ("# the same step as it really runs: weight gradients on the side stream (queue 2), co-resident with the main stream's kernels;\n"
+         "# per-kernel durations are inflated by the sharing, the queues' busy times overlap.  rocprofv3 --kernel-trace -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline\n")
+open(os.path.join(P, TAG + "_final_step_anatomy_overlapped.txt"), "w").write(hdr_o + open(os.path.join(F, "step_anatomy_overlapped.txt")).read())
+hdr_a = ("# AlterNet50 @192 with the fp8 forward path (BASELINE cfg 5), one training step, weight gradients on the main stream:\n"
+         "# rocprofv3 --kernel-trace -- python3 bench.py --network AlterNet50 --fp8 --steps 6 --warmup 3 --no-cpu-baseline ; tools/trace_summary.py\n")
+open(os.path.join(P, TAG + "_final_alternet50_fp8_step_anatomy.txt"), "w").write(hdr_a + open(os.path.join(F, "alt_step_anatomy.txt")).read())
+# MFMA utilisation counters of the dominant kernels (tools/pmc_run.sh: one rocprofv3 --pmc pass per counter group, kernel-trace only)
+with open(os.path.join(P, TAG + "_pmc_mfma_util.txt"), "w") as out:
+    out.write("# rocprofv3 --pmc <group> --kernel-trace -- python3 tools/pmc_one.py fwd|dgrad|wgrad 14 256 256   (B = 512, 256-channel 14x14 layer, bf16)\n"
+              "# groups: tools/pmc_run.sh.  MFMA utilisation = SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CU_CYCLES / 4 (four SIMDs per CU).\n"
+              "# wgrad = the 4-wave co-resident tile the step uses; wgrad8 = the stand-alone-fastest 8-wave tile (FRHIP_T9_NARROW=0).\n")
+    for what in ("fwd", "dgrad", "wgrad", "wgrad8"):
+        f = os.path.join(F, "pmc_%s.txt" % what)
+        if not os.path.exists(f):
+            continue
+        cur, vals = None, {}
+        for line in open(f):
+            if not line.startswith("   "):
+                cur = line.strip()
+                vals[cur] = {}
+            else:
+                k, v = line.split()
+                vals[cur][k] = float(v)
+        for k, v in vals.items():
+            if ("halo_kernel" in k or "taps9" in k) and v.get("SQ_BUSY_CU_CYCLES"):
+                out.write("\n[%s] %s\n" % (what, k[:110]))
+                out.write("  MFMA utilisation            %.3f\n" % (v["SQ_VALU_MFMA_BUSY_CYCLES"] / v["SQ_BUSY_CU_CYCLES"] / 4))
+                wc = v["SQ_WAVE_CYCLES"]
+                out.write("  wave cycles: waiting (s_waitcnt / barrier) %.2f, issue-stalled %.2f, issuing %.2f\n" % (v["SQ_WAIT_ANY"] / wc, v["SQ_WAIT_INST_ANY"] / wc, v["SQ_ACTIVE_INST_ANY"] / wc))
+                out.write("  LDS: bank-conflict cycles %.2f of LDS-active cycles; LDS issue stall %.3f of wave cycles\n" % (v["SQ_LDS_BANK_CONFLICT"] / max(v["SQ_LDS_IDX_ACTIVE"], 1), v["SQ_WAIT_INST_LDS"] / wc))
+                out.write("  instructions: MFMA %.3g, VALU %.3g (%.2f per MFMA), SALU %.3g, LDS %.3g; MFMA || VALU co-execution %.2f of MFMA-busy cycles\n" % (
+                    v["SQ_INSTS_MFMA"], v["SQ_INSTS_VALU"], v["SQ_INSTS_VALU"] / v["SQ_INSTS_MFMA"], v["SQ_INSTS_SALU"], v["SQ_INSTS_LDS"], v["SQ_VALU_MFMA_COEXEC_CYCLES"] / v["SQ_VALU_MFMA_BUSY_CYCLES"]))
+                for name in sorted(v):
+                    out.write("    %-32s %16.0f\n" % (name, v[name]))
 hdr2 = ("# Swin34 (BASELINE cfg 4), one training step, weight gradients on the main stream (FRHIP_OVERLAP_WGRAD=0):\n"
         "# rocprofv3 --kernel-trace -- python3 bench.py --network Swin34 --steps 6 --warmup 3 --no-cpu-baseline ; tools/trace_summary.py\n")
 open(os.path.join(P, TAG + "_final_swin34_step_anatomy.txt"), "w").write(hdr2 + open(os.path.join(F, "swin_step_anatomy.txt")).read())

@@ -29,4 +29,7 @@ for what in fwd dgrad wgrad; do
   bash tools/pmc_run.sh $OUT/pmc_$what $what 14 256 256 > $OUT/pmc_$what.log 2>&1 || true
   python tools/pmc_show.py $OUT/pmc_$what > $OUT/pmc_$what.txt 2>/dev/null || true
 done
+FRHIP_T9_NARROW=0 FRHIP_T9_LDS_PAD=0 bash tools/pmc_run.sh $OUT/pmc_wgrad8 wgrad 14 256 256 > $OUT/pmc_wgrad8.log 2>&1 || true
+python tools/pmc_show.py $OUT/pmc_wgrad8 > $OUT/pmc_wgrad8.txt 2>/dev/null || true
+rm -rf $OUT/pmc_*/g*      # raw counter CSVs: summarised in pmc_*.txt
 ls $OUT | head -40
