@@ -749,6 +749,8 @@ static int g_tn_taps9 = 1;
 // the stand-alone-fastest choice (kernel micro-benchmarks use it).
 static int g_t9_narrow = getenv("FRHIP_T9_NARROW") ? atoi(getenv("FRHIP_T9_NARROW")) : 1;
 static int g_t9_lds_pad = getenv("FRHIP_T9_LDS_PAD") ? atoi(getenv("FRHIP_T9_LDS_PAD")) : 83968;
+static int g_t9_maxsteps = getenv("FRHIP_T9_MAXSTEPS") ? atoi(getenv("FRHIP_T9_MAXSTEPS")) : 0;
+static int g_t9_slots = getenv("FRHIP_T9_SLOTS") ? atoi(getenv("FRHIP_T9_SLOTS")) : 0;     // experiment: workgroups per weight-gradient launch (fewer than 256 leaves CUs to the main stream alone)
 template <int WCO, int WCI, int COF, int CIF, bool XF = false>
 static int tn_taps9_launch(const TnGeom& g, const void* p, const void* q, float* out, int splits, hipStream_t stream) {
     typedef T9Cfg<WCO, WCI, COF, CIF> Cfg;
@@ -967,7 +969,7 @@ static int tn_run(int dtype, const void* p, const void* q, float* out, int n, in
         const bool wide = kc > 64 && !g_t9_narrow;
         const int co_t = wide ? 128 : 64;
         const long long tiles = 1LL * ((kc + co_t - 1) / co_t) * ((c + 63) / 64);
-        const int slots = 256 * ((wide || g_t9_lds_pad > 81920) ? 1 : 2);
+        const int slots = g_t9_slots > 0 ? g_t9_slots : 256 * ((wide || g_t9_lds_pad > 81920) ? 1 : 2);
         int best = 1; double best_t = 1e30;
         const int max_splits = g.ksteps / 8 > 0 ? g.ksteps / 8 : 1;
         for (int sp = 1; sp <= max_splits && sp <= 1024; ++sp) {
@@ -976,6 +978,12 @@ static int tn_run(int dtype, const void* p, const void* q, float* out, int n, in
             if (t < best_t * 0.98) { best_t = t; best = sp; }
         }
         if (splits <= 0) splits = best;
+        if (g_t9_maxsteps > 0) {          // experiment: short-lived workgroups (at most this many K steps each), as many splits as the slab workspace holds
+            int want = (g.ksteps + g_t9_maxsteps - 1) / g_t9_maxsteps;
+            const size_t cap = ws_bytes / (out_elems * sizeof(float));
+            if ((size_t)want > cap) want = (int)cap;
+            if (want > splits) splits = want;
+        }
         if (splits > g.ksteps) splits = g.ksteps;
         g.ksteps_per_split = (g.ksteps + splits - 1) / splits;
         splits = (g.ksteps + g.ksteps_per_split - 1) / g.ksteps_per_split;
