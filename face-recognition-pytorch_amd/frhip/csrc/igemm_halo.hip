@@ -2,6 +2,7 @@
 // frhip_conv_dgrad when the geometry matches; the generic NT kernel covers everything else.
 #include <cstdlib>
 #include "igemm_halo.h"
+#include "igemm_halo_wide.h"
 #include "frhip.h"
 
 namespace frhip {
@@ -34,6 +35,46 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void halo_kernel(HaloG
     const char* mine = ml.template stage_out<T>(smem);
     nt_epilogue_store<T, WM, WN, Tile::WROWS, Tile::THREADS, Tile::BN>(mine, Tile::template stage_pitch<T>(), smem, g.M, g.Nout,
                                                                        out, res != nullptr, stats, br, eo, g.stat_row0 + mtile, ntile, m0, n0);
+}
+
+// 4 waves, 256 pixels x 128 channels, a 64 x 128 tile per wave (igemm_halo_wide.h).  The store epilogue is the shared one,
+// run once per 64-channel half of the tile: to it the workgroup looks like two <4 x 1>-wave tiles of 64 channels.
+__global__ __launch_bounds__(256, 2) void halo_wide_kernel(HaloGeom g, const void* __restrict__ a, const void* __restrict__ b,
+                                                           void* __restrict__ out, const void* __restrict__ res,
+                                                           float* __restrict__ stats, EpiBnRed br, int mtiles, int ntiles) {
+    typedef HaloWideTile Tile;
+    typedef bf16_t T;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const uint32_t lin = xcd_remap(blockIdx.x, gridDim.x);
+    const int ntile = (int)(lin % (uint32_t)ntiles), mtile = (int)(lin / (uint32_t)ntiles);
+    HaloWideMainloop ml;
+    ml.run(g, a, b, smem, mtile, ntile);
+    const int m0 = mtile * Tile::BM + wave_id() * Tile::WROWS;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        const int n0 = ntile * Tile::BN + half * 64;
+        EpiOperands<T, Tile::WROWS> eo;
+        eo.fetch(res, (stats || br.gelu_bwd) ? br.y : nullptr, g.M, g.Nout, m0, n0, br.res_h, br.res_w, &br.map);
+        const char* mine = ml.stage_out(smem, half);
+        nt_epilogue_store<T, 4, 1, Tile::WROWS, Tile::THREADS, 64>(mine, Tile::stage_pitch, smem, g.M, g.Nout, out, res != nullptr,
+                                                                   stats, br, eo, mtile, ntile * 2 + half, m0, n0);
+    }
+}
+
+static int halo_wide_launch(const HaloGeom& g, const void* a, const void* b, void* out, const void* res, float* stats,
+                            const EpiBnRed& br, hipStream_t stream) {
+    typedef HaloWideTile Tile;
+    const int mtiles = (g.M + Tile::BM - 1) / Tile::BM, ntiles = (g.Nout + Tile::BN - 1) / Tile::BN;
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(halo_wide_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, Tile::LDS) != hipSuccess) {
+            set_error("igemm_halo: cannot raise dynamic LDS to %d bytes", Tile::LDS);
+            return FRHIP_ELAUNCH;
+        }
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(halo_wide_kernel, dim3(mtiles * ntiles), dim3(Tile::THREADS), Tile::LDS, stream, g, a, b, out, res, stats, br, mtiles, ntiles);
+    return check_launch("igemm_halo_wide");
 }
 
 // Tail balancing.  A launch of T = mtiles x ntiles equal tiles on `slots` resident workgroups takes ceil(T / slots) rounds;
@@ -115,6 +156,16 @@ bool halo_applicable(int dtype, int h, int w, int c, int k, int r, int s, int st
 
 // which kernel configuration a problem gets: 0 = <4,1,4,1> (4 waves, 256x64, two workgroups per CU), 1 = <8,1,2,2>,
 // 2 = <4,2,4,2> (8 waves, 256x128, double-buffered halo)
+static int g_halo_wide = getenv("FRHIP_HALO_WIDE") ? atoi(getenv("FRHIP_HALO_WIDE")) : 1;
+static int g_halo_wide_minc = getenv("FRHIP_HALO_WIDE_MINC") ? atoi(getenv("FRHIP_HALO_WIDE_MINC")) : 128;
+static int halo_config(int dtype, int c, int k);
+// 3 = the 64 x 128-per-wave tile (igemm_halo_wide.h): bf16, W <= 28, output channels in whole 128s, tail launches off
+static int halo_config_w(int dtype, int w, int c, int k) {
+    if (g_halo_wide && dtype == FRHIP_DT_BF16 && w <= HaloWideTile::MAXW && (k % 128) == 0 && (c % 64) == 0 && c >= g_halo_wide_minc && !g_halo_tail &&
+        (g_halo_enabled & 3) == 1)
+        return 3;
+    return halo_config(dtype, c, k);
+}
 static int halo_config(int dtype, int c, int k) {
     const int es = dtype == FRHIP_DT_BF16 ? 2 : 4;
     const int nchunks = c / (NT_ROWB / es);
@@ -165,6 +216,7 @@ int halo_run(int dtype, const void* a, const void* b, void* out, const void* res
         if (dtype != FRHIP_DT_BF16 || cfg != 0 || g_halo_tail) { set_error("igemm_halo: operand transform not available for this shape"); return FRHIP_EINVAL; }
         return halo_launch_one<bf16_t, 4, 1, 4, 1, true>(g, a, b, out, res, stats, br, (g.M + 255) / 256, 0, 0, stream);
     }
+    if (halo_config_w(dtype, w, c, k) == 3) return halo_wide_launch(g, a, b, out, res, stats, br, stream);
     if (dtype == FRHIP_DT_BF16) {
         if (cfg == 0) return halo_launch<bf16_t, 4, 1, 1, 2>(g, a, b, out, res, stats, br, stream);
         if (cfg == 1) return halo_launch_one<bf16_t, 8, 1, 2, 2>(g, a, b, out, res, stats, br, (g.M + 255) / 256, 0, 0, stream);
@@ -177,8 +229,9 @@ int halo_run(int dtype, const void* a, const void* b, void* out, const void* res
 }  // namespace frhip
 
 extern "C" int frhip_set_conv_halo(int enabled) {
-    // bits 0-1: 0 off, 1 auto, 2 force the 4-wave tile, 3 force the 8-wave tile; bit 5 set: tail-balancing launch on
-    const int old = frhip::g_halo_enabled | (frhip::g_halo_tail ? 32 : 0);
-    frhip::g_halo_enabled = enabled & 3; frhip::g_halo_tail = (enabled & 32) ? 1 : 0;
+    // bits 0-1: 0 off, 1 auto, 2 force the 4-wave tile, 3 force the 8-wave tile; bit 5 set: tail-balancing launch on;
+    // bit 6 set: the 64 x 128-per-wave tile OFF (it is on by default in auto mode)
+    const int old = frhip::g_halo_enabled | (frhip::g_halo_tail ? 32 : 0) | (frhip::g_halo_wide ? 0 : 64);
+    frhip::g_halo_enabled = enabled & 3; frhip::g_halo_tail = (enabled & 32) ? 1 : 0; frhip::g_halo_wide = (enabled & 64) ? 0 : 1;
     return old;
 }

@@ -134,6 +134,35 @@ def test_halo_kernel_equals_generic_kernel():
             np.testing.assert_allclose(o[2].numpy(), ref[2].numpy(), rtol=0, atol=ref[2].abs().max().item() * 2 ** -7)
 
 
+@pytest.mark.parametrize("case", [(6, 28, 128, 128), (7, 14, 256, 256), (11, 7, 512, 512), (9, 14, 128, 256), (300, 7, 256, 128),
+                                  (3, 20, 128, 384)])
+def test_halo_wide_tile_is_bit_identical_to_the_four_wave_tile(case):
+    """64 x 128 outputs per wave (igemm_halo_wide.h) against 64 x 64 (igemm_halo.h): the same MFMAs in the same order per output,
+    the same rows per BN-partial -> identical outputs AND identical partial sums, forward and data-gradient"""
+    ops = _ops()
+    from frhip._abi import lib
+    n, h, c, k = case
+    x = rnd(80, (n, h, h, c)).bfloat16().cuda()
+    w = (rnd(81, (k, 3, 3, c)) * 0.05).bfloat16().cuda()
+    dy = rnd(82, (n, h, h, k)).bfloat16().cuda()
+    wt = ops.pack_wt(w.float(), torch.bfloat16)
+    res = rnd(83, (n, h, h, c)).bfloat16().cuda()
+    y_bn = rnd(84, (n, h, h, c)).bfloat16().cuda()
+    rows = n * h * h
+    st = ops.bn_finalize(ops.colstats(y_bn.view(rows, c)), rows, torch.ones(c).cuda(), torch.zeros(c).cuda(), None, None)
+    outs = []
+    for mode in (1, 2 | 64):         # auto with the wide tile / the 4-wave tile forced, wide off
+        old = lib().frhip_set_conv_halo(mode)
+        y, part = ops.conv_fwd(x, w, 1, 1)
+        y2, _ = ops.conv_fwd(x, w, 1, 1, want_stats=False)
+        dx, bpart = ops.conv_dgrad(dy, wt, (n, h, h, c), 3, 3, 1, 1, residual=res, bnred=(y_bn, st, True))
+        dx2 = ops.conv_dgrad(dy, wt, (n, h, h, c), 3, 3, 1, 1)
+        lib().frhip_set_conv_halo(old)
+        outs.append((y, part, y2, dx, bpart, dx2))
+    for a, b in zip(*outs):
+        assert a.shape == b.shape and torch.equal(a, b)
+
+
 @pytest.mark.parametrize("case", [(48, 56, 64, 64, 1), (400, 7, 512, 512, 3), (200, 14, 256, 256, 1)])
 def test_halo_tail_balancing_equals_single_launch(case):
     """more tiles than resident workgroups: the full rounds run 256-row tiles and a second launch covers the rest with
