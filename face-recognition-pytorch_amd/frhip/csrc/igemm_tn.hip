@@ -424,31 +424,33 @@ __global__ __launch_bounds__(TN_THREADS, 2) void tn_lin_kernel(TnGeom g, const v
 constexpr int T9_MAXW = 56;
 constexpr int T9_QROWS = 192;                               // 24 pieces of 8 rows >= 64 + 2*56 + 2
 
-template <int WCO, int WCI, int COF, int CIF>
+// NST = LDS stages (operand DMA runs NST - 1 K steps ahead), QROWS = window rows a stage holds (>= 64 + 2 W + 2)
+template <int WCO, int WCI, int COF, int CIF, int NST = 2, int QROWS = T9_QROWS>
 struct T9Cfg {
     static_assert(WCI * CIF * 16 == 64 && COF == 4, "64 input channels per tile");
     static constexpr int NW = WCO * WCI;                     // waves: 4 or 8
-    static constexpr int QPW_MAX = 24 / NW;                  // window pieces per wave (upper bound)
+    static constexpr int QPW_MAX = QROWS / 8 / NW;           // window pieces per wave (every wave issues all of them: fixed DMA count)
     static constexpr int CO_T = WCO * COF * 16;              // 64 or 128 output channels per tile
     static constexpr int P_RB = CO_T * 2;                    // bytes per dy row: 128 or 256
     static constexpr int P_BYTES = TN_KP * P_RB;
     static constexpr int P_PIECES = P_BYTES / 1024 / NW;     // 1-KiB DMA pieces per wave
     static constexpr int P_CHUNKS = P_RB / 16, P_RPP = 1024 / P_RB;
-    static constexpr int Q_BYTES = T9_QROWS * 128;
+    static constexpr int Q_BYTES = QROWS * 128;
     static constexpr int ZERO = P_BYTES + Q_BYTES;           // 64 zero bytes at the end of EACH stage
     static constexpr int STAGE = ZERO + 64;                  // two stages; stage-relative offsets + an immediate
     static constexpr int EP = CIF * 16 * 4 + 16;             // epilogue staging pitch (bytes)
     static constexpr int EPI_BYTES = NW * COF * 16 * EP;
-    static constexpr int LDS = (2 * STAGE > EPI_BYTES) ? 2 * STAGE : EPI_BYTES;
-    static_assert(2 * STAGE <= 65536 + STAGE && STAGE < 65536, "stage base must fit the 16-bit DS offset field");
+    static constexpr int LDS = (NST * STAGE > EPI_BYTES) ? NST * STAGE : EPI_BYTES;
+    static constexpr int DMA_PER_STAGE = P_PIECES + QPW_MAX; // DMA instructions a wave issues per stage
+    static_assert((NST - 1) * STAGE < 65536 && (QROWS / 8) % NW == 0, "stage base must fit the 16-bit DS offset field");
 };
 
-template <int WCO, int WCI, int COF, int CIF, bool XF = false>
+template <int WCO, int WCI, int COF, int CIF, bool XF = false, int NST = 2, int QROWS = T9_QROWS>
 __global__ __launch_bounds__(64 * WCO * WCI, (WCO * WCI > 4 ? 1 : 2))
 void tn_taps9_kernel(TnGeom g, const void* __restrict__ p_ptr, const void* __restrict__ q_ptr, float* __restrict__ out,
                      int co_tiles, int ci_tiles) {
     typedef bf16_t T;
-    typedef T9Cfg<WCO, WCI, COF, CIF> Cfg;
+    typedef T9Cfg<WCO, WCI, COF, CIF, NST, QROWS> Cfg;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = lane_id(), wave = wave_id();
     const TnSlot slot = tn_slot(co_tiles * ci_tiles);
@@ -468,7 +470,7 @@ void tn_taps9_kernel(TnGeom g, const void* __restrict__ p_ptr, const void* __res
         for (int a = 0; a < COF; ++a)
 #pragma unroll
             for (int b = 0; b < CIF; ++b) acc[t][a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    if (threadIdx.x < 8)
+    if (threadIdx.x < 4 * NST)
         *reinterpret_cast<f32x4_t*>(smem + (threadIdx.x >> 2) * Cfg::STAGE + Cfg::ZERO + (threadIdx.x & 3) * 16) = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
     const __amdgpu_buffer_rsrc_t rp = make_rsrc(p_ptr, g.p_bytes);
@@ -489,7 +491,7 @@ void tn_taps9_kernel(TnGeom g, const void* __restrict__ p_ptr, const void* __res
     for (int j = 0; j < Cfg::QPW_MAX; ++j) {
         const int row = (wave + Cfg::NW * j) * 8 + (lane >> 3);
         const int ce = ((lane & 7) ^ tn_swz<128>(row)) * 8;
-        okq[j] = ci0 + ce < g.C;
+        okq[j] = ci0 + ce < g.C && j < qpw;          // pieces past the window: out-of-range offset, zero fill, no traffic
         offq[j] = (uint32_t)(((ks_begin * TN_KP - g.W - 1 + row) * g.C + ci0 + ce) * 2);   // negative pixel -> out of range
     }
     auto stage = [&](int buf) {
@@ -502,7 +504,7 @@ void tn_taps9_kernel(TnGeom g, const void* __restrict__ p_ptr, const void* __res
         }
 #pragma unroll
         for (int j = 0; j < Cfg::QPW_MAX; ++j) {
-            if (j < qpw) glds16<T9_AUX>(rq, sq + (wave + Cfg::NW * j) * 1024, okq[j] ? offq[j] : OOB_OFFSET);
+            glds16<T9_AUX>(rq, sq + (wave + Cfg::NW * j) * 1024, okq[j] ? offq[j] : OOB_OFFSET);
             offq[j] += incq;
         }
     };
@@ -655,26 +657,35 @@ void tn_taps9_kernel(TnGeom g, const void* __restrict__ p_ptr, const void* __res
         }
     };
 
-    // ---- K loop: two LDS stages (unrolled by two so the stage is a compile-time constant), DMA one step ahead
+    // ---- K loop: NST LDS stages (unrolled by NST so the stage is a compile-time constant), DMA NST - 1 steps ahead.
+    //      Two stages leave a load ONE K step (72 MFMAs per wave, ~0.5 us) to arrive; with one wave per SIMD (the 4-wave tile, one
+    //      workgroup per CU) every step then ends waiting for memory.  Three stages (W <= 28: 24 KB each) give it two steps.
+    //      Every wave issues DMA_PER_STAGE loads per stage, so "the stage before the newest has landed" is a counted wait.
     if (ks_begin < ks_end) {
         const int nks = ks_end - ks_begin;
-        stage(0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int pre = 0; pre < NST - 1; ++pre)
+            if (pre < nks) stage(pre);
+        if (NST == 3 && nks > 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(Cfg::DMA_PER_STAGE) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         xform_stage(0, ks_begin);
         __syncthreads();
         auto step = [&](auto buf_c, int it) {
             constexpr int BUF = decltype(buf_c)::value;
-            if (it + 1 < nks && !(FRHIP_ABL & 8)) stage(BUF ^ 1);
+            // refill the stage read one step ago (everyone passed the barrier that ended that step)
+            if (it + NST - 1 < nks && !(FRHIP_ABL & 8)) stage((BUF + NST - 1) % NST);
             compute(buf_c);
             if (it + 1 < nks) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                xform_stage(BUF ^ 1, ks_begin + it + 1);
+                if (NST == 3 && it + 2 < nks) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(Cfg::DMA_PER_STAGE) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                xform_stage((BUF + 1) % NST, ks_begin + it + 1);
                 if constexpr (!(FRHIP_ABL & 1)) __builtin_amdgcn_s_barrier();
             }
         };
-        for (int it = 0; it < nks; it += 2) {
+        for (int it = 0; it < nks; it += NST) {
             step(std::integral_constant<int, 0>{}, it);
             if (it + 1 < nks) step(std::integral_constant<int, 1>{}, it + 1);
+            if constexpr (NST == 3) { if (it + 2 < nks) step(std::integral_constant<int, 2>{}, it + 2); }
         }
     }
     // ---- epilogue: accumulators straight from registers.  D layout: lane holds rows co = a*16 + 4*(lane>>4) + e, column
@@ -750,12 +761,13 @@ static int g_tn_taps9 = 1;
 static int g_t9_narrow = getenv("FRHIP_T9_NARROW") ? atoi(getenv("FRHIP_T9_NARROW")) : 1;
 static int g_t9_lds_pad = getenv("FRHIP_T9_LDS_PAD") ? atoi(getenv("FRHIP_T9_LDS_PAD")) : 83968;
 static int g_t9_maxsteps = getenv("FRHIP_T9_MAXSTEPS") ? atoi(getenv("FRHIP_T9_MAXSTEPS")) : 0;
+static int g_t9_stages = getenv("FRHIP_T9_STAGES") ? atoi(getenv("FRHIP_T9_STAGES")) : 3;      // 4-wave tile, W <= 28: LDS stages
 static int g_t9_slots = getenv("FRHIP_T9_SLOTS") ? atoi(getenv("FRHIP_T9_SLOTS")) : 0;     // experiment: workgroups per weight-gradient launch (fewer than 256 leaves CUs to the main stream alone)
-template <int WCO, int WCI, int COF, int CIF, bool XF = false>
+template <int WCO, int WCI, int COF, int CIF, bool XF = false, int NST = 2, int QROWS = T9_QROWS>
 static int tn_taps9_launch(const TnGeom& g, const void* p, const void* q, float* out, int splits, hipStream_t stream) {
-    typedef T9Cfg<WCO, WCI, COF, CIF> Cfg;
+    typedef T9Cfg<WCO, WCI, COF, CIF, NST, QROWS> Cfg;
     const int co_tiles = (g.Kc + Cfg::CO_T - 1) / Cfg::CO_T, ci_tiles = (g.C + 63) / 64;
-    auto kern = tn_taps9_kernel<WCO, WCI, COF, CIF, XF>;
+    auto kern = tn_taps9_kernel<WCO, WCI, COF, CIF, XF, NST, QROWS>;
     static bool attr_done = false;
     if (!attr_done) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -988,9 +1000,12 @@ static int tn_run(int dtype, const void* p, const void* q, float* out, int n, in
         g.ksteps_per_split = (g.ksteps + splits - 1) / splits;
         splits = (g.ksteps + g.ksteps_per_split - 1) / g.ksteps_per_split;
         float* dst = (kc % 4 == 0) ? tn_pick_dst(g, out, splits, out_elems, ws, ws_bytes) : out;      // slab layout packs co in fours
+        const bool deep = !wide && g_t9_stages == 3 && 64 + 2 * w + 2 <= 128;      // three stages of a 128-row window
         if (xf_scale) rc = wide ? tn_taps9_launch<2, 4, 4, 1, true>(g, p, q, dst, splits, stream)
+                         : deep ? tn_taps9_launch<1, 4, 4, 1, true, 3, 128>(g, p, q, dst, splits, stream)
                                 : tn_taps9_launch<1, 4, 4, 1, true>(g, p, q, dst, splits, stream);
         else rc = wide ? tn_taps9_launch<2, 4, 4, 1>(g, p, q, dst, splits, stream)
+                : deep ? tn_taps9_launch<1, 4, 4, 1, false, 3, 128>(g, p, q, dst, splits, stream)
                        : tn_taps9_launch<1, 4, 4, 1>(g, p, q, dst, splits, stream);
         return rc ? rc : t9_finish(g, out, splits, out_elems, ws, stream);
     }
