@@ -39,6 +39,7 @@ struct HaloGeom {
     // has landed; the activated tensor never exists in HBM (nets/resnet.py:91-93: bn1 -> relu -> conv2)
     const float* xf_scale;
     const float* xf_shift;
+    int wide_big;           // wide tile (igemm_halo_wide.h): m-tiles [0, wide_big) have 256 rows, the rest 192
     int wave_prio;          // > 0: s_setprio for the whole kernel (the critical-path convolutions outrank a co-resident weight gradient)
 };
 

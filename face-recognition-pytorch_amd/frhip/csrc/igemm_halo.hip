@@ -37,19 +37,17 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void halo_kernel(HaloG
                                                                        out, res != nullptr, stats, br, eo, g.stat_row0 + mtile, ntile, m0, n0);
 }
 
-// 4 waves, 256 pixels x 128 channels, a 64 x 128 tile per wave (igemm_halo_wide.h).  The store epilogue is the shared one,
-// run once per 64-channel half of the tile: to it the workgroup looks like two <4 x 1>-wave tiles of 64 channels.
-__global__ __launch_bounds__(256, 2) void halo_wide_kernel(HaloGeom g, const void* __restrict__ a, const void* __restrict__ b,
-                                                           void* __restrict__ out, const void* __restrict__ res,
-                                                           float* __restrict__ stats, EpiBnRed br, int mtiles, int ntiles) {
-    typedef HaloWideTile Tile;
+// 4 waves, 256 (or 192) pixels x 128 channels, a 64 (48) x 128 tile per wave (igemm_halo_wide.h).  The store epilogue is the
+// shared one, run once per 64-channel half of the tile: to it the workgroup looks like two <4 x 1>-wave tiles of 64 channels.
+template <int MT>
+__device__ __forceinline__ void halo_wide_body(const HaloGeom& g, const void* __restrict__ a, const void* __restrict__ b,
+                                               void* __restrict__ out, const void* __restrict__ res, float* __restrict__ stats,
+                                               const EpiBnRed& br, char* smem, int mtile, int ntile, int m_tile0) {
+    typedef HaloWideTile<MT> Tile;
     typedef bf16_t T;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const uint32_t lin = xcd_remap(blockIdx.x, gridDim.x);
-    const int ntile = (int)(lin % (uint32_t)ntiles), mtile = (int)(lin / (uint32_t)ntiles);
-    HaloWideMainloop ml;
-    ml.run(g, a, b, smem, mtile, ntile);
-    const int m0 = mtile * Tile::BM + wave_id() * Tile::WROWS;
+    HaloWideMainloop<MT> ml;
+    ml.run(g, a, b, smem, m_tile0, ntile);
+    const int m0 = m_tile0 + wave_id() * Tile::WROWS;
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
         const int n0 = ntile * Tile::BN + half * 64;
@@ -61,10 +59,56 @@ __global__ __launch_bounds__(256, 2) void halo_wide_kernel(HaloGeom g, const voi
     }
 }
 
-static int halo_wide_launch(const HaloGeom& g, const void* a, const void* b, void* out, const void* res, float* stats,
+__global__ __launch_bounds__(256, 2) void halo_wide_kernel(HaloGeom g, const void* __restrict__ a, const void* __restrict__ b,
+                                                           void* __restrict__ out, const void* __restrict__ res,
+                                                           float* __restrict__ stats, EpiBnRed br, int mtiles, int ntiles) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const uint32_t lin = xcd_remap(blockIdx.x, gridDim.x);
+    const int ntile = (int)(lin % (uint32_t)ntiles), mtile = (int)(lin / (uint32_t)ntiles);
+    // the few 256-row tiles come first (they start first and take longest), then the 192-row ones: a workgroup-uniform branch
+    if (mtile < g.wide_big) halo_wide_body<4>(g, a, b, out, res, stats, br, smem, mtile, ntile, mtile * 256);
+    else halo_wide_body<3>(g, a, b, out, res, stats, br, smem, mtile, ntile, g.wide_big * 256 + (mtile - g.wide_big) * 192);
+}
+
+// Tile plan of a wide launch.  With equal 256-row tiles a launch of T workgroups on 512 resident ones takes ceil(T / 512)
+// rounds and the last one is mostly empty at the ResNet shapes (B = 512: 784 workgroups at 14x14x256, 1568 at 28x28x128,
+// 392 at 7x7x512 -- on shapes that fill whole rounds the same kernel runs 15-25 % faster, tools/bench_halo_rounds.py).
+// Instead: make the number of workgroups a MULTIPLE of the resident ones and fit the rows with two tile heights,
+// `big` tiles of 256 rows and the rest of 192 (MT = 3): 256 big + 192 (T - big) >= M.
+struct HaloWidePlan { int mtiles, big; };
+static int g_wide_slots = getenv("FRHIP_HALO_WIDE_SLOTS") ? atoi(getenv("FRHIP_HALO_WIDE_SLOTS")) : 512;   // 0: equal tiles only
+// Which launches get the mixed plan: bit 0 forward, bit 1 data-gradient.  Measured inside the ResNet50 step (two A/B rounds): with
+// the plan on both 27.83 ms against 27.70 ms with equal tiles, although every launch is faster on an empty chip (14x14x256:
+// 110 -> 103 us) -- in the backward pass each CU also holds a weight-gradient workgroup of the side stream, the resident-slot
+// arithmetic does not apply and the extra tiles only add prologues.  The forward pass runs alone: default = forward only.
+static int g_wide_mix = getenv("FRHIP_HALO_WIDE_MIX") ? atoi(getenv("FRHIP_HALO_WIDE_MIX")) : 1;
+static HaloWidePlan halo_wide_plan(int M, int ntiles, int sign) {
+    const int even = (M + 255) / 256;
+    HaloWidePlan p = {even, even};
+    if (!(g_wide_mix & (sign > 0 ? 1 : 2))) return p;
+    if (g_wide_slots <= 0 || ntiles > g_wide_slots || (g_wide_slots % ntiles) != 0) return p;
+    const int per = g_wide_slots / ntiles;                       // m-tiles per round
+    const double x = (double)even * ntiles / g_wide_slots;       // rounds of equal tiles
+    const double frac = x - (double)(long long)x;
+    const double cost_even = (double)(long long)x + (frac == 0.0 ? 0.0 : (frac <= 0.5 ? 0.7 : 1.0));   // a half-empty round: one workgroup per CU, faster
+    for (int r = 1; r <= 64; ++r) {
+        const long long T = 1LL * per * r;
+        if (T * 256 < M) continue;                               // not enough rows even with big tiles only
+        if (T * 192 > M) break;                                  // small tiles alone overshoot: nothing to balance
+        if (r * 0.8 >= cost_even) break;                         // a 192-row tile costs ~0.8 of a 256-row one
+        const int big = (int)((M - T * 192 + 63) / 64);
+        p.mtiles = (int)T; p.big = big;
+        break;
+    }
+    return p;
+}
+
+static int halo_wide_launch(HaloGeom g, const void* a, const void* b, void* out, const void* res, float* stats,
                             const EpiBnRed& br, hipStream_t stream) {
-    typedef HaloWideTile Tile;
-    const int mtiles = (g.M + Tile::BM - 1) / Tile::BM, ntiles = (g.Nout + Tile::BN - 1) / Tile::BN;
+    typedef HaloWideTile<4> Tile;
+    const int ntiles = (g.Nout + Tile::BN - 1) / Tile::BN;
+    const HaloWidePlan p = halo_wide_plan(g.M, ntiles, g.sign);
+    g.wide_big = p.big;
     static bool attr_done = false;
     if (!attr_done) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(halo_wide_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, Tile::LDS) != hipSuccess) {
@@ -73,7 +117,7 @@ static int halo_wide_launch(const HaloGeom& g, const void* a, const void* b, voi
         }
         attr_done = true;
     }
-    hipLaunchKernelGGL(halo_wide_kernel, dim3(mtiles * ntiles), dim3(Tile::THREADS), Tile::LDS, stream, g, a, b, out, res, stats, br, mtiles, ntiles);
+    hipLaunchKernelGGL(halo_wide_kernel, dim3(p.mtiles * ntiles), dim3(Tile::THREADS), Tile::LDS, stream, g, a, b, out, res, stats, br, p.mtiles, ntiles);
     return check_launch("igemm_halo_wide");
 }
 
@@ -161,7 +205,7 @@ static int g_halo_wide_minc = getenv("FRHIP_HALO_WIDE_MINC") ? atoi(getenv("FRHI
 static int halo_config(int dtype, int c, int k);
 // 3 = the 64 x 128-per-wave tile (igemm_halo_wide.h): bf16, W <= 28, output channels in whole 128s, tail launches off
 static int halo_config_w(int dtype, int w, int c, int k) {
-    if (g_halo_wide && dtype == FRHIP_DT_BF16 && w <= HaloWideTile::MAXW && (k % 128) == 0 && (c % 64) == 0 && c >= g_halo_wide_minc && !g_halo_tail &&
+    if (g_halo_wide && dtype == FRHIP_DT_BF16 && w <= HaloWideTile<4>::MAXW && (k % 128) == 0 && (c % 64) == 0 && c >= g_halo_wide_minc && !g_halo_tail &&
         (g_halo_enabled & 3) == 1)
         return 3;
     return halo_config(dtype, c, k);
@@ -186,7 +230,8 @@ static int halo_config(int dtype, int c, int k) {
 }
 
 // rows of the BN-partial buffer a halo launch writes for an output of m pixels
-int halo_stat_rows(int dtype, int m, int c, int k) {
+int halo_stat_rows(int dtype, int m, int w, int c, int k, int sign) {
+    if (halo_config_w(dtype, w, c, k) == 3) return halo_wide_plan(m, (k + 127) / 128, sign).mtiles;
     const int cfg = halo_config(dtype, c, k);
     if (cfg == 1) return (m + 255) / 256;
     const int bn = cfg == 0 ? 64 : 128;
@@ -208,13 +253,22 @@ int halo_run(int dtype, const void* a, const void* b, void* out, const void* res
     g.H = h; g.W = w; g.C = c; g.M = n * h * w; g.Nout = k; g.Ktot = 9 * c; g.sign = sign;
     g.m_origin = 0; g.stat_row0 = 0;
     g.a_bytes = (uint32_t)ab; g.b_bytes = (uint32_t)bb;
-    g.xf_scale = xf_scale; g.xf_shift = xf_shift;
+    g.xf_scale = xf_scale; g.xf_shift = xf_shift; g.wide_big = 0;
     static const int prio = getenv("FRHIP_HALO_PRIO") ? atoi(getenv("FRHIP_HALO_PRIO")) : 0;
     g.wave_prio = prio;
     const int cfg = halo_config(dtype, c, k);
     if (xf_scale) {
         if (dtype != FRHIP_DT_BF16 || cfg != 0 || g_halo_tail) { set_error("igemm_halo: operand transform not available for this shape"); return FRHIP_EINVAL; }
-        return halo_launch_one<bf16_t, 4, 1, 4, 1, true>(g, a, b, out, res, stats, br, (g.M + 255) / 256, 0, 0, stream);
+        const int wrote = (g.M + 255) / 256;
+        const int rc = halo_launch_one<bf16_t, 4, 1, 4, 1, true>(g, a, b, out, res, stats, br, wrote, 0, 0, stream);
+        // the caller sized the BN-partial buffer with halo_stat_rows, which may plan more (smaller) tiles than this kernel has
+        const int want = halo_stat_rows(dtype, g.M, w, c, k, sign);
+        if (!rc && stats && want > wrote &&
+            hipMemsetAsync(stats + (size_t)wrote * 2 * k, 0, (size_t)(want - wrote) * 2 * k * sizeof(float), stream) != hipSuccess) {
+            set_error("igemm_halo: cannot clear the unused partial rows");
+            return FRHIP_ELAUNCH;
+        }
+        return rc;
     }
     if (halo_config_w(dtype, w, c, k) == 3) return halo_wide_launch(g, a, b, out, res, stats, br, stream);
     if (dtype == FRHIP_DT_BF16) {
@@ -227,6 +281,14 @@ int halo_run(int dtype, const void* a, const void* b, void* out, const void* res
 }
 
 }  // namespace frhip
+
+extern "C" int frhip_set_halo_wide_slots(int slots) {
+    // low 16 bits: resident workgroups to balance for; bits 16-17: which launches get the mixed plan (1 forward, 2 data-gradient)
+    const int old = frhip::g_wide_slots | (frhip::g_wide_mix << 16);
+    frhip::g_wide_slots = slots & 0xffff;
+    if (slots >> 16) frhip::g_wide_mix = (slots >> 16) & 3;
+    return old;
+}
 
 extern "C" int frhip_set_conv_halo(int enabled) {
     // bits 0-1: 0 off, 1 auto, 2 force the 4-wave tile, 3 force the 8-wave tile; bit 5 set: tail-balancing launch on;

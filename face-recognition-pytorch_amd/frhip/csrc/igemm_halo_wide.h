@@ -18,11 +18,14 @@
 
 namespace frhip {
 
+// MT_ = 16-pixel sub-tiles per wave: 4 (256-row workgroup tile) or 3 (192 rows).  The LDS layout is that of the 256-row tile
+// for both, so ONE kernel holds both bodies and a launch can mix tile heights (halo_wide_plan in igemm_halo.hip).
+template <int MT_ = 4>
 struct HaloWideTile {
-    static constexpr int WAVES = 4, THREADS = 256, MT = 4, NTW = 8;      // per wave: 4 x 16 pixels, 8 x 16 channels
-    static constexpr int BM = 256, BN = 128, WROWS = 64;
+    static constexpr int WAVES = 4, THREADS = 256, MT = MT_, NTW = 8;    // per wave: MT x 16 pixels, 8 x 16 channels
+    static constexpr int BM = 64 * MT, BN = 128, WROWS = 16 * MT;
     static constexpr int MAXW = 28;
-    static constexpr int HROWS = ((BM + 2 * MAXW + 2 + 7) / 8) * 8;      // 320
+    static constexpr int HROWS = ((256 + 2 * MAXW + 2 + 7) / 8) * 8;     // 320
     static constexpr int ZROW = HROWS * NT_ROWB;
     static constexpr int HALO_BYTES = ZROW + NT_ROWB;
     static constexpr int DUMP_OFF = HALO_BYTES;
@@ -31,18 +34,19 @@ struct HaloWideTile {
     static constexpr int B_PIECES = BN / 8 / WAVES;                      // 4 one-KiB pieces per wave and tap
     static constexpr int stage_pitch = 64 * 2 + 16;
     static constexpr int LOOP_BYTES = W_OFF + 2 * WBUF_BYTES;
-    static constexpr int EPI_BYTES = WAVES * WROWS * stage_pitch;
+    static constexpr int EPI_BYTES = WAVES * 64 * stage_pitch;
     static constexpr int LDS = LOOP_BYTES > EPI_BYTES ? LOOP_BYTES : EPI_BYTES;
 };
 
+template <int MT_>
 struct HaloWideMainloop {
-    typedef HaloWideTile Tile;
+    typedef HaloWideTile<MT_> Tile;
     typedef bf16_t T;
-    typedef Mma<T>::Frag Frag;
+    typedef typename Mma<T>::Frag Frag;
     f32x4_t acc[Tile::NTW][Tile::MT];
 
     __device__ __forceinline__ void run(const HaloGeom& g, const void* __restrict__ a_ptr, const void* __restrict__ b_ptr,
-                                        char* smem, int mtile, int ntile) {
+                                        char* smem, int m0, int ntile) {
         constexpr int MT = Tile::MT, BKE = 64;
         const int lane = lane_id(), wave = wave_id();
 #pragma unroll
@@ -51,7 +55,6 @@ struct HaloWideMainloop {
             for (int j = 0; j < MT; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
         const __amdgpu_buffer_rsrc_t ra = make_rsrc(a_ptr, g.a_bytes);
         const __amdgpu_buffer_rsrc_t rb = make_rsrc(b_ptr, g.b_bytes);
-        const int m0 = mtile * Tile::BM;
         const int hrows = Tile::BM + 2 * g.W + 2;
         const int npieces = (hrows + 7) >> 3;
         const int p_lo = m0 - g.W - 1;
@@ -85,7 +88,7 @@ struct HaloWideMainloop {
         // of the 16-byte chunk this lane feeds to the MFMA, or the zero row; two 16-bit offsets per register
         const int fi = lane & 15, fg = lane >> 4;
         static_assert(Tile::HALO_BYTES < 65536, "packed fragment offsets");
-        uint32_t xa[9][MT / 2];
+        uint32_t xa[9][(MT + 1) / 2];
         {
             const int HW = g.H * g.W;
 #pragma unroll

@@ -7,7 +7,7 @@
 namespace frhip {
 
 bool halo_applicable(int dtype, int h, int w, int c, int k, int r, int s, int stride, int pad);
-int halo_stat_rows(int dtype, int m, int c, int k);
+int halo_stat_rows(int dtype, int m, int w, int c, int k, int sign);
 bool halo_xf_applicable(int dtype, int h, int w, int c, int k, int r, int s, int stride, int pad);
 int halo_run(int dtype, const void* a, const void* b, void* out, const void* res, float* stats, const EpiBnRed& br,
              int n, int h, int w, int c, int k, int sign, hipStream_t stream, const float* xf_scale = nullptr,
@@ -177,7 +177,7 @@ extern "C" int frhip_nt_block_m(int nout) {
 }
 extern "C" int frhip_conv_stat_rows(int dtype, int m, int k, int h, int w, int c, int r, int s, int stride, int pad) {
     // rows of the stats_partial buffer frhip_conv_fwd writes for an output of m pixels x k channels
-    if (halo_applicable(dtype, h, w, c, k, r, s, stride, pad)) return halo_stat_rows(dtype, m, c, k);
+    if (halo_applicable(dtype, h, w, c, k, r, s, stride, pad)) return halo_stat_rows(dtype, m, w, c, k, +1);
     NtGeom g; g.M = m; g.Nout = k;
     static const int bm_of[5] = {128, 128, 256, 256, 256};
     const int bm = bm_of[nt_pick_tile(dtype, g)];
@@ -244,7 +244,7 @@ extern "C" int frhip_conv_dgrad(int dtype, const void* dy, const void* wt, void*
 
 extern "C" int frhip_dgrad_stat_rows(int dtype, int n, int h, int wd, int c, int k, int r, int s, int stride, int pad) {
     const int m = n * h * wd;
-    if (halo_applicable(dtype, h, wd, k, c, r, s, stride, pad)) return halo_stat_rows(dtype, m, k, c);
+    if (halo_applicable(dtype, h, wd, k, c, r, s, stride, pad)) return halo_stat_rows(dtype, m, wd, k, c, -1);
     NtGeom g; g.M = m; g.Nout = c;
     g.mode = 1; g.stride = stride; g.R = r; g.S = s; g.pad = pad; g.Ho = h; g.Wo = wd; g.C = k;
     if (dgrad_by_parity(g)) {

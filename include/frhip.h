@@ -55,8 +55,14 @@ int frhip_conv_stat_rows(int dtype, int m, int k, int h, int w, int c, int r, in
 int frhip_set_tn_linear(int enabled);
 /* test hook.  bits 0-1: 0 disables the LDS-halo 3x3/s1 kernel (generic NT kernel is used instead), 1 automatic tile choice,
  * 2 forces the 4-wave 256x64 tile (two workgroups per CU), 3 the 8-wave 256x128 tile; bit 5 (32) enables the tail-balancing
- * second launch of smaller tiles.  Returns the old value */
+ * second launch of smaller tiles; bit 6 (64) turns the 64 x 128-per-wave tile of the W <= 28 layers OFF (automatic mode uses it).
+ * Returns the old value */
 int frhip_set_conv_halo(int enabled);
+/* test / tuning hook: resident workgroups the tile plan of the 64 x 128-per-wave halo kernel balances a launch for
+ * (low 16 bits; default 512 = 2 per CU; 0 = equal 256-row tiles only; small values make small test shapes take the mixed
+ * 256 / 192-row plan); bits 16-17, when non-zero: which launches are planned that way (1 forward [default], 2 data-gradient, 3 both).
+ * Returns the old value */
+int frhip_set_halo_wide_slots(int slots);
 /* test / micro-benchmark hook: force the NT tile (0 auto, 1 128x128, 2 256x64, 3 256x128, 4 256x256); returns the old value */
 int frhip_set_nt_tile(int tile);
 int frhip_conv_fwd(int dtype, const void* x, const void* w, void* y, float* stats_partial,
