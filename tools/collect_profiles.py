@@ -50,7 +50,7 @@ with open(os.path.join(P, TAG + "_pmc_mfma_util.txt"), "w") as out:
                 k, v = line.split()
                 vals[cur][k] = float(v)
         for k, v in vals.items():
-            if ("halo_kernel" in k or "taps9" in k) and v.get("SQ_BUSY_CU_CYCLES"):
+            if ("halo_kernel" in k or "halo_wide_kernel" in k or "taps9" in k) and v.get("SQ_BUSY_CU_CYCLES"):
                 out.write("\n[%s] %s\n" % (what, k[:110]))
                 out.write("  MFMA utilisation            %.3f\n" % (v["SQ_VALU_MFMA_BUSY_CYCLES"] / v["SQ_BUSY_CU_CYCLES"] / 4))
                 wc = v["SQ_WAVE_CYCLES"]

@@ -8,6 +8,10 @@ R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/final
 rm -rf $OUT; mkdir -p $OUT
 cd $R
+# PMC traffic passes first: bench.py reports roofline.traffic only from a pass whose kernel-source digest matches this tree
+rm -rf $R/gpurun_out/pmc
+bash tools/pmc_traffic.sh > $OUT/pmc.log 2>&1
+python tools/pmc_traffic_report.py gpurun_out/pmc ${TAG:-r02} > $OUT/pmc_report.log 2>&1
 python bench.py > $OUT/bench.json 2> $OUT/bench.log
 tail -1 $OUT/bench.json | cut -c1-200
 export FRHIP_BENCH_INSTEP=0
@@ -23,7 +27,6 @@ python tools/trace_summary.py $OUT/overlap_trace.csv > $OUT/step_anatomy_overlap
 python tools/trace_summary.py $(ls $OUT/swin/*kernel_trace.csv | head -1) > $OUT/swin_step_anatomy.txt
 python tools/trace_summary.py $(ls $OUT/alt/*kernel_trace.csv | head -1) > $OUT/alt_step_anatomy.txt
 rm -f $OUT/serial/*kernel_trace.csv $OUT/swin/*kernel_trace.csv $OUT/alt/*kernel_trace.csv $OUT/stats/*kernel_trace.csv $OUT/overlap_trace.csv
-bash tools/pmc_traffic.sh > $OUT/pmc.log 2>&1
 # MFMA utilisation / LDS counters of the dominant kernels (256-channel 14x14 layer, B = 512), one rocprofv3 pass per counter group
 for what in fwd dgrad wgrad; do
   bash tools/pmc_run.sh $OUT/pmc_$what $what 14 256 256 > $OUT/pmc_$what.log 2>&1 || true

@@ -38,7 +38,8 @@ with open(out, "w") as fh:
     for _, k, n, f, w, mb in rows:
         fh.write("%-96s %6d %12.1f %12.1f %14.1f\n" % (k[:96], n, f, w, mb))
 # dominant kernel = the bf16 conv implicit GEMMs with the store epilogue (halo + generic NT)
-sel = [r for r in rows if ("halo_kernel" in r[1] or ("nt_kernel" in r[1] and "Li0EEEv" in r[1])) and "DF16b" in r[1] and "halo8" not in r[1]]
+sel = [r for r in rows if "halo_wide_kernel" in r[1] or
+       (("halo_kernel" in r[1] or ("nt_kernel" in r[1] and "Li0EEEv" in r[1])) and "DF16b" in r[1] and "halo8" not in r[1])]
 n = sum(r[2] for r in sel)
 avg = sum(r[2] * r[5] for r in sel) / n * 1e6
 import hashlib
@@ -54,7 +55,7 @@ def csrc_digest():
     return h.hexdigest()[:16]
 
 
-js = {"kernel": "frhip conv implicit GEMM (halo_kernel + nt_kernel, bf16): forward + data-gradient launches",
+js = {"kernel": "frhip conv implicit GEMM (halo_kernel + halo_wide_kernel + nt_kernel, bf16): forward + data-gradient launches",
       "csrc_digest": csrc_digest(),
       "hbm_bytes_per_launch": int(avg), "launches_sampled": n,
       "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes; bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 FETCH_SIZE correction)",
