@@ -77,6 +77,187 @@ __global__ __launch_bounds__(256) void augment_kernel(const uint8_t* __restrict_
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// MotionBlur and ISONoise of the reference chain (/root/reference/utils/data_partial.py:139-143: alb.MotionBlur(p),
+// alb.ISONoise(p, color_shift, intensity)), on the uint8 HWC batch BEFORE the resize, as the chain has them.
+// Both restate published algorithms of packages that are not installed here (albumentations 1.x functional.py, OpenCV
+// filter2D / cvtColor): PARITY UNPINNED, like the rest of this file.
+
+// MotionBlur = cv2.filter2D(img, -1, kernel): correlation with a k x k (k = 3, 5, 7) kernel holding a normalised one-pixel line,
+// anchor at the centre, BORDER_REFLECT_101, float accumulation over the non-zero taps in row-major order, cvRound + saturate to
+// uint8.  The host draws the line (as albumentations does) and passes it zero-padded to 7 x 7 with the centre at (3, 3);
+// ksize[n] == 0: image n is copied.  `lut` (RandomGamma table per image, may be null) is applied to the source bytes first.
+__device__ __forceinline__ int reflect101(int i, int n) {
+    if (n == 1) return 0;
+    while (i < 0 || i >= n) i = i < 0 ? -i : 2 * (n - 1) - i;
+    return i;
+}
+
+__global__ __launch_bounds__(256) void motion_blur_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out,
+                                                          const uint8_t* __restrict__ lut, const float* __restrict__ kernels,
+                                                          const int32_t* __restrict__ ksize, int B, int H, int W) {
+    const size_t total = (size_t)B * H * W;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const int x = (int)(idx % W), y = (int)((idx / W) % H), n = (int)(idx / ((size_t)W * H));
+        const uint8_t* img = in + (size_t)n * H * W * 3;
+        const uint8_t* tb = lut ? lut + (size_t)n * 256 : nullptr;
+        const int k = ksize ? ksize[n] : 0;
+        uint8_t* o = out + idx * 3;
+        if (k <= 0) {
+            const uint8_t* p = img + ((size_t)y * W + x) * 3;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) o[c] = tb ? tb[p[c]] : p[c];
+            continue;
+        }
+        const float* kn = kernels + (size_t)n * 49;
+        const int a = k >> 1;
+        float acc[3] = {0.f, 0.f, 0.f};
+        for (int i = -a; i <= a; ++i) {
+            const int yy = reflect101(y + i, H);
+            for (int j = -a; j <= a; ++j) {
+                const float wgt = kn[(i + 3) * 7 + (j + 3)];
+                if (wgt == 0.f) continue;
+                const uint8_t* p = img + ((size_t)yy * W + reflect101(x + j, W)) * 3;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) acc[c] += wgt * (float)(tb ? tb[p[c]] : p[c]);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float r = rintf(acc[c]);
+            o[c] = (uint8_t)(r < 0.f ? 0.f : (r > 255.f ? 255.f : r));
+        }
+    }
+}
+
+// OpenCV's float RGB <-> HLS (H in degrees [0, 360], L and S in [0, 1]), restated from imgproc's RGB2HLS_f / HLS2RGB_f
+struct Hls { float h, l, s; };
+__device__ __forceinline__ Hls rgb2hls(float r, float g, float b) {
+    float vmax = r, vmin = r;
+    if (vmax < g) vmax = g;
+    if (vmax < b) vmax = b;
+    if (vmin > g) vmin = g;
+    if (vmin > b) vmin = b;
+    float diff = vmax - vmin;
+    Hls o; o.l = (vmax + vmin) * 0.5f; o.h = 0.f; o.s = 0.f;
+    if (diff > 1.1920929e-07f) {
+        o.s = o.l < 0.5f ? diff / (vmax + vmin) : diff / (2.f - vmax - vmin);
+        diff = 60.f / diff;
+        if (vmax == r) o.h = (g - b) * diff;
+        else if (vmax == g) o.h = (b - r) * diff + 120.f;
+        else o.h = (r - g) * diff + 240.f;
+        if (o.h < 0.f) o.h += 360.f;
+    }
+    return o;
+}
+__device__ __forceinline__ void hls2rgb(float h, float l, float s, float& r, float& g, float& b) {
+    if (s == 0.f) { r = g = b = l; return; }
+    const float p2 = l <= 0.5f ? l * (1.f + s) : l + s - l * s;
+    const float p1 = 2.f * l - p2;
+    h *= (6.f / 360.f);
+    if (h < 0.f) do h += 6.f; while (h < 0.f);
+    else if (h >= 6.f) do h -= 6.f; while (h >= 6.f);
+    int sector = (int)floorf(h);
+    h -= (float)sector;
+    if ((unsigned)sector >= 6u) { sector = 0; h = 0.f; }
+    float tab[4];
+    tab[0] = p2; tab[1] = p1; tab[2] = p1 + (p2 - p1) * (1.f - h); tab[3] = p1 + (p2 - p1) * h;
+    const int sd[6][3] = {{1, 3, 0}, {1, 0, 2}, {3, 0, 1}, {0, 2, 1}, {0, 1, 3}, {2, 1, 0}};
+    b = tab[sd[sector][0]]; g = tab[sd[sector][1]]; r = tab[sd[sector][2]];
+}
+
+// ISONoise, pass 1: per-image partial sums of the L channel (cv2.meanStdDev accumulates in double): partial[n][blk][2]
+constexpr int ISO_BLOCKS = 16;
+__global__ __launch_bounds__(256) void iso_stats_kernel(const uint8_t* __restrict__ img, double* __restrict__ partial, int H, int W) {
+    const int n = blockIdx.y, blk = blockIdx.x;
+    const uint8_t* p = img + (size_t)n * H * W * 3;
+    const float inv = (float)(1.0 / 255.0);
+    double s1 = 0.0, s2 = 0.0;
+    for (int i = blk * 256 + threadIdx.x; i < H * W; i += ISO_BLOCKS * 256) {
+        const Hls v = rgb2hls((float)p[3 * i] * inv, (float)p[3 * i + 1] * inv, (float)p[3 * i + 2] * inv);
+        s1 += (double)v.l; s2 += (double)v.l * (double)v.l;
+    }
+    __shared__ double red[2][256];
+    red[0][threadIdx.x] = s1; red[1][threadIdx.x] = s2;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) { red[0][threadIdx.x] += red[0][threadIdx.x + st]; red[1][threadIdx.x] += red[1][threadIdx.x + st]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { partial[((size_t)n * ISO_BLOCKS + blk) * 2] = red[0][0]; partial[((size_t)n * ISO_BLOCKS + blk) * 2 + 1] = red[1][0]; }
+}
+
+// counter-based generator for the device-drawn noise: Philox-4x32-10 (Salmon et al. 2011), key = per-image seed, counter = pixel
+__device__ __forceinline__ void philox4x32(uint32_t c0, uint32_t c1, uint32_t k0, uint32_t k1, uint32_t (&o)[4]) {
+    uint32_t c[4] = {c0, c1, 0u, 0u};
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n1 = (uint32_t)p1, n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1, n3 = (uint32_t)p0;
+        c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    o[0] = c[0]; o[1] = c[1]; o[2] = c[2]; o[3] = c[3];
+}
+__device__ __forceinline__ float u01(uint32_t x) { return ((float)(x >> 8) + 0.5f) * (1.f / 16777216.f); }      // (0, 1)
+
+// ISONoise, pass 2 (albumentations functional.iso_noise): hue += N(0, color_shift * 360 * intensity) (wrapped into [0, 360]),
+// L += Poisson(std(L) * intensity * 255) / 255 * (1 - L), back to RGB, * 255, truncated to uint8.
+// params[n] = (color_shift, intensity); intensity <= 0: image n is copied.  The draws are either explicit inputs (lum_noise int32 /
+// color_noise float32, one per pixel: parity tests) or made here from seeds[n] (production).
+__global__ __launch_bounds__(256) void iso_noise_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out,
+                                                        const double* __restrict__ partial, const float* __restrict__ params,
+                                                        const int32_t* __restrict__ lum_noise, const float* __restrict__ color_noise,
+                                                        const uint64_t* __restrict__ seeds, int B, int H, int W) {
+    const size_t total = (size_t)B * H * W;
+    const float inv = (float)(1.0 / 255.0);
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const int n = (int)(idx / ((size_t)W * H));
+        const uint8_t* p = in + idx * 3;
+        uint8_t* o = out + idx * 3;
+        const float cshift = params[2 * n], intensity = params[2 * n + 1];
+        if (!(intensity > 0.f)) { o[0] = p[0]; o[1] = p[1]; o[2] = p[2]; continue; }
+        double s1 = 0.0, s2 = 0.0;
+        for (int k = 0; k < ISO_BLOCKS; ++k) { s1 += partial[((size_t)n * ISO_BLOCKS + k) * 2]; s2 += partial[((size_t)n * ISO_BLOCKS + k) * 2 + 1]; }
+        const double cnt = (double)H * (double)W, mean = s1 / cnt;
+        double var = s2 / cnt - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const float lam = (float)(sqrt(var) * (double)intensity * 255.0);
+        const float sigma = cshift * 360.f * intensity;
+        float cn, ln;
+        if (lum_noise) { ln = (float)lum_noise[idx]; cn = color_noise[idx]; }
+        else {
+            uint32_t r[4];
+            const uint64_t pix = idx - (size_t)n * W * H;
+            philox4x32((uint32_t)pix, (uint32_t)(pix >> 32), (uint32_t)seeds[n], (uint32_t)(seeds[n] >> 32), r);
+            const float ra = sqrtf(-2.f * logf(u01(r[0]))), th = 6.2831853f * u01(r[1]);
+            cn = sigma * ra * cosf(th);
+            if (lam >= 10.f) {                         // normal approximation with continuity correction
+                const float z = sqrtf(-2.f * logf(u01(r[2]))) * cosf(6.2831853f * u01(r[3]));
+                ln = floorf(lam + sqrtf(lam) * z + 0.5f);
+                if (ln < 0.f) ln = 0.f;
+            } else {                                   // inversion by sequential search
+                const float u = u01(r[2]);
+                float pk = expf(-lam), cdf = pk;
+                int k = 0;
+                while (u > cdf && k < 64) { ++k; pk *= lam / (float)k; cdf += pk; }
+                ln = (float)k;
+            }
+        }
+        Hls v = rgb2hls((float)p[0] * inv, (float)p[1] * inv, (float)p[2] * inv);
+        v.h += cn;
+        if (v.h < 0.f) v.h += 360.f;
+        if (v.h > 360.f) v.h -= 360.f;
+        v.l = v.l + (ln / 255.f) * (1.f - v.l);
+        float r_, g_, b_;
+        hls2rgb(v.h, v.l, v.s, r_, g_, b_);
+        const float rgb[3] = {r_ * 255.f, g_ * 255.f, b_ * 255.f};
+#pragma unroll
+        for (int c = 0; c < 3; ++c) o[c] = (uint8_t)(rgb[c] < 0.f ? 0.f : (rgb[c] > 255.f ? 255.f : rgb[c]));      // astype(uint8): truncation
+    }
+}
+
 }  // namespace frhip
 
 using namespace frhip;
@@ -102,4 +283,35 @@ extern "C" int frhip_augment_u8(const uint8_t* in, float* out, const int32_t* fl
 extern "C" int frhip_augment_u8_lut(const uint8_t* in, const uint8_t* lut, float* out, const int32_t* flip, const int32_t* holes,
                                     int nholes, int b, int hin, int win, int size, hipStream_t stream) {
     return augment_run(in, out, flip, holes, lut, nholes, b, hin, win, size, stream);
+}
+
+extern "C" int frhip_motion_blur_u8(const uint8_t* in, uint8_t* out, const uint8_t* lut, const float* kernels, const int32_t* ksize,
+                                    int b, int h, int w, hipStream_t stream) {
+    if (!in || !out || in == out || b <= 0 || h <= 0 || w <= 0 || (ksize && !kernels)) {
+        set_error("frhip_motion_blur_u8: bad arguments (b=%d h=%d w=%d; out must not alias in)", b, h, w);
+        return FRHIP_EINVAL;
+    }
+    size_t blocks = ((size_t)b * h * w + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(motion_blur_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, in, out, lut, kernels, ksize, b, h, w);
+    return check_launch("frhip_motion_blur_u8");
+}
+
+extern "C" int frhip_iso_noise_scratch_doubles(int b) { return b * ISO_BLOCKS * 2; }
+
+extern "C" int frhip_iso_noise_u8(const uint8_t* in, uint8_t* out, double* scratch, const float* params, const int32_t* lum_noise,
+                                  const float* color_noise, const uint64_t* seeds, int b, int h, int w, hipStream_t stream) {
+    if (!in || !out || !scratch || !params || b <= 0 || h <= 0 || w <= 0 || ((lum_noise == nullptr) != (color_noise == nullptr)) ||
+        (!lum_noise && !seeds)) {
+        set_error("frhip_iso_noise_u8: bad arguments (b=%d h=%d w=%d; explicit noise needs both arrays, device noise needs seeds)", b, h, w);
+        return FRHIP_EINVAL;
+    }
+    hipLaunchKernelGGL(iso_stats_kernel, dim3(ISO_BLOCKS, b), dim3(256), 0, stream, in, scratch, h, w);
+    int rc = check_launch("frhip_iso_noise_u8(stats)");
+    if (rc) return rc;
+    size_t blocks = ((size_t)b * h * w + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(iso_noise_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, in, out, scratch, params, lum_noise, color_noise,
+                       seeds, b, h, w);
+    return check_launch("frhip_iso_noise_u8");
 }

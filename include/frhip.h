@@ -352,6 +352,21 @@ int frhip_augment_u8(const uint8_t* in, float* out, const int32_t* flip, const i
  * ((i / 255) ** gamma * 255 truncated to uint8, gamma = uniform(gamma_limit) / 100) applied to the source bytes before Resize */
 int frhip_augment_u8_lut(const uint8_t* in, const uint8_t* lut, float* out, const int32_t* flip, const int32_t* holes,
                          int nholes, int b, int hin, int win, int size, frhip_stream_t stream);
+/* alb.MotionBlur of the chain (utils/data_partial.py:139-140) on the uint8 HWC batch, before Resize: out = cv2.filter2D(in, -1,
+ * kernel) per image -- correlation, anchor at the centre, BORDER_REFLECT_101, float accumulation, round-half-even + saturate.
+ * kernels float [b][7][7]: the k x k line kernel (k = ksize[n] in {3, 5, 7}) zero-padded with its centre at (3, 3); ksize int32 [b],
+ * 0 = image copied (ksize NULL: all copied).  lut (may be NULL): RandomGamma tables applied to the source bytes first.
+ * out must not alias in. */
+int frhip_motion_blur_u8(const uint8_t* in, uint8_t* out, const uint8_t* lut, const float* kernels, const int32_t* ksize,
+                         int b, int h, int w, frhip_stream_t stream);
+/* alb.ISONoise of the chain (utils/data_partial.py:142-143; albumentations functional.iso_noise) on the uint8 HWC batch:
+ * RGB/255 -> HLS; hue += N(0, color_shift * 360 * intensity) wrapped to [0, 360]; L += Poisson(std(L) * intensity * 255) / 255 * (1 - L);
+ * -> RGB * 255 truncated to uint8.  params float [b][2] = (color_shift, intensity), intensity <= 0: image copied.
+ * Draws: lum_noise int32 [b][h][w] + color_noise float [b][h][w] (already scaled) when given (tests), else generated on the device
+ * from seeds uint64 [b] (Philox-4x32-10, counter = pixel).  scratch: frhip_iso_noise_scratch_doubles(b) doubles. */
+int frhip_iso_noise_scratch_doubles(int b);
+int frhip_iso_noise_u8(const uint8_t* in, uint8_t* out, double* scratch, const float* params, const int32_t* lum_noise,
+                       const float* color_noise, const uint64_t* seeds, int b, int h, int w, frhip_stream_t stream);
 
 /* ---- optimizer: torch.optim.SGD(momentum, weight_decay).step() + torch.nn.utils.clip_grad_norm_ of the training step
  * (model/FR_PartialFC.py:153-160, :181-190) as multi-tensor kernels.  A chunk is a run of at most

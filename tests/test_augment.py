@@ -113,3 +113,176 @@ def test_augment_kernel_with_random_gamma_matches_oracle(shape):
     got = t.apply(torch.from_numpy(img).cuda(), flip, holes, gamma).cpu().numpy()
     np.testing.assert_array_equal(got, augment_ref.augment(img, size, flip, holes, gamma))
     assert not np.array_equal(got[0], augment_ref.augment(img[:1], size, flip[:1], holes[:1])[0])     # the table did something
+
+
+def _full_conf(size=112):
+    conf = _conf(size, aug=("RandomGammaContrast", "RandomMotionBlur", "ISONoise", "RandomHorizontalFlip", "RandomErasing"))
+    ia = conf.img_augmenation
+    ia.gamma_p, ia.gamma_s, ia.blur_p, ia.iso_p, ia.c_shift, ia.intensity = 0.5, (80, 120), 0.6, 0.6, (0.01, 0.05), (0.1, 0.5)
+    return conf
+
+
+def test_oracle_motion_blur_properties():
+    """line kernels: max(|dx|, |dy|) + 1 pixels, end points set, 8-connected, sum 1; a centred one-pixel 'line' is the identity;
+    constant images stay constant; a horizontal line through the centre averages along rows with reflect-101 borders"""
+    for k in (3, 5, 7):
+        for (xs, ys, xe, ye) in [(0, 0, k - 1, k - 1), (0, k - 1, k - 1, 0), (0, 1, k - 1, 1), (1, 0, 1, k - 1), (0, 0, k - 1, 1), (k - 1, 2, 0, 0)]:
+            pts = augment_ref.line_points(xs, ys, xe, ye)
+            assert len(pts) == max(abs(xe - xs), abs(ye - ys)) + 1 and pts[0] == (xs, ys) and pts[-1] == (xe, ye)
+            assert all(max(abs(a[0] - b[0]), abs(a[1] - b[1])) == 1 for a, b in zip(pts, pts[1:]))
+            kern = augment_ref.motion_kernel(k, xs, ys, xe, ye)
+            assert abs(kern.sum() - 1) < 1e-6 and (kern > 0).sum() == len(pts)
+    rng = np.random.default_rng(2)
+    img = rng.integers(0, 256, (20, 24, 3), dtype=np.uint8)
+    ident = np.zeros((3, 3), dtype=np.float32)
+    ident[1, 1] = 1
+    np.testing.assert_array_equal(augment_ref.motion_blur(img, ident), img)
+    assert (augment_ref.motion_blur(np.full((9, 9, 3), 200, np.uint8), augment_ref.motion_kernel(5, 0, 0, 4, 4)) == 200).all()
+    row = augment_ref.motion_blur(img, augment_ref.motion_kernel(3, 0, 1, 2, 1)).astype(int)
+    src = img.astype(int)
+    want = np.rint((src[:, [1] + list(range(0, 23))] + src + src[:, list(range(1, 24)) + [22]]).astype(np.float32) / 3)
+    assert np.abs(row - want).max() <= 1          # fp32 accumulation of thirds vs exact thirds: at most one level at ties
+
+
+def test_oracle_hls_round_trip_and_iso_noise_properties():
+    rng = np.random.default_rng(3)
+    rgb = rng.random((64, 64, 3)).astype(np.float32)
+    h, l, s = augment_ref.rgb2hls(rgb)
+    assert h.min() >= 0 and h.max() <= 360 and l.min() >= 0 and l.max() <= 1 and s.min() >= 0 and s.max() <= 1 + 1e-6
+    np.testing.assert_allclose(augment_ref.hls2rgb(h, l, s), rgb, atol=2e-6)
+    grey = np.repeat(rng.random((8, 8, 1)).astype(np.float32), 3, axis=2)
+    hg, lg, sg = augment_ref.rgb2hls(grey)
+    assert (hg == 0).all() and (sg == 0).all() and np.allclose(lg, grey[..., 0])
+    img = rng.integers(0, 256, (32, 32, 3), dtype=np.uint8)
+    zero = augment_ref.iso_noise(img, np.zeros((32, 32), np.int64), np.zeros((32, 32), np.float32))
+    assert np.abs(zero.astype(int) - img.astype(int)).max() <= 1            # no draws: the HLS round trip, truncated
+    bright = augment_ref.iso_noise(img, np.full((32, 32), 40), np.zeros((32, 32), np.float32))
+    assert (bright.astype(int).sum(2) >= zero.astype(int).sum(2)).all() and bright.mean() > zero.mean() + 5       # luminance only goes up
+    lam = augment_ref.iso_lambda(img, 0.3)
+    assert 0 < lam < 0.5 * 0.3 * 255
+
+
+def test_device_transform_blur_and_iso_draws():
+    from utils.device_transform import DeviceTransform
+    t = DeviceTransform(_full_conf(), seed=23)
+    ks, kern = t.draw_blur(300)
+    on = ks > 0
+    assert 140 < on.sum() < 220 and set(np.unique(ks)) <= {0, 3, 5, 7} and (kern[~on] == 0).all()
+    np.testing.assert_allclose(kern[on].sum((1, 2)), 1.0, rtol=1e-5)
+    for k in (3, 5, 7):                     # nothing outside the centred k x k window
+        m = np.ones((7, 7), bool)
+        o = 3 - k // 2
+        m[o:o + k, o:o + k] = False
+        assert (kern[ks == k][:, m] == 0).all()
+    # the host's line drawing and the oracle's are two restatements of the same iterator
+    for k in (3, 5, 7):
+        for xs in range(k):
+            for ys in range(k):
+                for xe in range(k):
+                    for ye in range(k):
+                        if (xs, ys) == (xe, ye):
+                            continue
+                        o = 3 - k // 2
+                        np.testing.assert_array_equal(DeviceTransform.line_kernel(k, xs, ys, xe, ye)[o:o + k, o:o + k],
+                                                      augment_ref.motion_kernel(k, xs, ys, xe, ye))
+    params, seeds = t.draw_iso(300)
+    on = params[:, 1] > 0
+    assert 140 < on.sum() < 220 and (params[~on] == 0).all() and seeds.dtype == np.uint64 and len(np.unique(seeds)) == 300
+    assert (params[on, 0] >= 0.01).all() and (params[on, 0] <= 0.05).all() and (params[on, 1] >= 0.1).all() and (params[on, 1] <= 0.5).all()
+    plain = DeviceTransform(_conf(), seed=1)
+    assert plain.draw_blur(4) is None and plain.draw_iso(4) is None
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(6, 112, 112, 112), (3, 90, 130, 112)])
+def test_motion_blur_and_iso_noise_kernels_match_oracle(shape):
+    """the whole chain with every decision explicit (gamma, blur kernels, noise draws, flip, holes): MotionBlur bit-exact (same
+    float32 accumulation order), ISONoise within one 8-bit level of the numpy restatement (the float HLS arithmetic is the same
+    sequence of operations; compilers may contract a multiply-add), then the integer resize / normalize exactly on top"""
+    from utils.device_transform import DeviceTransform
+    b, h, w, size = shape
+    rng = np.random.default_rng(29)
+    img = rng.integers(0, 256, (b, h, w, 3), dtype=np.uint8)
+    img[1] = (img[1] // 32) * 32                                         # flat patches: grey / saturated pixels, hue sectors
+    t = DeviceTransform(_full_conf(size), seed=31)
+    gamma = t.draw_gamma(b)
+    gamma[0], gamma[2] = 0.9, np.nan
+    ks, kern = t.draw_blur(b)
+    ks[0], kern[0] = 7, DeviceTransform.line_kernel(7, 0, 6, 6, 1)
+    ks[1], kern[1] = 3, DeviceTransform.line_kernel(3, 1, 0, 1, 2)
+    ks[2], kern[2] = 0, 0
+    params, seeds = t.draw_iso(b)
+    params[0], params[1], params[2] = (0.05, 0.5), (0.0, 0.0), (0.02, 0.3)
+    x = torch.from_numpy(img).cuda()
+    # --- blur alone (gamma folded in): bit-exact
+    blurred = t.blur_noise(x, gamma, (ks, kern), None).cpu().numpy()
+    want_b = []
+    for n in range(b):
+        im = img[n]
+        if np.isfinite(gamma[n]) and gamma[n] > 0:
+            im = augment_ref.gamma_table(float(gamma[n]))[im]
+        o = 3 - ks[n] // 2
+        want_b.append(augment_ref.motion_blur(im, kern[n][o:o + ks[n], o:o + ks[n]]) if ks[n] else im)
+    np.testing.assert_array_equal(blurred, np.stack(want_b))
+    assert not np.array_equal(blurred[0], want_b[2] if b < 1 else img[0])
+    # --- noise with explicit draws on top of the blurred batch
+    lum = np.zeros((b, h, w), dtype=np.int32)
+    col = np.zeros((b, h, w), dtype=np.float32)
+    iso_ref = []
+    for n in range(b):
+        if params[n, 1] > 0:
+            lam = augment_ref.iso_lambda(want_b[n], params[n, 1])
+            lum[n] = rng.poisson(lam, (h, w))
+            col[n] = rng.normal(0, params[n, 0] * 360 * params[n, 1], (h, w)).astype(np.float32)
+            iso_ref.append((lum[n], col[n]))
+        else:
+            iso_ref.append(None)
+    noisy = t.blur_noise(x, gamma, (ks, kern), (params, seeds), (lum, col)).cpu().numpy()
+    want_n = np.stack([augment_ref.iso_noise(want_b[n], *iso_ref[n]) if iso_ref[n] else want_b[n] for n in range(b)])
+    diff = np.abs(noisy.astype(int) - want_n.astype(int))
+    assert diff.max() <= 1 and (diff > 0).mean() < 1e-3
+    np.testing.assert_array_equal(noisy[1], want_b[1])                   # intensity 0: copied
+    assert np.abs(noisy[0].astype(int) - want_b[0].astype(int)).mean() > 1
+    # --- and the fused resize / flip / normalize / dropout kernel on top: same result as the oracle chain on the device's bytes
+    flip, holes = t.draw(b)
+    got = t.apply(x, flip, holes, gamma, (ks, kern), (params, seeds), (lum, col)).cpu().numpy()
+    np.testing.assert_array_equal(got, augment_ref.augment(noisy, size, flip, holes))
+
+
+@pytest.mark.gpu
+def test_iso_noise_device_generator_statistics():
+    """production mode: draws made on the device from per-image seeds.  Same seed -> same bytes; different seeds differ; on a flat
+    grey-free image the luminance lift has the Poisson mean / variance the transform prescribes and the hue shift is centred."""
+    from utils.device_transform import DeviceTransform
+    b, h, w = 4, 128, 128
+    rng = np.random.default_rng(37)
+    base = np.empty((b, h, w, 3), dtype=np.uint8)
+    base[:] = rng.integers(0, 256, (1, h, w, 3), dtype=np.uint8)         # the same textured image four times
+    t = DeviceTransform(_full_conf(), seed=41)
+    params = np.tile(np.array([[0.03, 0.4]], np.float32), (b, 1))
+    params[3] = (0.03, 0.075)                                            # lambda ~ 3: the inversion branch of the generator
+    seeds = np.array([5, 5, 6, 7], dtype=np.uint64)
+    x = torch.from_numpy(base).cuda()
+    out = t.blur_noise(x, None, None, (params, seeds)).cpu().numpy()
+    np.testing.assert_array_equal(out[0], out[1])
+    assert (out[0] != out[2]).mean() > 0.5
+    # reference point: the same kernel with all-zero explicit draws (HLS round trip + truncation), so the 8-bit truncation bias
+    # cancels in the difference
+    zero = t.blur_noise(x, None, None, (params, seeds), (np.zeros((b, h, w), np.int32), np.zeros((b, h, w), np.float32))).cpu().numpy()
+    for n in (0, 3):
+        lam = augment_ref.iso_lambda(base[n], params[n, 1])
+        assert (lam >= 10) == (n == 0)
+        _, l0, _ = augment_ref.rgb2hls(zero[n].astype(np.float32) / np.float32(255))
+        h1, l1, _ = augment_ref.rgb2hls(out[n].astype(np.float32) / np.float32(255))
+        ok = l0 < 0.8                                                    # L' = L + k/255 (1 - L): recover k where it is well conditioned
+        k = (l1[ok] - l0[ok]) / (1 - l0[ok]) * 255
+        assert abs(k.mean() - lam) < 0.05 * lam + 0.25, (k.mean(), lam)
+        if n == 0:
+            assert 0.7 * lam < k.var() < 1.5 * lam + 2.0, (k.var(), lam)   # Poisson: variance = mean (+ quantisation noise)
+    # hue noise: centred, with the prescribed spread, on well-saturated mid-tone pixels (hue is ill-conditioned elsewhere)
+    h0, l0, s0 = augment_ref.rgb2hls(zero[2].astype(np.float32) / np.float32(255))
+    h2, _, _ = augment_ref.rgb2hls(out[2].astype(np.float32) / np.float32(255))
+    sel = (s0 > 0.5) & (l0 > 0.3) & (l0 < 0.6)
+    dh = (h2[sel] - h0[sel] + 180) % 360 - 180
+    sigma = 0.03 * 360 * 0.4
+    assert abs(dh.mean()) < 0.3 and 0.8 * sigma < dh.std() < 1.3 * sigma, (dh.mean(), dh.std(), sigma)
