@@ -26,6 +26,11 @@ for p in (ROOT, PKG):
     if p not in sys.path:
         sys.path.insert(0, p)
 
+# More hardware queues than HIP's default of 4: with RCCL's and the process group's streams alive, the weight-gradient side
+# stream must not be multiplexed onto the main stream's queue (nets/_backbone.side_stream also probes for that at run time).
+# Read by the HIP runtime when it initialises, i.e. at the first device call, not at import.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 

@@ -25,6 +25,8 @@ def _ctype(decl):
         return ctypes.c_void_p
     if base == "int":
         return ctypes.c_int
+    if d.startswith("long long"):
+        return ctypes.c_longlong
     if base == "float":
         return ctypes.c_float
     if base == "double":

@@ -243,3 +243,18 @@ extern "C" int frhip_scatter_rows(const float* src, const int64_t* index, float*
     hipLaunchKernelGGL(scatter_rows_kernel, dim3(blocks), dim3(256), 0, stream, src, index, dst, n, d);
     return check_launch("frhip_scatter_rows");
 }
+
+// One wave that keeps a hardware queue busy for `ticks` of the constant-rate wall clock (100 MHz on MI355X) and does nothing
+// else: the probe nets/_backbone.py uses to find a side stream that really runs CONCURRENTLY with the main stream.  HIP
+// multiplexes streams onto GPU_MAX_HW_QUEUES (default 4) hardware queues; once RCCL and the process group have taken their
+// streams, a freshly created stream can land on the main stream's queue and "the weight gradients on the side stream" then
+// run strictly after whatever the main stream enqueued first (measured: 31.3 ms per step instead of 26.1).
+__global__ void spin_kernel(long long ticks) {
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+extern "C" int frhip_spin(long long ticks, hipStream_t stream) {
+    if (ticks < 0 || ticks > 100000000LL) { frhip::set_error("frhip_spin: ticks out of range"); return FRHIP_EINVAL; }
+    hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, stream, ticks);
+    return frhip::check_launch("frhip_spin");
+}

@@ -42,6 +42,9 @@ typedef void* frhip_stream_t;
 
 const char* frhip_last_error(void);
 int frhip_abi_version(void);
+/* stream-concurrency probe: one wave that occupies `stream`'s hardware queue for `ticks` of the 100-MHz wall clock (<= 1e8).
+ * nets/_backbone.py times two of them on two streams to find a side stream that does not share the main stream's hardware queue. */
+int frhip_spin(long long ticks, frhip_stream_t stream);
 
 /* ---- convolution = MFMA implicit GEMM.  nn.Conv2d(bias=False): nets/resnet.py:23-46, used at :89-103, :232 ---- */
 /* y[n,ho,wo,k] = conv(x[n,h,w,c], w[k,r,s,c]); stats_partial (may be NULL) receives per-row-tile
