@@ -8,14 +8,10 @@
 namespace frhip {
 
 template <typename T, int WM, int WN, int MT, int HBUFS, bool XF = false>
-__global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void halo_kernel(HaloGeom g, const void* __restrict__ a,
-                                                                         const void* __restrict__ b, void* __restrict__ out,
-                                                                         const void* __restrict__ res, float* __restrict__ stats,
-                                                                         EpiBnRed br, int mtiles, int ntiles) {
+__device__ __forceinline__ void halo_body(const HaloGeom& g, const void* __restrict__ a, const void* __restrict__ b,
+                                          void* __restrict__ out, const void* __restrict__ res, float* __restrict__ stats,
+                                          const EpiBnRed& br, char* smem, int mtile, int ntile) {
     typedef HaloTile<T, WM, WN, MT, HBUFS> Tile;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const uint32_t lin = xcd_remap(blockIdx.x, gridDim.x);
-    const int ntile = (int)(lin % (uint32_t)ntiles), mtile = (int)(lin / (uint32_t)ntiles);
     HaloMainloop<T, WM, WN, MT, HBUFS, XF> ml;
     ml.run(g, a, b, smem, mtile, ntile);
     if constexpr (FRHIP_ABL & 16) {
@@ -35,6 +31,33 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void halo_kernel(HaloG
     const char* mine = ml.template stage_out<T>(smem);
     nt_epilogue_store<T, WM, WN, Tile::WROWS, Tile::THREADS, Tile::BN>(mine, Tile::template stage_pitch<T>(), smem, g.M, g.Nout,
                                                                        out, res != nullptr, stats, br, eo, g.stat_row0 + mtile, ntile, m0, n0);
+}
+
+template <typename T, int WM, int WN, int MT, int HBUFS, bool XF = false>
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void halo_kernel(HaloGeom g, const void* __restrict__ a,
+                                                                         const void* __restrict__ b, void* __restrict__ out,
+                                                                         const void* __restrict__ res, float* __restrict__ stats,
+                                                                         EpiBnRed br, int mtiles, int ntiles) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const uint32_t lin = xcd_remap(blockIdx.x, gridDim.x);
+    const int ntile = (int)(lin % (uint32_t)ntiles), mtile = (int)(lin / (uint32_t)ntiles);
+    halo_body<T, WM, WN, MT, HBUFS, XF>(g, a, b, out, res, stats, br, smem, mtile, ntile);
+}
+
+// The 4-wave 256 x 64 tile with MIXED tile heights (see halo_mixed_plan below): m-tiles [0, wide_big) have 256 rows (MT = 4), the rest
+// 192 (MT = 3); both bodies in one kernel behind a workgroup-uniform branch.  m0 = m_origin + mtile * BM inside the body, so the
+// 192-row body gets m_origin = 64 * big: 64 big + 192 mtile = 256 big + 192 (mtile - big).
+__global__ __launch_bounds__(256, 2) void halo_mixed_kernel(HaloGeom g, const void* __restrict__ a, const void* __restrict__ b,
+                                                            void* __restrict__ out, const void* __restrict__ res,
+                                                            float* __restrict__ stats, EpiBnRed br, int mtiles, int ntiles) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const uint32_t lin = xcd_remap(blockIdx.x, gridDim.x);
+    const int ntile = (int)(lin % (uint32_t)ntiles), mtile = (int)(lin / (uint32_t)ntiles);
+    if (mtile < g.wide_big) halo_body<bf16_t, 4, 1, 4, 1>(g, a, b, out, res, stats, br, smem, mtile, ntile);
+    else {
+        g.m_origin = 64 * g.wide_big;
+        halo_body<bf16_t, 4, 1, 3, 1>(g, a, b, out, res, stats, br, smem, mtile, ntile);
+    }
 }
 
 // 4 waves, 256 (or 192) pixels x 128 channels, a 64 (48) x 128 tile per wave (igemm_halo_wide.h).  The store epilogue is the
@@ -77,12 +100,16 @@ __global__ __launch_bounds__(256, 2) void halo_wide_kernel(HaloGeom g, const voi
 // `big` tiles of 256 rows and the rest of 192 (MT = 3): 256 big + 192 (T - big) >= M.
 struct HaloWidePlan { int mtiles, big; };
 static int g_wide_slots = getenv("FRHIP_HALO_WIDE_SLOTS") ? atoi(getenv("FRHIP_HALO_WIDE_SLOTS")) : 512;   // 0: equal tiles only
-// Which launches get the mixed plan: bit 0 forward, bit 1 data-gradient.  Measured inside the ResNet50 step (two A/B rounds): with
-// the plan on both 27.83 ms against 27.70 ms with equal tiles, although every launch is faster on an empty chip (14x14x256:
-// 110 -> 103 us) -- in the backward pass each CU also holds a weight-gradient workgroup of the side stream, the resident-slot
-// arithmetic does not apply and the extra tiles only add prologues.  The forward pass runs alone: default = forward only.
-static int g_wide_mix = getenv("FRHIP_HALO_WIDE_MIX") ? atoi(getenv("FRHIP_HALO_WIDE_MIX")) : 1;
-static HaloWidePlan halo_wide_plan(int M, int ntiles, int sign) {
+// Which launches get the mixed plan: bit 0 forward, bit 1 data-gradient.  OFF by default.  Measured inside the ResNet50 step (A/B
+// rounds on one box each): every planned launch is faster on an empty chip (14x14x256: 110 -> 103 us on the wide tile), and with
+// the wide tile in both directions the plan gained 0.2 ms in the forward launches and lost 0.15 ms in the data-gradient ones (in the
+// backward pass each CU also holds a weight-gradient workgroup of the side stream: the resident-slot arithmetic does not apply
+// and the extra tiles only add prologues).  But the forward pass is better off on the 4-wave 64-wide tile altogether (wide tile
+// forward + data-gradient 26.48 ms, forward only 26.94, data-gradient only 26.33), and on THAT tile, with twice the tiles per
+// launch, equal heights win: 26.26 (off) / 26.42 (forward) / 26.72 ms (both).
+static int g_wide_mix = getenv("FRHIP_HALO_WIDE_MIX") ? atoi(getenv("FRHIP_HALO_WIDE_MIX")) : 0;
+// ntiles = column tiles of the kernel that will run (128 channels wide for the wide tile, 64 for the 4-wave tile)
+static HaloWidePlan halo_mixed_plan(int M, int ntiles, int sign) {
     const int even = (M + 255) / 256;
     HaloWidePlan p = {even, even};
     if (!(g_wide_mix & (sign > 0 ? 1 : 2))) return p;
@@ -95,9 +122,9 @@ static HaloWidePlan halo_wide_plan(int M, int ntiles, int sign) {
         const long long T = 1LL * per * r;
         if (T * 256 < M) continue;                               // not enough rows even with big tiles only
         if (T * 192 > M) break;                                  // small tiles alone overshoot: nothing to balance
-        if (r * 0.8 >= cost_even) break;                         // a 192-row tile costs ~0.8 of a 256-row one
         const int big = (int)((M - T * 192 + 63) / 64);
-        p.mtiles = (int)T; p.big = big;
+        const double cost = ((double)big + 0.8 * (double)(T - big)) / (double)per;      // a 192-row tile costs ~0.8 of a 256-row one
+        if (cost < 0.97 * cost_even) { p.mtiles = (int)T; p.big = big; }
         break;
     }
     return p;
@@ -107,7 +134,7 @@ static int halo_wide_launch(HaloGeom g, const void* a, const void* b, void* out,
                             const EpiBnRed& br, hipStream_t stream) {
     typedef HaloWideTile<4> Tile;
     const int ntiles = (g.Nout + Tile::BN - 1) / Tile::BN;
-    const HaloWidePlan p = halo_wide_plan(g.M, ntiles, g.sign);
+    const HaloWidePlan p = halo_mixed_plan(g.M, ntiles, g.sign);
     g.wide_big = p.big;
     static bool attr_done = false;
     if (!attr_done) {
@@ -119,6 +146,24 @@ static int halo_wide_launch(HaloGeom g, const void* a, const void* b, void* out,
     }
     hipLaunchKernelGGL(halo_wide_kernel, dim3(p.mtiles * ntiles), dim3(Tile::THREADS), Tile::LDS, stream, g, a, b, out, res, stats, br, p.mtiles, ntiles);
     return check_launch("igemm_halo_wide");
+}
+
+static int halo_mixed_launch(HaloGeom g, const HaloWidePlan& p, const void* a, const void* b, void* out, const void* res, float* stats,
+                             const EpiBnRed& br, hipStream_t stream) {
+    typedef HaloTile<bf16_t, 4, 1, 4, 1> Tile;
+    const int ntiles = (g.Nout + Tile::BN - 1) / Tile::BN;
+    const int lds = Tile::template lds_bytes<bf16_t>();
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(halo_mixed_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
+            set_error("igemm_halo: cannot raise dynamic LDS to %d bytes", lds);
+            return FRHIP_ELAUNCH;
+        }
+        attr_done = true;
+    }
+    g.wide_big = p.big; g.m_origin = 0; g.stat_row0 = 0;
+    hipLaunchKernelGGL(halo_mixed_kernel, dim3(p.mtiles * ntiles), dim3(Tile::THREADS), lds, stream, g, a, b, out, res, stats, br, p.mtiles, ntiles);
+    return check_launch("igemm_halo_mixed");
 }
 
 // Tail balancing.  A launch of T = mtiles x ntiles equal tiles on `slots` resident workgroups takes ceil(T / slots) rounds;
@@ -204,8 +249,9 @@ static int g_halo_wide = getenv("FRHIP_HALO_WIDE") ? atoi(getenv("FRHIP_HALO_WID
 static int g_halo_wide_minc = getenv("FRHIP_HALO_WIDE_MINC") ? atoi(getenv("FRHIP_HALO_WIDE_MINC")) : 128;
 static int halo_config(int dtype, int c, int k);
 // 3 = the 64 x 128-per-wave tile (igemm_halo_wide.h): bf16, W <= 28, output channels in whole 128s, tail launches off
-static int halo_config_w(int dtype, int w, int c, int k) {
-    if (g_halo_wide && dtype == FRHIP_DT_BF16 && w <= HaloWideTile<4>::MAXW && (k % 128) == 0 && (c % 64) == 0 && c >= g_halo_wide_minc && !g_halo_tail &&
+static int g_halo_wide_dirs = getenv("FRHIP_HALO_WIDE_DIRS") ? atoi(getenv("FRHIP_HALO_WIDE_DIRS")) : 2;    // bit 0 forward, bit 1 data-gradient
+static int halo_config_w(int dtype, int w, int c, int k, int sign) {
+    if (g_halo_wide && (g_halo_wide_dirs & (sign > 0 ? 1 : 2)) && dtype == FRHIP_DT_BF16 && w <= HaloWideTile<4>::MAXW && (k % 128) == 0 && (c % 64) == 0 && c >= g_halo_wide_minc && !g_halo_tail &&
         (g_halo_enabled & 3) == 1)
         return 3;
     return halo_config(dtype, c, k);
@@ -231,8 +277,9 @@ static int halo_config(int dtype, int c, int k) {
 
 // rows of the BN-partial buffer a halo launch writes for an output of m pixels
 int halo_stat_rows(int dtype, int m, int w, int c, int k, int sign) {
-    if (halo_config_w(dtype, w, c, k) == 3) return halo_wide_plan(m, (k + 127) / 128, sign).mtiles;
+    if (halo_config_w(dtype, w, c, k, sign) == 3) return halo_mixed_plan(m, (k + 127) / 128, sign).mtiles;
     const int cfg = halo_config(dtype, c, k);
+    if (cfg == 0 && dtype == FRHIP_DT_BF16 && !g_halo_tail) return halo_mixed_plan(m, (k + 63) / 64, sign).mtiles;
     if (cfg == 1) return (m + 255) / 256;
     const int bn = cfg == 0 ? 64 : 128;
     return halo_plan(m, (k + bn - 1) / bn, cfg == 0 ? 512 : 256, g_halo_tail != 0).rows();
@@ -270,8 +317,12 @@ int halo_run(int dtype, const void* a, const void* b, void* out, const void* res
         }
         return rc;
     }
-    if (halo_config_w(dtype, w, c, k) == 3) return halo_wide_launch(g, a, b, out, res, stats, br, stream);
+    if (halo_config_w(dtype, w, c, k, sign) == 3) return halo_wide_launch(g, a, b, out, res, stats, br, stream);
     if (dtype == FRHIP_DT_BF16) {
+        if (cfg == 0 && !g_halo_tail) {
+            const HaloWidePlan p = halo_mixed_plan(g.M, (k + 63) / 64, sign);
+            if (p.big != p.mtiles) return halo_mixed_launch(g, p, a, b, out, res, stats, br, stream);
+        }
         if (cfg == 0) return halo_launch<bf16_t, 4, 1, 1, 2>(g, a, b, out, res, stats, br, stream);
         if (cfg == 1) return halo_launch_one<bf16_t, 8, 1, 2, 2>(g, a, b, out, res, stats, br, (g.M + 255) / 256, 0, 0, stream);
         return halo_launch<bf16_t, 4, 2, 2, 1>(g, a, b, out, res, stats, br, stream);
@@ -283,10 +334,13 @@ int halo_run(int dtype, const void* a, const void* b, void* out, const void* res
 }  // namespace frhip
 
 extern "C" int frhip_set_halo_wide_slots(int slots) {
-    // low 16 bits: resident workgroups to balance for; bits 16-17: which launches get the mixed plan (1 forward, 2 data-gradient)
-    const int old = frhip::g_wide_slots | (frhip::g_wide_mix << 16);
+    // low 16 bits: resident workgroups to balance for; bit 20 set: bits 16-17 = which launches get the mixed-height plan
+    // (1 forward, 2 data-gradient); bit 21 set: bits 18-19 = which launches may use the 64 x 128-per-wave tile.
+    // The returned old value has bits 20 and 21 set, so passing it back restores everything.
+    const int old = frhip::g_wide_slots | (frhip::g_wide_mix << 16) | (frhip::g_halo_wide_dirs << 18) | (3 << 20);
     frhip::g_wide_slots = slots & 0xffff;
-    if (slots >> 16) frhip::g_wide_mix = (slots >> 16) & 3;
+    if (slots & (1 << 20)) frhip::g_wide_mix = (slots >> 16) & 3;
+    if (slots & (1 << 21)) frhip::g_halo_wide_dirs = (slots >> 18) & 3;
     return old;
 }
 

@@ -61,10 +61,11 @@ int frhip_set_tn_linear(int enabled);
  * second launch of smaller tiles; bit 6 (64) turns the 64 x 128-per-wave tile of the W <= 28 layers OFF (automatic mode uses it).
  * Returns the old value */
 int frhip_set_conv_halo(int enabled);
-/* test / tuning hook: resident workgroups the tile plan of the 64 x 128-per-wave halo kernel balances a launch for
- * (low 16 bits; default 512 = 2 per CU; 0 = equal 256-row tiles only; small values make small test shapes take the mixed
- * 256 / 192-row plan); bits 16-17, when non-zero: which launches are planned that way (1 forward [default], 2 data-gradient, 3 both).
- * Returns the old value */
+/* test / tuning hook of the halo kernels' tile plan.  Low 16 bits: resident workgroups a launch is balanced for (default 512 = 2 per
+ * CU; 0 = equal 256-row tiles only; small values make small test shapes take the mixed 256 / 192-row plan).  Bit 20 set: bits
+ * 16-17 = which launches get the mixed plan (1 forward, 2 data-gradient, 3 both; default 0: none).  Bit 21 set: bits 18-19 = which
+ * launches may use the 64 x 128-per-wave tile (1 forward, 2 data-gradient [default], 3 both).  Returns the old value with bits 20
+ * and 21 set, so passing it back restores the previous state */
 int frhip_set_halo_wide_slots(int slots);
 /* test / micro-benchmark hook: force the NT tile (0 auto, 1 128x128, 2 256x64, 3 256x128, 4 256x256); returns the old value */
 int frhip_set_nt_tile(int tile);

@@ -151,6 +151,7 @@ def test_halo_wide_tile_is_bit_identical_to_the_four_wave_tile(case):
     rows = n * h * h
     st = ops.bn_finalize(ops.colstats(y_bn.view(rows, c)), rows, torch.ones(c).cuda(), torch.zeros(c).cuda(), None, None)
     outs = []
+    old_plan = lib().frhip_set_halo_wide_slots(0 | (3 << 18) | (1 << 21))       # equal tiles; wide tile allowed in both directions
     for mode in (1, 2 | 64):         # auto with the wide tile / the 4-wave tile forced, wide off
         old = lib().frhip_set_conv_halo(mode)
         y, part = ops.conv_fwd(x, w, 1, 1)
@@ -161,16 +162,20 @@ def test_halo_wide_tile_is_bit_identical_to_the_four_wave_tile(case):
         outs.append((y, part, y2, dx, bpart, dx2))
     for a, b in zip(*outs):
         assert a.shape == b.shape and torch.equal(a, b)
-    # mixed tile heights (256- and 192-row tiles, as many workgroups as fill whole rounds of `slots` resident ones): the same
-    # outputs bit for bit; the BN partial sums come in more rows and add up to the same column sums
+    # mixed tile heights (256- and 192-row tiles, as many workgroups as fill whole rounds of `slots` resident ones), on the wide
+    # tile (dirs 3) and on the 4-wave tile (wide off: conv_halo bit 6): the same outputs bit for bit; the BN partial sums come in
+    # more rows and add up to the same column sums
     for slots in (8, 16):
-        old_slots = lib().frhip_set_halo_wide_slots(slots | (3 << 16))      # forward and data-gradient
-        y, part = ops.conv_fwd(x, w, 1, 1)
-        dx, bpart = ops.conv_dgrad(dy, wt, (n, h, h, c), 3, 3, 1, 1, residual=res, bnred=(y_bn, st, True))
-        lib().frhip_set_halo_wide_slots(old_slots)
-        assert torch.equal(y, outs[0][0]) and torch.equal(dx, outs[0][3])
-        np.testing.assert_allclose(part.sum(0).cpu().numpy(), outs[0][1].sum(0).cpu().numpy(), rtol=1e-4, atol=1e-2)
-        np.testing.assert_allclose(bpart.sum(0).cpu().numpy(), outs[0][4].sum(0).cpu().numpy(), rtol=1e-4, atol=1e-2)
+        for mode in (1, 1 | 64):
+            lib().frhip_set_halo_wide_slots(slots | (3 << 16) | (3 << 18) | (3 << 20))      # plan for forward and data-gradient
+            old = lib().frhip_set_conv_halo(mode)
+            y, part = ops.conv_fwd(x, w, 1, 1)
+            dx, bpart = ops.conv_dgrad(dy, wt, (n, h, h, c), 3, 3, 1, 1, residual=res, bnred=(y_bn, st, True))
+            lib().frhip_set_conv_halo(old)
+            assert torch.equal(y, outs[0][0]) and torch.equal(dx, outs[0][3])
+            np.testing.assert_allclose(part.sum(0).cpu().numpy(), outs[0][1].sum(0).cpu().numpy(), rtol=1e-4, atol=1e-2)
+            np.testing.assert_allclose(bpart.sum(0).cpu().numpy(), outs[0][4].sum(0).cpu().numpy(), rtol=1e-4, atol=1e-2)
+    lib().frhip_set_halo_wide_slots(old_plan)
 
 
 @pytest.mark.parametrize("case", [(48, 56, 64, 64, 1), (400, 7, 512, 512, 3), (200, 14, 256, 256, 1)])
