@@ -19,7 +19,10 @@ _STEM_FUSED_REDUCE = os.environ.get("FRHIP_STEM_FUSED_REDUCE", "1") == "1"     #
 # matrix pipe already waits on instruction issue; it costs more (+15 us per forward conv2, +20 us per weight gradient) than
 # the 23-91 us HBM pass it removes wherever that pass is short, and the long passes (64 channels) sit on the layers whose
 # weight-gradient K step is shortest.  DESIGN.md section 4.8.
-_FUSE_BN1 = os.environ.get("FRHIP_FUSE_BN1", "0") == "1"
+# 0: a1 = relu(bn1(y1)) is a pass of its own.  1: folded into conv2's forward AND weight-gradient kernels (a1 never exists).
+# 2: folded into the forward kernel only; the backward pass re-forms a1 with a BatchNorm-apply pass on the SIDE stream right in front
+#    of conv2's weight gradient, where it hides beside the main stream's matrix work (the forward pass has nothing to hide it under)
+_FUSE_BN1 = int(os.environ.get("FRHIP_FUSE_BN1", "0"))
 # hand a weight gradient to the side stream BEFORE the data-gradient of the same dy is enqueued (the side stream waits for what
 # the main stream holds at the hand-over): 27.16 -> 26.9 ms on the ResNet50 step.  One hand-over per block instead of one per
 # weight gradient (fewer barrier packets, but conv2's weight gradient starts a data-gradient later) measured 27.3 -> 27.7: off.
@@ -241,7 +244,9 @@ class BackwardCtx:
     def wgrad(self, dy, x, gview, r, s, stride, pad, bnrelu=None):
         """bnrelu = BN state: x is the INPUT of a BatchNorm + ReLU whose output (the convolution's real operand) was never
         materialised; the weight-gradient kernel re-forms it in LDS"""
-        if bnrelu is not None:
+        if bnrelu is not None and _FUSE_BN1 == 2:
+            fn = lambda: ops.conv_wgrad(dy, ops.bn_apply(x, bnrelu, relu=True), gview, r, s, stride, pad)      # noqa: E731
+        elif bnrelu is not None:
             fn = lambda: ops.conv_wgrad_bnrelu(dy, x, bnrelu, gview, r, s, stride, pad)       # noqa: E731
         else:
             fn = lambda: ops.conv_wgrad(dy, x, gview, r, s, stride, pad)                      # noqa: E731
