@@ -181,10 +181,14 @@ def side_stream(device):
     taken theirs, a new stream can land on the queue of the main stream: everything then executes in enqueue order and the
     overlap is gone (ResNet50 step, 1-rank RCCL group: 31.3 ms against 26.1 ms).  So candidates are probed with two timed spin
     kernels and the first one that overlaps is kept."""
-    key = torch.device(device).index
+    main = torch.cuda.current_stream(device)
+    key = (torch.device(device).index, main.cuda_stream)       # probed against THIS main stream; another one gets its own probe
     if key not in _SIDE_STREAMS:
-        main = torch.cuda.current_stream(device)
-        tried = [torch.cuda.Stream(device=device)]
+        reuse = [v for k, v in _SIDE_STREAMS.items() if k[0] == key[0] and k[1] != "rejected" and v != main]
+        tried = [reuse[0] if reuse else torch.cuda.Stream(device=device)]
+        if torch.cuda.is_current_stream_capturing():              # no timing inside a graph capture: streams are graph branches there
+            _SIDE_STREAMS[key] = tried[0]
+            return tried[0]
         if _PROBE_STREAMS:
             while not _runs_beside(main, tried[-1]) and len(tried) < 12:
                 tried.append(torch.cuda.Stream(device=device))
@@ -196,7 +200,7 @@ def side_stream(device):
         if os.environ.get("FRHIP_DEBUG_STREAMS"):
             print("frhip: side stream = candidate %d of %d probed" % (len(tried), len(tried)), flush=True)
         _SIDE_STREAMS[key] = tried[-1]
-        _SIDE_STREAMS[("rejected", key)] = tried[:-1]      # keep them alive: their pool slots stay taken, later streams differ
+        _SIDE_STREAMS[(key[0], "rejected", key[1])] = tried[:-1]      # keep them alive: later candidates get other queues
     return _SIDE_STREAMS[key]
 
 
