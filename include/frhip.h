@@ -40,6 +40,12 @@ typedef void* frhip_stream_t;
 #define FRHIP_DT_BF16 0
 #define FRHIP_DT_F32 1
 
+/* Threading contract.  Every compute entry point is asynchronous on the stream it is given, keeps no state between calls and may
+ * be called concurrently from several host threads on different streams (frhip_last_error() is per thread).
+ * The frhip_set_* functions are TEST / TUNING HOOKS, not part of that contract: they flip process-global kernel-selection
+ * switches (which tile, which kernel variant -- never the arithmetic contract beyond what each hook documents), are not
+ * synchronised, and must only be called while no other thread is inside the library.  The product path (nets/, model/,
+ * bench.py) never changes them (one read-only query, frhip_set_winattn_mfma(-1)); the defaults are the measured-best settings (environment overrides are read once, at load). */
 const char* frhip_last_error(void);
 int frhip_abi_version(void);
 /* stream-concurrency probe: one wave that occupies `stream`'s hardware queue for `ticks` of the 100-MHz wall clock (<= 1e8).
