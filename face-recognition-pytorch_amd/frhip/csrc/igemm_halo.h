@@ -39,6 +39,7 @@ struct HaloGeom {
     // has landed; the activated tensor never exists in HBM (nets/resnet.py:91-93: bn1 -> relu -> conv2)
     const float* xf_scale;
     const float* xf_shift;
+    FastDiv d_hw, d_w;      // pixel decode of the per-tile prologue without integer division instructions
     int wide_big;           // wide tile (igemm_halo_wide.h): m-tiles [0, wide_big) have 256 rows, the rest 192
     int wave_prio;          // > 0: s_setprio for the whole kernel (the critical-path convolutions outrank a co-resident weight gradient)
 };
@@ -165,7 +166,7 @@ struct HaloMainloop {
                 const int m = m0 + q;
                 int y = 0, x = 0;
                 const bool live = m < g.M;
-                if (live) { const int rem = m % HW; y = rem / g.W; x = rem - y * g.W; }
+                if (live) { const int rem = m - (int)fdiv((uint32_t)m, g.d_hw) * HW; y = (int)fdiv((uint32_t)rem, g.d_w); x = rem - y * g.W; }
 #pragma unroll
                 for (int tap = 0; tap < 9; ++tap) {
                     const int dy = g.sign * (tap / 3 - 1), dx = g.sign * (tap % 3 - 1);

@@ -301,6 +301,7 @@ int halo_run(int dtype, const void* a, const void* b, void* out, const void* res
     g.m_origin = 0; g.stat_row0 = 0;
     g.a_bytes = (uint32_t)ab; g.b_bytes = (uint32_t)bb;
     g.xf_scale = xf_scale; g.xf_shift = xf_shift; g.wide_big = 0;
+    g.d_hw = make_fastdiv((uint32_t)(h * w)); g.d_w = make_fastdiv((uint32_t)w);
     static const int prio = getenv("FRHIP_HALO_PRIO") ? atoi(getenv("FRHIP_HALO_PRIO")) : 0;
     g.wave_prio = prio;
     const int cfg = halo_config(dtype, c, k);

@@ -97,7 +97,7 @@ struct HaloWideMainloop {
                 const int m = m0 + q;
                 int y = 0, x = 0;
                 const bool live = m < g.M;
-                if (live) { const int rem = m % HW; y = rem / g.W; x = rem - y * g.W; }
+                if (live) { const int rem = m - (int)fdiv((uint32_t)m, g.d_hw) * HW; y = (int)fdiv((uint32_t)rem, g.d_w); x = rem - y * g.W; }
 #pragma unroll
                 for (int tap = 0; tap < 9; ++tap) {
                     const int dy = g.sign * (tap / 3 - 1), dx = g.sign * (tap % 3 - 1);
