@@ -47,6 +47,7 @@ class SGD(torch.optim.SGD):
         self._keep = None
         self._coef = self._norm = self._pin = None
         self._pin_next = 0
+        self._early = {}             # group index -> stream its update already runs on (step_group_early)
 
     # ------------------------------------------------------------------------------------------------
     def _options_ok(self):
@@ -94,9 +95,74 @@ class SGD(torch.optim.SGD):
         buf.copy_(slot, non_blocking=True)
         return buf, len(host)
 
-    def _fallback(self, clip):
+    def _group_table(self, gi, g, clip_sig, clip):
+        """-> (cached chunk table of parameter group gi or None when it has no gradients, entries); (False, None): not servable"""
+        mom = g["momentum"] != 0
+        entries = []
+        for p in g["params"]:
+            gr = p.grad
+            if gr is not None:
+                entries.append((p, gr, self.state[p].get("momentum_buffer") if mom else None, gi))
+        if not entries:
+            return None, None
+        key = (gi, clip_sig) + tuple((p.data_ptr(), gr.data_ptr(), 0 if m is None else m.data_ptr(), p.numel()) for p, gr, m, _ in entries)
+        hit = self._tables.get(key)
+        if hit is None:
+            fixed = []
+            for p, gr, m, _ in entries:
+                if mom and (m is None or not _dense_same_layout(p.data, m)):
+                    m = self.state[p]["momentum_buffer"] = torch.zeros_like(p.data, memory_format=torch.preserve_format)
+                fixed.append((p, gr, m, gi))
+            entries = fixed
+            clip_ids = set() if clip is None else {id(p) for p in clip[0]}
+            inside = [id(p) in clip_ids for p, _, _, _ in entries]
+            if not self._tensors_ok(entries) or (any(inside) and not all(inside)):
+                return False, None
+            device = entries[0][0].device
+            table, n = self._build_table(entries, device)
+            hit = (table, n, all(inside), torch.empty(n, dtype=torch.float32, device=device))
+            if len(self._tables) >= 16:
+                self._tables.clear()
+            key = (gi, clip_sig) + tuple((p.data_ptr(), gr.data_ptr(), 0 if m is None else m.data_ptr(), p.numel()) for p, gr, m, _ in entries)
+            self._tables[key] = hit
+            if self._coef is None or self._coef.device != device:
+                self._coef = torch.ones(2, dtype=torch.float32, device=device)
+        return hit, entries
+
+    @torch.no_grad()
+    def step_group_early(self, gi, stream):
+        """Update parameter group `gi` NOW, on `stream`, from the gradients it already has -- for a group that takes no part in the
+        gradient clip (the PartialFC class centres: their gradient is final when the head's backward has run, a whole backbone
+        backward before step(); their 1.25-GB update then runs beside it instead of after it).  step() skips the group and makes
+        its stream wait for `stream`.  Returns False (and does nothing) when the fused path cannot serve the group."""
+        if not self._options_ok() or gi in self._early:
+            return False
+        g = self.param_groups[gi]
+        hit, entries = self._group_table(gi, g, ("early",), None)
+        if not hit:
+            return False
+        groups = (_Group * len(self.param_groups))()
+        for k, gg in enumerate(self.param_groups):
+            groups[k] = _Group(float(gg["lr"]), float(gg["weight_decay"]), float(gg["momentum"]), 0.0)
+        stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(stream):
+            check(lib().frhip_sgd_multi(ctypes.c_void_p(hit[0].data_ptr()), hit[1], ctypes.cast(groups, ctypes.c_void_p), len(groups),
+                                        None, ops._s()), "frhip_sgd_multi")
+        self._early[gi] = stream
+        self._keep_early = entries
+        return True
+
+    def _fallback(self, clip, done=()):
+        """torch's own step; `done` = group indices step_group_early has already updated (their gradients are hidden meanwhile)"""
         self._norm = torch.nn.utils.clip_grad_norm_(list(clip[0]), float(clip[1])) if clip is not None else None
+        hidden = []
+        for gi in done:
+            for p in self.param_groups[gi]["params"]:
+                hidden.append((p, p.grad))
+                p.grad = None
         super().step()
+        for p, g in hidden:
+            p.grad = g
 
     @torch.no_grad()
     def step(self, closure=None, clip=None):
@@ -108,52 +174,31 @@ class SGD(torch.optim.SGD):
                 loss = closure()
         if clip is not None:
             clip = (list(clip[0]), float(clip[1]))
+        early, self._early = self._early, {}
+        for gi, st in early.items():
+            torch.cuda.current_stream().wait_stream(st)
+            if clip is not None and {id(p) for p in self.param_groups[gi]["params"]} & {id(p) for p in clip[0]}:
+                raise RuntimeError("frhip.optim.SGD: group %d was updated by step_group_early but takes part in the gradient clip" % gi)
         if not self._options_ok():
-            self._fallback(clip)
+            self._fallback(clip, early)
             return loss
         clip_sig = None if clip is None else (id(clip[0][0]) if clip[0] else 0, len(clip[0]))
-        clip_ids = None
         # One chunk table per parameter group, cached by the pointer + size signature of its (parameter, gradient, momentum)
         # triples (the size matters: the caching allocator hands a freed block to a tensor of another size at the same
         # address, and PartialFC's `index = positive` branch changes the row count of its parameter from step to step): PartialFC swaps the sampled class-centre parameter of the LAST group every step, which then rebuilds a
         # ~100-chunk table instead of the whole model's.
         hits, keep = [], []
         for gi, g in enumerate(self.param_groups):
-            mom = g["momentum"] != 0
-            entries = []
-            for p in g["params"]:
-                gr = p.grad
-                if gr is not None:
-                    entries.append((p, gr, self.state[p].get("momentum_buffer") if mom else None, gi))
-            if not entries:
+            if gi in early:                                # updated during the backward pass already (step_group_early)
                 hits.append(None)
                 continue
-            key = (gi, clip_sig) + tuple((p.data_ptr(), gr.data_ptr(), 0 if m is None else m.data_ptr(), p.numel()) for p, gr, m, _ in entries)
-            hit = self._tables.get(key)
-            if hit is None:
-                fixed = []
-                for p, gr, m, _ in entries:
-                    if mom and (m is None or not _dense_same_layout(p.data, m)):
-                        m = self.state[p]["momentum_buffer"] = torch.zeros_like(p.data, memory_format=torch.preserve_format)
-                    fixed.append((p, gr, m, gi))
-                entries = fixed
-                if clip_ids is None:
-                    clip_ids = set() if clip is None else {id(p) for p in clip[0]}
-                inside = [id(p) in clip_ids for p, _, _, _ in entries]
-                if not self._tensors_ok(entries) or (any(inside) and not all(inside)):
-                    self._fallback(clip)                  # incl. a clip set that cuts through a group
-                    return loss
-                device = entries[0][0].device
-                table, n = self._build_table(entries, device)
-                hit = (table, n, all(inside), torch.empty(n, dtype=torch.float32, device=device))
-                if len(self._tables) >= 16:
-                    self._tables.clear()
-                key = (gi, clip_sig) + tuple((p.data_ptr(), gr.data_ptr(), 0 if m is None else m.data_ptr(), p.numel()) for p, gr, m, _ in entries)
-                self._tables[key] = hit
-                if self._coef is None or self._coef.device != device:
-                    self._coef = torch.ones(2, dtype=torch.float32, device=device)
+            hit, entries = self._group_table(gi, g, clip_sig, clip)
+            if hit is False:
+                self._fallback(clip, early)               # incl. a clip set that cuts through a group
+                return loss
             hits.append(hit)
-            keep.append(entries)
+            if hit is not None:
+                keep.append(entries)
         if not keep:
             return loss
         self._keep = keep                                  # the tables hold raw pointers: keep their owners alive
@@ -166,7 +211,7 @@ class SGD(torch.optim.SGD):
             groups[gi] = _Group(float(g["lr"]), float(g["weight_decay"]), float(g["momentum"]), 1.0 if c else 0.0)
         gptr, coef = ctypes.cast(groups, ctypes.c_void_p), None
         if len(clipped) > 1:
-            self._fallback(clip)                           # the norm would span several tables: not built (torch does it)
+            self._fallback(clip, early)                    # the norm would span several tables: not built (torch does it)
             return loss
         if clipped:
             table, n, _, partial = hits[clipped[0]]

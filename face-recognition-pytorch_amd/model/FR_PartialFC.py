@@ -81,6 +81,9 @@ class Model(nn.Module):
                 raise ValueError(conf.optimizer)
             self.loss.train().to(conf.local_rank)
             self.opt, self.sch = self.configure_optimizers()
+            # _step() clips the ENCODER's gradients only (reference :181), so the head's parameter group may be updated as soon as
+            # its gradient exists, beside the backbone's backward pass (nets/PartialFC.py: _hook_early_update)
+            self.loss.allow_early_update = hasattr(self.opt, "step_group_early")
 
     def forward(self, x):
         return self.encoder(x)

@@ -171,3 +171,44 @@ def test_adamw_matches_torch_adamw_and_clip_grad_norm():
     assert got[3] == ref[3] == [3] * len(ref[3])
     for x, y in zip(got[0] + got[1] + got[2], ref[0] + ref[1] + ref[2]):
         np.testing.assert_allclose(x.numpy(), y.numpy(), rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.gpu
+def test_sgd_step_group_early_equals_plain_step():
+    """the last (unclipped) parameter group updated ahead of step(), on another stream: same parameters and momentum buffers as
+    one step() over everything -- when step() runs its fused kernels for the rest, and when it has to fall back to torch's own
+    step (a clip set that cuts through a group) and must leave the early group alone"""
+    from frhip.optim import SGD
+    for fused in (True, False):
+        torch.manual_seed(3)
+        a = [torch.randn(300, 40, device="cuda"), torch.randn(77, device="cuda")]
+        h = [torch.randn(1000, 64, device="cuda")]
+        models = []
+        for _ in range(2):
+            pa = [torch.nn.Parameter(t.clone()) for t in a]
+            ph = [torch.nn.Parameter(t.clone()) for t in h]
+            models.append((pa, ph, SGD([{"params": pa}, {"params": ph}], lr=0.1, momentum=0.9, weight_decay=5e-4)))
+        side = torch.cuda.Stream()
+        for it in range(3):
+            grads = [torch.randn_like(t) * (it + 1) for t in a + h]
+            for k, (pa, ph, opt) in enumerate(models):
+                for p, g in zip(pa + ph, grads):
+                    p.grad = g.clone()
+                if k == 0:
+                    assert opt.step_group_early(1, side) is True
+                    assert opt.step_group_early(1, side) is False          # once per step
+                opt.step(clip=(pa if fused else pa[:1], 5.0))             # pa[:1] cuts through group 0 -> torch's step
+        torch.cuda.synchronize()
+        for p, q in zip(models[0][0] + models[0][1], models[1][0] + models[1][1]):
+            mp, mq = models[0][2].state[p]["momentum_buffer"], models[1][2].state[q]["momentum_buffer"]
+            if fused:                       # same kernel on both sides: bit-identical
+                assert torch.equal(p.data, q.data) and torch.equal(mp, mq)
+            else:                           # model 1 went through torch's own arithmetic for every group
+                torch.testing.assert_close(p.data, q.data, rtol=1e-5, atol=1e-6)
+                torch.testing.assert_close(mp, mq, rtol=1e-5, atol=1e-6)
+        pa, ph, opt = models[0]
+        for p in pa + ph:
+            p.grad = torch.ones_like(p)
+        opt.step_group_early(1, side)
+        with pytest.raises(RuntimeError):
+            opt.step(clip=(pa + ph, 5.0))                                   # a group updated early must not be in the clip set
