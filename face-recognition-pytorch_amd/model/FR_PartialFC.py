@@ -81,9 +81,6 @@ class Model(nn.Module):
                 raise ValueError(conf.optimizer)
             self.loss.train().to(conf.local_rank)
             self.opt, self.sch = self.configure_optimizers()
-            # _step() clips the ENCODER's gradients only (reference :181), so the head's parameter group may be updated as soon as
-            # its gradient exists, beside the backbone's backward pass (nets/PartialFC.py: _hook_early_update)
-            self.loss.allow_early_update = hasattr(self.opt, "step_group_early")
 
     def forward(self, x):
         return self.encoder(x)
@@ -97,6 +94,10 @@ class Model(nn.Module):
         feat = normalize(self.forward(img))
         self.loss.train()
         loss = self.loss(feat, id_, self.opt)
+        if hasattr(self.opt, "step_group_early") and hasattr(self.loss, "arm_early_update"):
+            # the clip below covers the ENCODER only (reference :181) and step() follows this one backward(): the head's parameter
+            # group may be updated as soon as its gradient exists, beside the backbone's backward pass
+            self.loss.arm_early_update(self.opt)
         loss.backward()
         if hasattr(self.opt, "last_grad_norm"):          # frhip.optim.SGD: the clip rides inside the fused update
             self.opt.step(clip=(self.encoder.parameters(), 5))

@@ -448,7 +448,6 @@ class _PartialFCBase(torch.nn.Module):
         n_global = batch_size * self.world_size
         s, m = float(self.margin_softmax.scale), float(self.margin_softmax.margin)
         if ready is not None and ready.numel() == n_global:      # everything label-side was done by prepare()
-            self._hook_early_update(optimizer)
             return _MarginSoftmaxFn.apply(local_embeddings, self.weight_activated, ready, self.kernels, s, m,
                                           self.world_size, collectives)
         n_pos = None
@@ -465,31 +464,30 @@ class _PartialFCBase(torch.nn.Module):
         labels = torch.where(index_positive, labels - self.class_start, torch.full_like(labels, -1))
         if self.sample_rate < 1:
             self.sample(labels, index_positive, optimizer, n_pos)
-        self._hook_early_update(optimizer)
         return _MarginSoftmaxFn.apply(local_embeddings, self.weight_activated, labels.view(-1).to(torch.int32).contiguous(),
                                       self.kernels, s, m, self.world_size, collectives)
 
-    def _hook_early_update(self, optimizer):
-        """The class centres take no part in the backbone's gradient clip (reference model/FR_PartialFC.py:181: clip_grad_norm_ over
-        the ENCODER's parameters) and their gradient is final as soon as the head's backward has run -- a whole backbone backward
-        before optimizer.step().  With frhip.optim.SGD their update (1.25 GB of HBM traffic at 122 000 classes) is launched from a
-        post-accumulate-grad hook on the weight-gradient side stream and runs beside the backbone's backward; step() skips the group.
-        Same kernel, same arithmetic, only earlier.  Opt-in (`allow_early_update = True`, set by model.FR_PartialFC.Model, whose
-        step clips the encoder only); FRHIP_EARLY_HEAD_UPDATE=0 turns it off."""
+    def arm_early_update(self, optimizer):
+        """Call between forward() and loss.backward() of a step whose gradient clip leaves the class centres out and that calls
+        optimizer.step() exactly once afterwards (model.FR_PartialFC.Model._step does).
+        The reference clips the ENCODER's gradients only (model/FR_PartialFC.py:181) and the centres' gradient is final as soon as
+        the head's backward has run -- a whole backbone backward before optimizer.step().  With frhip.optim.SGD their update
+        (1.25 GB of HBM traffic at 122 000 classes) is then launched from a post-accumulate-grad hook on the weight-gradient side
+        stream and runs beside the backbone's backward; step() skips the group.  Same kernel, same arithmetic, only earlier.
+        ONE-SHOT: the hook disarms itself, so a backward() that is not followed by step() (gradient accumulation, inspection)
+        never changes a parameter.  FRHIP_EARLY_HEAD_UPDATE=0 turns it off."""
         p = self.weight_activated
-        if not getattr(self, "allow_early_update", False):      # the CALLER promises that its gradient clip leaves this group out
-            return
         if not _EARLY_HEAD_UPDATE or optimizer is None or not hasattr(optimizer, "step_group_early") or not p.is_cuda:
             return
-        self._early_opt = weakref.ref(optimizer)
+        self._early_armed = optimizer
         if getattr(p, "_frhip_early_hook", None) is not None:
             return
 
         def hook(param):
-            opt = self._early_opt() if self._early_opt is not None else None
-            if opt is None or not opt.param_groups or not any(q is param for q in opt.param_groups[-1]["params"]):
+            opt, self._early_armed = getattr(self, "_early_armed", None), None
+            if opt is None or not opt.param_groups or len(opt.param_groups[-1]["params"]) != 1:
                 return
-            if len(opt.param_groups[-1]["params"]) != 1 or torch.cuda.is_current_stream_capturing():
+            if opt.param_groups[-1]["params"][0] is not param or torch.cuda.is_current_stream_capturing():
                 return
             from ._backbone import side_stream
             opt.step_group_early(len(opt.param_groups) - 1, side_stream(param.device))

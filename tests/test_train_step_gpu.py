@@ -142,3 +142,36 @@ def test_stale_prepare_is_discarded(pg):
     assert torch.equal(ia, ib) and sa == sb == 1 and ra == rb
     np.testing.assert_allclose(la, lb, rtol=1e-6)
     np.testing.assert_allclose(ga.numpy(), gb.numpy(), rtol=1e-5, atol=1e-7)
+
+
+def test_head_update_during_backward_is_one_shot_and_bit_identical(pg):
+    """Model._step arms the early update of the class centres (launched from a post-accumulate-grad hook, on the side stream,
+    right after the head's backward).  (1) a backward() that nobody armed changes no parameter; (2) the armed step ends with
+    exactly the class centres and momentum of a step whose head group is updated inside optimizer.step()."""
+    from model.FR_PartialFC import Model, normalize
+    torch.cuda.set_device(0)
+    conf = _conf(1.0, "fp32")
+    img, ids = recipe.images(4101, 8, 112, 112).cuda(), recipe.labels(4102, 8, 256).cuda()
+    outs = []
+    for armed in (True, False):
+        torch.manual_seed(5)
+        m = Model(conf, None, "train")
+        w0 = m.loss.weight_activated.data.clone()
+        # (1) plain backward: nothing moves
+        m.opt.zero_grad()
+        m.encoder.train()
+        m.loss(normalize(m.forward(img)), ids, m.opt).backward()
+        torch.cuda.synchronize()
+        assert torch.equal(m.loss.weight_activated.data, w0) and not m.opt._early
+        # (2) one optimisation step, armed (Model._step) or with the arming taken out
+        if not armed:
+            m.loss.arm_early_update = lambda opt: None
+        m.training_step((img, ids.clone()))
+        torch.cuda.synchronize()
+        assert not m.opt._early
+        outs.append((m.loss.weight_activated.data.clone(), m.opt.state[m.loss.weight_activated]["momentum_buffer"].clone(),
+                     next(m.encoder.parameters()).data.clone()))
+    assert not torch.equal(outs[0][0], w0)
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])      # class centres + momentum: bit-identical
+    # (the encoder's small 1x1 weight gradients are summed with fp32 atomics: equal to rounding, not to the bit, run to run)
+    torch.testing.assert_close(outs[0][2], outs[1][2], rtol=1e-5, atol=1e-6)
