@@ -243,16 +243,21 @@ bool halo_applicable(int dtype, int h, int w, int c, int k, int r, int s, int st
            (dtype == FRHIP_DT_BF16 || dtype == FRHIP_DT_F32);
 }
 
-// which kernel configuration a problem gets: 0 = <4,1,4,1> (4 waves, 256x64, two workgroups per CU), 1 = <8,1,2,2>,
-// 2 = <4,2,4,2> (8 waves, 256x128, double-buffered halo)
+// Which kernel configuration a problem gets:
+//   0 = <4,1,4,1>: 4 waves, 256 x 64 tile, 64 x 64 per wave, two workgroups per CU (igemm_halo.h)
+//   1 = <8,1,2,2>, 2 = <4,2,4,2>: 8 waves, 256 x 128 tile, double-buffered window (fp32 validation mode; bf16 only when forced)
+//   3 = the 64 x 128-per-wave tile (igemm_halo_wide.h): bf16, W <= 28, output channels in whole 128s, input channels >= 128,
+//       tail launches off, automatic mode -- and only in the directions g_halo_wide_dirs names (bit 0 forward, bit 1 data-gradient).
+//       Default: data-gradient only.  One box, two A/B rounds each: both directions 26.48 ms, forward only 26.94, data-gradient only
+//       26.33, nowhere 27.0 -- the wide tile earns its keep beside the weight-gradient workgroups of the backward pass; the forward
+//       launches, alone on the chip, are better off with twice as many 64-wide tiles.
 static int g_halo_wide = getenv("FRHIP_HALO_WIDE") ? atoi(getenv("FRHIP_HALO_WIDE")) : 1;
 static int g_halo_wide_minc = getenv("FRHIP_HALO_WIDE_MINC") ? atoi(getenv("FRHIP_HALO_WIDE_MINC")) : 128;
+static int g_halo_wide_dirs = getenv("FRHIP_HALO_WIDE_DIRS") ? atoi(getenv("FRHIP_HALO_WIDE_DIRS")) : 2;
 static int halo_config(int dtype, int c, int k);
-// 3 = the 64 x 128-per-wave tile (igemm_halo_wide.h): bf16, W <= 28, output channels in whole 128s, tail launches off
-static int g_halo_wide_dirs = getenv("FRHIP_HALO_WIDE_DIRS") ? atoi(getenv("FRHIP_HALO_WIDE_DIRS")) : 2;    // bit 0 forward, bit 1 data-gradient
 static int halo_config_w(int dtype, int w, int c, int k, int sign) {
-    if (g_halo_wide && (g_halo_wide_dirs & (sign > 0 ? 1 : 2)) && dtype == FRHIP_DT_BF16 && w <= HaloWideTile<4>::MAXW && (k % 128) == 0 && (c % 64) == 0 && c >= g_halo_wide_minc && !g_halo_tail &&
-        (g_halo_enabled & 3) == 1)
+    if (g_halo_wide && (g_halo_wide_dirs & (sign > 0 ? 1 : 2)) && dtype == FRHIP_DT_BF16 && w <= HaloWideTile<4>::MAXW &&
+        (k % 128) == 0 && (c % 64) == 0 && c >= g_halo_wide_minc && !g_halo_tail && (g_halo_enabled & 3) == 1)
         return 3;
     return halo_config(dtype, c, k);
 }
