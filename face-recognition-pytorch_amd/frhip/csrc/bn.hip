@@ -181,7 +181,10 @@ template <typename T, bool NT> __device__ __forceinline__ void ew_store(T* p, co
     else *reinterpret_cast<Vec16<T>*>(p) = x;
 }
 static size_t EW_NT_BYTES = (size_t)(getenv("FRHIP_EW_NT_MB") ? atoi(getenv("FRHIP_EW_NT_MB")) : 0) << 20;
-static int g_ew_nt = getenv("FRHIP_EW_NT") ? atoi(getenv("FRHIP_EW_NT")) : 5;
+// bit 0: non-temporal loads in the residual / backward-apply passes, bit 2: in the plain BatchNorm-apply pass too, bit 1: non-temporal
+// stores.  Default 1.  (Round 1 had 5; with the round-2 tile choices the plain apply pass is better off with cached loads of the
+// tensor the convolution has just written: 26.34 vs 26.40 ms over four same-box A/B rounds, 26.67 vs 26.73 over two more.)
+static int g_ew_nt = getenv("FRHIP_EW_NT") ? atoi(getenv("FRHIP_EW_NT")) : 1;
 
 template <typename T, bool NTL, bool NTS>
 __global__ __launch_bounds__(EW_THREADS) void bn_apply_kernel(const T* __restrict__ y, const float* __restrict__ scale,
