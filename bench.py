@@ -411,7 +411,7 @@ def main():
             "roofline": {"bound": "mfma", "achieved": round(achieved, 1), "peak": BF16_DENSE_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(achieved / BF16_DENSE_PEAK_TFLOPS, 4), "traffic": traffic,
                          "traffic_source": traffic_src,
-                         "kernel": "frhip::halo_kernel<bf16> + frhip::nt_kernel<bf16> (conv forward + data-gradient implicit GEMM)",
+                         "kernel": "frhip::halo_kernel<bf16> + frhip::halo_wide_kernel + frhip::nt_kernel<bf16> (conv forward + data-gradient implicit GEMM)",
                          "measured": ("HIP events around every launch inside %d further steps of the same loop, run right behind the timed "
                                       "region (%.3f ms per instrumented step: the event records themselves cost ~0.6 ms)"
                                       % (in_steps, in_dt / in_steps * 1e3)) if in_n else "back-to-back re-issue",
