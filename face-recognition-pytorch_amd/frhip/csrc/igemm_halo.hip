@@ -3,10 +3,6 @@
 #include <cstdlib>
 #include "igemm_halo.h"
 #include "igemm_halo_wide.h"
-#ifndef IMG_LB
-#define IMG_LB 2
-#endif
-#include "igemm_halo_img.h"
 #include "frhip.h"
 
 namespace frhip {
@@ -170,70 +166,6 @@ static int halo_mixed_launch(HaloGeom g, const HaloWidePlan& p, const void* a, c
     return check_launch("igemm_halo_mixed");
 }
 
-// Launch-fitted tile height (igemm_halo_img.h): tpx <= 208 pixels x 128 channels per workgroup.
-__global__ __launch_bounds__(256, IMG_LB) void halo_img_kernel(HaloGeom g, const void* __restrict__ a, const void* __restrict__ b,
-                                                          void* __restrict__ out, const void* __restrict__ res,
-                                                          float* __restrict__ stats, EpiBnRed br, int tpx, int ntiles) {
-    typedef HaloImgTile Tile;
-    typedef bf16_t T;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const uint32_t lin = xcd_remap(blockIdx.x, gridDim.x);
-    const int ntile = (int)(lin % (uint32_t)ntiles), mtile = (int)(lin / (uint32_t)ntiles);
-    const int m0 = mtile * tpx;
-    HaloImgMainloop ml;
-    if (g.wide_big) {              // epilogue-operand prefetch (dense rows only)
-        const bool dense = br.res_w == 0 && br.map.wc == 0 && (size_t)g.M * g.Nout * 2 < 0x7fffffffULL && (g.Nout % 128) == 0;
-        if (dense && res) HaloImgMainloop::touch_rows(res, g.M, g.Nout, smem, m0, tpx, ntile);
-        if (dense && stats && br.y && !br.gelu_bwd) HaloImgMainloop::touch_rows(br.y, g.M, g.Nout, smem, m0, tpx, ntile);
-    }
-    ml.run(g, a, b, smem, m0, tpx, ntile);
-    const int wave = wave_id();
-    const int wm = wave >> 1, wn = wave & 1;
-    const int m_end = min(g.M, m0 + tpx);                      // rows past the tile's live pixels are neither read nor stored
-    const int mw = m0 + wm * Tile::SROWS, n0 = ntile * Tile::BN + wn * 64;
-    EpiOperands<T, Tile::SROWS> eo;
-    eo.fetch(res, (stats || br.gelu_bwd) ? br.y : nullptr, m_end, g.Nout, mw, n0, br.res_h, br.res_w, &br.map);
-    const char* mine = ml.stage_out(smem);
-    nt_epilogue_store<T, 2, 2, Tile::SROWS, Tile::THREADS, Tile::BN>(mine, Tile::stage_pitch, smem, m_end, g.Nout, out, res != nullptr,
-                                                                     stats, br, eo, mtile, ntile, mw, n0);
-}
-
-// Tile plan: T tiles of tpx = ceil(M / T) pixels per 128-channel column.  T is the largest count that does not add a round of
-// `slots` resident workgroups (two per CU; a multiple of 512 also fills whole rounds of one per CU beside a weight gradient).
-struct HaloImgPlan { int mtiles, tpx; };
-static int g_img_slots = getenv("FRHIP_HALO_IMG_SLOTS") ? atoi(getenv("FRHIP_HALO_IMG_SLOTS")) : 512;
-static HaloImgPlan halo_img_plan(int M, int ntiles) {
-    const int tmin = (M + HaloImgTile::TPX_MAX - 1) / HaloImgTile::TPX_MAX;
-    int T = tmin;
-    if (g_img_slots > 0 && ntiles <= g_img_slots && (g_img_slots % ntiles) == 0) {
-        const int per = g_img_slots / ntiles;                  // m-tiles per round
-        if (tmin >= per) T = ((tmin + per - 1) / per) * per;
-    }
-    HaloImgPlan p;
-    p.tpx = (M + T - 1) / T;
-    p.mtiles = (M + p.tpx - 1) / p.tpx;
-    return p;
-}
-
-static int halo_img_launch(HaloGeom g, const void* a, const void* b, void* out, const void* res, float* stats,
-                           const EpiBnRed& br, hipStream_t stream) {
-    typedef HaloImgTile Tile;
-    const int ntiles = (g.Nout + Tile::BN - 1) / Tile::BN;
-    const HaloImgPlan p = halo_img_plan(g.M, ntiles);
-    static const int prefetch = getenv("FRHIP_HALO_IMG_PREFETCH") ? atoi(getenv("FRHIP_HALO_IMG_PREFETCH")) : 1;
-    g.wide_big = prefetch;         // (field reused) 1: touch the store epilogue's operand rows at the start of the tile
-    static bool attr_done = false;
-    if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(halo_img_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, Tile::LDS) != hipSuccess) {
-            set_error("igemm_halo: cannot raise dynamic LDS to %d bytes", Tile::LDS);
-            return FRHIP_ELAUNCH;
-        }
-        attr_done = true;
-    }
-    hipLaunchKernelGGL(halo_img_kernel, dim3(p.mtiles * ntiles), dim3(Tile::THREADS), Tile::LDS, stream, g, a, b, out, res, stats, br, p.tpx, ntiles);
-    return check_launch("igemm_halo_img");
-}
-
 // Tail balancing.  A launch of T = mtiles x ntiles equal tiles on `slots` resident workgroups takes ceil(T / slots) rounds;
 // with T = 3.06 x slots (256-channel layers at B = 512) the fourth round is 94 % empty.  Plan: run only the FULL rounds
 // with 256-row tiles, then cover the remaining rows of every column with at most slots / ntiles smaller tiles
@@ -322,13 +254,8 @@ bool halo_applicable(int dtype, int h, int w, int c, int k, int r, int s, int st
 static int g_halo_wide = getenv("FRHIP_HALO_WIDE") ? atoi(getenv("FRHIP_HALO_WIDE")) : 1;
 static int g_halo_wide_minc = getenv("FRHIP_HALO_WIDE_MINC") ? atoi(getenv("FRHIP_HALO_WIDE_MINC")) : 128;
 static int g_halo_wide_dirs = getenv("FRHIP_HALO_WIDE_DIRS") ? atoi(getenv("FRHIP_HALO_WIDE_DIRS")) : 2;
-// 4 = launch-fitted tile (igemm_halo_img.h): bf16, W <= 28, output channels in whole 128s; bit 0 forward, bit 1 data-gradient
-static int g_halo_img = getenv("FRHIP_HALO_IMG") ? atoi(getenv("FRHIP_HALO_IMG")) : 3;
 static int halo_config(int dtype, int c, int k);
 static int halo_config_w(int dtype, int w, int c, int k, int sign) {
-    if ((g_halo_img & (sign > 0 ? 1 : 2)) && dtype == FRHIP_DT_BF16 && w <= HaloImgTile::MAXW && (k % 128) == 0 && (c % 64) == 0 &&
-        !g_halo_tail && (g_halo_enabled & 3) == 1)
-        return 4;
     if (g_halo_wide && (g_halo_wide_dirs & (sign > 0 ? 1 : 2)) && dtype == FRHIP_DT_BF16 && w <= HaloWideTile<4>::MAXW &&
         (k % 128) == 0 && (c % 64) == 0 && c >= g_halo_wide_minc && !g_halo_tail && (g_halo_enabled & 3) == 1)
         return 3;
@@ -355,7 +282,6 @@ static int halo_config(int dtype, int c, int k) {
 
 // rows of the BN-partial buffer a halo launch writes for an output of m pixels
 int halo_stat_rows(int dtype, int m, int w, int c, int k, int sign) {
-    if (halo_config_w(dtype, w, c, k, sign) == 4) return halo_img_plan(m, (k + 127) / 128).mtiles;
     if (halo_config_w(dtype, w, c, k, sign) == 3) return halo_mixed_plan(m, (k + 127) / 128, sign).mtiles;
     const int cfg = halo_config(dtype, c, k);
     if (cfg == 0 && dtype == FRHIP_DT_BF16 && !g_halo_tail) return halo_mixed_plan(m, (k + 63) / 64, sign).mtiles;
@@ -397,7 +323,6 @@ int halo_run(int dtype, const void* a, const void* b, void* out, const void* res
         }
         return rc;
     }
-    if (halo_config_w(dtype, w, c, k, sign) == 4) return halo_img_launch(g, a, b, out, res, stats, br, stream);
     if (halo_config_w(dtype, w, c, k, sign) == 3) return halo_wide_launch(g, a, b, out, res, stats, br, stream);
     if (dtype == FRHIP_DT_BF16) {
         if (cfg == 0 && !g_halo_tail) {
@@ -422,13 +347,6 @@ extern "C" int frhip_set_halo_wide_slots(int slots) {
     frhip::g_wide_slots = slots & 0xffff;
     if (slots & (1 << 20)) frhip::g_wide_mix = (slots >> 16) & 3;
     if (slots & (1 << 21)) frhip::g_halo_wide_dirs = (slots >> 18) & 3;
-    return old;
-}
-
-extern "C" int frhip_set_halo_img(int dirs) {
-    // bit 0 / bit 1: forward / data-gradient launches may use the launch-fitted tile (igemm_halo_img.h); < 0: query
-    const int old = frhip::g_halo_img;
-    if (dirs >= 0) frhip::g_halo_img = dirs & 3;
     return old;
 }
 

@@ -259,7 +259,7 @@ struct NtMainloop {
 template <typename T, int WROWS>
 struct EpiOperands {
     static constexpr int EPV = 16 / (int)sizeof(T), LPR = 64 / EPV, RPI = 64 / LPR, ITERS = WROWS / RPI;
-    static constexpr bool PRE = ITERS <= 13;         // 128-row wave tiles would need 128 registers: those load in the loop
+    static constexpr bool PRE = ITERS <= 8;          // 128-row wave tiles would need 128 registers: those load in the loop
     Vec16<T> rv[PRE ? ITERS : 1], yv[PRE ? ITERS : 1];
     const T* r; const T* y;
     int M, Nout, m0, n, rsub;

@@ -73,10 +73,6 @@ int frhip_set_conv_halo(int enabled);
  * launches may use the 64 x 128-per-wave tile (1 forward, 2 data-gradient [default], 3 both).  Returns the old value with bits 20
  * and 21 set, so passing it back restores the previous state */
 int frhip_set_halo_wide_slots(int slots);
-/* test / tuning hook: which 3x3 / stride-1 launches (bf16, W <= 28, output channels in whole 128s) run on the launch-fitted tile
- * (csrc/igemm_halo_img.h: tile height = ceil(M / T) <= 208 pixels so that T workgroups per 128-channel column fill whole rounds
- * of the chip).  bit 0 forward, bit 1 data-gradient; default 3; < 0 queries.  Returns the old value */
-int frhip_set_halo_img(int dirs);
 /* test / micro-benchmark hook: force the NT tile (0 auto, 1 128x128, 2 256x64, 3 256x128, 4 256x256); returns the old value */
 int frhip_set_nt_tile(int tile);
 int frhip_conv_fwd(int dtype, const void* x, const void* w, void* y, float* stats_partial,
