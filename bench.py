@@ -243,6 +243,43 @@ def cpu_baseline(classes, batch=16, steps=12):
                       "steps (%.1f s)" % (classes, batch, steps, dt)}
 
 
+FLOP_IMG = {"ResNet50": 33.92e9, "ResNet18": 10.3e9, "Swin34": 10.2e9,
+            "AlterNet50": 6 * 2.1025e9}       # tools/count_macs.py: 2.1025 GMAC forward at 192 x 192
+
+
+def extra_config(network, batch, fp8, classes, steps=10, warmup=3):
+    """One more BASELINE configuration timed in this process after the headline line: same step loop,
+    same barrier + synchronize bracket, K = `steps` after `warmup` untimed steps.  Returns the fields of a bench line."""
+    from model.FR_PartialFC import Model
+    a = types.SimpleNamespace(network=network, img_size=192 if network.startswith("AlterNet") else 112, classes=classes)
+    conf = make_conf(a, 0, 1)
+    conf.frhip_fp8 = bool(fp8)
+    torch.manual_seed(1234)
+    model = Model(conf, None, "train")
+    model.sync_loss = False
+    gen = torch.Generator().manual_seed(1234)
+    img = torch.randn((batch, 3, a.img_size, a.img_size), generator=gen).clamp_(-1, 1).cuda()
+    ids = torch.randint(0, classes, (batch,), generator=gen).cuda()
+    for _ in range(warmup):
+        model.training_step((img, ids.clone()))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = model.training_step((img, ids.clone()))
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    value = batch * steps / dt
+    rec = {"workload": "BASELINE cfg %d: %s + ArcFace (PartialFC rate 1.0), %d ids, B=%d, %dx%d" % (
+               5 if network.startswith("AlterNet") else 4, network, classes, batch, a.img_size, a.img_size),
+           "dtype": "fp8-weights" if fp8 else "bf16", "value": round(value, 1), "unit": "imgs/sec", "steps": steps, "warmup": warmup,
+           "ms_per_step": round(dt / steps * 1e3, 3), "final_loss": round(float(out["loss"]), 4),
+           "step_frac": round(value * (FLOP_IMG[network] + 6.0 * 512 * classes) / 1e12 / BF16_DENSE_PEAK_TFLOPS, 4),
+           "step_frac_peak": "bf16 dense MFMA %.1f TFLOP/s (also for the fp8 run: its backward is bf16)" % BF16_DENSE_PEAK_TFLOPS}
+    del model, img, ids
+    torch.cuda.empty_cache()
+    return rec
+
+
 def log(msg):
     if int(os.environ.get("RANK", "0")) == 0:
         print("[bench %7.1fs] %s" % (time.time() - T_START, msg), file=sys.stderr, flush=True)
@@ -267,6 +304,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--fp8", action="store_true",
                     help="BASELINE cfg 5: forward convolutions / linears with >= 128 input channels on the fp8 MFMA path")
+    ap.add_argument("--no-extra", action="store_true", help="skip the cfg 4 / cfg 5 runs that follow the headline measurement")
     ap.add_argument("--dist-path", action="store_true",
                     help="rehearse the N>1 code path (RCCL group, DDP wrap, PartialFC rate 0.1) in a 1-rank group")
     args = ap.parse_args()
@@ -387,7 +425,7 @@ def main():
         else:
             launches, achieved, avg_us, flop_per_launch = n, probe, ms * 1e3 / max(n, 1), fl / max(n, 1)
         traffic, traffic_src = pmc_traffic(args)
-        flop_img = {"ResNet50": 33.92e9, "ResNet18": 10.3e9, "Swin34": 10.2e9}.get(args.network)
+        flop_img = FLOP_IMG.get(args.network)
         value = args.batch * world * args.steps / dt
         step_frac = None
         if flop_img is not None:
@@ -428,6 +466,20 @@ def main():
                                     "launches": f8_n // in_steps, "avg_launch_us": round(f8_ms * 1e3 / f8_n, 2)}
         if world == 1 and not args.no_cpu_baseline and args.network == "ResNet50":
             line["cpu_baseline"] = cpu_baseline(args.classes)
+        # BASELINE cfg 4 / cfg 5 in the same process, after (and outside) the headline's timed region; the headline fields above are
+        # final at this point.  Only in the plain headline run: N = 1, ResNet50, default batch, eager.
+        if (world == 1 and args.network == "ResNet50" and args.batch == BATCH and not args.dist_path and not use_graph and not args.fp8
+                and not args.no_extra and os.environ.get("FRHIP_BENCH_EXTRA", "1") == "1"):
+            del model, out
+            torch.cuda.empty_cache()
+            extras = []
+            for net, b, f8 in (("Swin34", 512, False), ("AlterNet50", 256, False), ("AlterNet50", 256, True)):
+                try:
+                    extras.append(extra_config(net, b, f8, args.classes))
+                    log("extra config %s%s: %.1f img/s" % (net, " fp8" if f8 else "", extras[-1]["value"]))
+                except Exception as e:       # the headline line must still be printed
+                    extras.append({"workload": "%s B=%d%s" % (net, b, " fp8" if f8 else ""), "error": repr(e)[:300]})
+            line["extra_configs"] = extras
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

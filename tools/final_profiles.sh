@@ -3,7 +3,8 @@
 # gradients on the main stream so durations add up), the overlapped anatomy (what the step really runs), Swin34 / AlterNet50
 # anatomies, PMC traffic passes and the MFMA-utilisation counters of the dominant kernels.
 # Everything lands under gpurun_out/final/ ; tools/collect_profiles.py <tag> copies the summaries into profiles/.
-set -e
+set -eu
+: "${GRAFT_REPO_ROOT:?run on the GPU box (gpurun exports GRAFT_REPO_ROOT)}"
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/final
 rm -rf $OUT; mkdir -p $OUT
@@ -16,11 +17,11 @@ python bench.py > $OUT/bench.json 2> $OUT/bench.log
 tail -1 $OUT/bench.json | cut -c1-200
 export FRHIP_BENCH_INSTEP=0
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o r50 -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline > $OUT/stats.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o r50 -- python3 $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extra > $OUT/stats.log 2>&1
 cp $(ls $OUT/stats/*kernel_trace.csv | head -1) $OUT/overlap_trace.csv
-FRHIP_OVERLAP_WGRAD=0 rocprofv3 --kernel-trace --output-format csv -d $OUT/serial -o r50 -- python3 $R/bench.py --steps 6 --warmup 3 --no-cpu-baseline > $OUT/serial.log 2>&1
-FRHIP_OVERLAP_WGRAD=0 rocprofv3 --kernel-trace --output-format csv -d $OUT/swin -o swin -- python3 $R/bench.py --network Swin34 --steps 6 --warmup 3 --no-cpu-baseline > $OUT/swin.log 2>&1
-FRHIP_OVERLAP_WGRAD=0 rocprofv3 --kernel-trace --output-format csv -d $OUT/alt -o alt -- python3 $R/bench.py --network AlterNet50 --fp8 --steps 6 --warmup 3 --no-cpu-baseline > $OUT/alt.log 2>&1
+FRHIP_OVERLAP_WGRAD=0 rocprofv3 --kernel-trace --output-format csv -d $OUT/serial -o r50 -- python3 $R/bench.py --steps 6 --warmup 3 --no-cpu-baseline --no-extra > $OUT/serial.log 2>&1
+FRHIP_OVERLAP_WGRAD=0 rocprofv3 --kernel-trace --output-format csv -d $OUT/swin -o swin -- python3 $R/bench.py --network Swin34 --steps 6 --warmup 3 --no-cpu-baseline --no-extra > $OUT/swin.log 2>&1
+FRHIP_OVERLAP_WGRAD=0 rocprofv3 --kernel-trace --output-format csv -d $OUT/alt -o alt -- python3 $R/bench.py --network AlterNet50 --fp8 --steps 6 --warmup 3 --no-cpu-baseline --no-extra > $OUT/alt.log 2>&1
 cd $R
 python tools/trace_summary.py $(ls $OUT/serial/*kernel_trace.csv | head -1) > $OUT/step_anatomy.txt
 python tools/trace_summary.py $OUT/overlap_trace.csv > $OUT/step_anatomy_overlapped.txt

@@ -1,6 +1,7 @@
 #!/bin/bash
 # usage: tools/pmc_run.sh <outdir> <what> <h> <c> <k>   (GPU box; one rocprofv3 pass per counter group)
-set -e
+set -eu
+: "${GRAFT_REPO_ROOT:?run on the GPU box (gpurun exports GRAFT_REPO_ROOT)}"
 out=$1; shift
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
