@@ -5,7 +5,8 @@ Composition follows /root/reference/model/FR_PartialFC.py:162-193 (non-mixed bra
   -> loss = PartialFC(feat, id, opt) (:175) -> loss.backward() (:186)
   -> clip_grad_norm_(encoder.parameters(), 5) (:187) -> opt.step() (:188)
 with ONE optimizer over param groups [encoder, head] (:434-449, SGD momentum + weight decay
-on every tensor, BN affine included).  world_size == 1 here (BASELINE cfg 1 / cfg 2).
+on every tensor, BN affine included).  train_step: world_size 1 (BASELINE cfg 1 / cfg 2); train_step_ranks: a world of N
+ranks in one process (DDP-averaged backbone gradients, class-sharded head), pinned by the ws-2 reference fixtures.
 The SGD update itself is restated by hand (torch.optim.SGD semantics: d = g + wd*p;
 buf = d on the first step else mom*buf + d; p -= lr*buf).
 """
@@ -77,3 +78,47 @@ def train_step(sd, head_w, img, ids, blocks, num_classes, opt, s=30.0, m=0.35,
         opt.buf["head"][idx] = buf_rows
         head_w[idx] = w_rows - opt.lr * buf_rows
     return dict(loss=h["loss"], feat=feat.detach(), grad_norm=total, index=idx)
+
+
+def train_step_ranks(sds, head_ws, imgs, idss, blocks, num_classes, opts, s=30.0, m=0.35, emd_size=512,
+                     sample_rate=1.0, uniforms=None):
+    """One step of a world of len(sds) ranks (reference composition model/FR_PartialFC.py:98, :162-193):
+    every rank runs its own backbone on its own images (BatchNorm statistics and buffers stay per rank: the reference wraps the
+    encoder in DDP(broadcast_buffers=False)), the class-sharded head sees the gathered embeddings (nets/PartialFC.py:182-186),
+    DDP averages the backbone gradients over the ranks, each rank clips the averaged gradient and takes the same SGD step;
+    a rank's head rows are updated from its own shard gradient (never reduced: nets/PartialFC.py:208).
+    sds / opts: one state dict / SGDState per rank (mutated in place); head_ws: one [num_local_r, D] shard per rank.
+    Returns dict(loss, grad_norm, index[r])."""
+    ws = len(sds)
+    names = resnet_ref.trainable_names(sds[0])
+    leaves, feats = [], []
+    for r in range(ws):
+        lv = {k: sds[r][k].detach().clone().requires_grad_(True) for k in names}
+        work = dict(sds[r])
+        work.update(lv)
+        raw = resnet_ref.resnet_forward(work, imgs[r], blocks, True, emd_size)
+        for k in sds[r]:
+            if k not in lv:
+                sds[r][k] = work[k]
+        leaves.append(lv)
+        feats.append(F.normalize(raw))
+    h = head_ref.head_all_shards([f.detach() for f in feats], idss, head_ws, num_classes, s, m,
+                                 sample_rate=sample_rate, uniforms=uniforms)
+    for r in range(ws):
+        feats[r].backward(h["d_emb"][r])
+    avg = {k: sum(leaves[r][k].grad for r in range(ws)) / ws for k in names}        # DDP: mean over the ranks
+    coef, total = clip_coef([avg[k] for k in names])
+    with torch.no_grad():
+        for r in range(ws):
+            for k in names:
+                opts[r].apply(k, sds[r][k], avg[k] * coef)
+            idx = h["index"][r]
+            first = "head" not in opts[r].buf
+            if first:
+                opts[r].buf["head"] = torch.zeros_like(head_ws[r])
+            w_rows = head_ws[r][idx]
+            d = h["d_w_act"][r] + opts[r].wd * w_rows
+            buf_rows = opts[r].buf["head"][idx] * opts[r].momentum + d if (sample_rate < 1 or not first) else d
+            opts[r].buf["head"][idx] = buf_rows
+            head_ws[r][idx] = w_rows - opts[r].lr * buf_rows
+    return dict(loss=h["loss"], grad_norm=total, index=h["index"])

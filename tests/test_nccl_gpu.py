@@ -1,0 +1,82 @@
+"""The `nccl` (= RCCL) branches of the multi-rank code path under a real RCCL process group.
+
+nets/PartialFC.py and nets/_backbone.py take a different route when the backend is RCCL than on the gloo groups every other
+multi-rank test uses: `reduce_scatter_tensor(async_op=True)` instead of all-reduce-and-slice for dE, `ReduceOp.AVG` in place on the
+gradient arena instead of SUM-then-scale, `device_id` group initialisation, `all_gather_into_tensor` on device buffers.  A one-GPU
+box can only host a 1-rank RCCL group, but every one of those calls is issued in it (FRHIP_FORCE_COLLECTIVES=1 + conf.force_ddp, the
+switches `bench.py --dist-path` uses): the same two training steps run once under `nccl` and once under `gloo`, each in its own
+process, and must agree bit for bit (a 1-rank SUM / AVG / gather / reduce-scatter is the identity)."""
+import os
+import sys
+import tempfile
+import types
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def _worker(_, backend, port, ret):
+    os.environ["FRHIP_FORCE_COLLECTIVES"] = "1"              # read when nets.PartialFC is imported
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+    for p in (ROOT, os.path.join(ROOT, "face-recognition-pytorch_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    torch.cuda.set_device(0)
+    if backend == "nccl":
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+    else:
+        dist.init_process_group("gloo", init_method="file://" + os.path.join(ret, "pg"), rank=0, world_size=1)
+    from model.FR_PartialFC import Model
+    from oracle import recipe, resnet_ref
+    C, B = 256, 8
+    conf = types.SimpleNamespace(network="ResNet18", emd_size=512, img_size=112, local_rank=0, world_size=1, force_ddp=True,
+                                 sample_rate=0.3, mixed_precision=False, loss_s=30.0, loss_m=0.35, n_classes=C,
+                                 optimizer="SGD", lr=0.1, wd=5e-4, mom=0.9, loss="PartialFC", lr_scheduler=None,
+                                 frhip_dtype="fp32", ckpt_path=None)
+    torch.manual_seed(5)
+    model = Model(conf, None, "train")
+    sd = recipe.fill_state(resnet_ref.resnet_spec(resnet_ref.BLOCKS["ResNet18"]), 777)
+    model.encoder.module.load_state_dict(sd, strict=True)
+    with torch.no_grad():
+        model.loss.weight.copy_(recipe.normal(778, (C, 512), 0.01).cuda())
+    img, ids = recipe.images(779, B), recipe.labels(780, B, C)
+    out = {"backend": dist.get_backend(), "wrapped": type(model.encoder).__name__, "losses": []}
+    for st in range(2):
+        torch.manual_seed(3000 + st)
+        out["losses"].append(float(model.training_step((img, ids.clone()))["loss"]))
+        out["index%d" % st] = model.loss.weight_index.cpu().numpy()
+    model.loss.update()
+    enc = model.encoder.module
+    for k in ("conv1.weight", "layer3.1.conv2.weight", "fc.weight", "bn3.weight"):
+        out["p." + k] = enc.state_dict()[k].float().cpu().numpy()
+        out["g." + k] = dict(enc.named_parameters())[k].grad.float().cpu().numpy()
+    out["head"] = model.loss.weight.float().cpu().numpy()
+    np.savez(os.path.join(ret, backend + ".npz"), **out)
+    dist.destroy_process_group()
+
+
+def test_rccl_branches_equal_the_gloo_route_in_a_one_rank_group():
+    with tempfile.TemporaryDirectory() as td:
+        port = 29600 + os.getpid() % 300
+        for backend in ("nccl", "gloo"):                       # one child at a time: the box admits few processes on the card
+            mp.spawn(_worker, args=(backend, port, td), nprocs=1, join=True)
+        a, b = (dict(np.load(os.path.join(td, be + ".npz"))) for be in ("nccl", "gloo"))
+        assert str(a["backend"]) == "nccl" and str(b["backend"]) == "gloo"
+        assert str(a["wrapped"]) == str(b["wrapped"]) == "DataParallel"
+        assert np.isfinite(a["losses"]).all() and a["losses"][0] != a["losses"][1]
+        for k in a:
+            if k in ("backend", "wrapped"):
+                continue
+            if k.startswith("index"):
+                assert np.array_equal(a[k], b[k]), k
+            else:
+                # identity collectives: the only difference allowed is the order of concurrent fp32 atomics (none are used
+                # in fp32 validation mode), i.e. none
+                np.testing.assert_allclose(a[k], b[k], rtol=1e-6, atol=1e-9, err_msg=k)

@@ -105,3 +105,45 @@ def test_train_steps(golden, tag):
               "bn3.running_var", "bn1.running_mean"):
         _summary_close(sd[k].float(), g["after." + k], 5e-3, 5e-5)
     _summary_close(W, g["after.head_weight"], 5e-3, 5e-5)
+
+
+@pytest.mark.parametrize("tag", ["rate10", "rate03"])
+def test_train_steps_two_ranks(golden, tag):
+    """The reference composition at world size 2 (torch DDP around the encoder + the class-sharded PartialFC, gloo/CPU, generated by
+    tools/make_golden.py train_ws2): per-rank data, one global loss, averaged backbone gradients, per-rank head shards, 3 SGD steps."""
+    g = golden("train_step_resnet18_c256_ws2_" + tag)
+    C, B, steps, rate, ws = int(g["C"]), int(g["B"]), int(g["steps"]), float(g["rate"]), int(g["ws"])
+    blocks = resnet_ref.BLOCKS["ResNet18"]
+    spec = resnet_ref.resnet_spec(blocks)
+    sds, Ws, imgs, idss, opts = [], [], [], [], []
+    for r in range(ws):
+        sd = recipe.fill_state(spec, 777)
+        for k, _, kind in spec:
+            if kind in ("bn_w", "bn_rv"):
+                sd[k].fill_(1.0)
+            elif kind in ("bn_b", "bn_rm"):
+                sd[k].zero_()
+        sds.append(sd)
+        c0, nloc = int(g["r%d_class_start" % r]), int(g["r%d_num_local" % r])
+        Ws.append(recipe.normal(778, (C, 512), 0.01)[c0:c0 + nloc].clone())
+        imgs.append(recipe.images(779 + r, B))
+        idss.append(recipe.labels(780 + r, B, C))
+        opts.append(train_ref.SGDState(float(g["lr"]), float(g["momentum"]), float(g["wd"])))
+    for st in range(steps):
+        u = None
+        if rate < 1:
+            u = []
+            for r in range(ws):
+                torch.manual_seed(3000 + st + 50 * r)           # the draw the reference made on rank r (nets/PartialFC.py:110)
+                u.append(torch.rand(int(g["r%d_num_local" % r])))
+        out = train_ref.train_step_ranks(sds, Ws, imgs, idss, blocks, C, opts, sample_rate=rate, uniforms=u)
+        for r in range(ws):
+            # later steps start from ~1e-5 losses of a memorised batch: summation-order noise is amplified (as in the ws-1 test)
+            np.testing.assert_allclose(out["loss"].item(), g["r%d_losses" % r][st], rtol=2e-3 if st == 0 else 5e-2)
+            np.testing.assert_allclose(out["grad_norm"].item(), g["r%d_grad_norms" % r][st], rtol=5e-3 if st == 0 else 5e-2)
+            if rate < 1:
+                assert np.array_equal(out["index"][r].numpy(), g["r%d_index_step%d" % (r, st)])
+    for r in range(ws):
+        for k in ("conv1.weight", "layer2.0.downsample.0.weight", "layer4.1.bn2.weight", "fc.weight", "bn3.running_var", "bn1.running_mean"):
+            _summary_close(sds[r][k].float(), g["r%d_after.%s" % (r, k)], 5e-3, 5e-5)
+        _summary_close(Ws[r], g["r%d_after.head_weight" % r], 5e-3, 5e-5)

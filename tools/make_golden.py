@@ -259,6 +259,69 @@ def gen_train_steps():
             dist.destroy_process_group()
 
 
+# ----------------------------------------------------------------------------- training steps, two ranks (DDP + PartialFC)
+def _train_ws2_worker(rank, ws, path, rate, out_dir):
+    """The reference composition of model/FR_PartialFC.py:98, :162-193 at world size 2 on gloo/CPU: torch DDP around the reference
+    encoder (broadcast_buffers=False, find_unused_parameters=True), the reference PartialFC shard, one SGD over both."""
+    _, P, R = _ref()
+    import torch.nn.functional as F
+    from torch.nn.parallel import DistributedDataParallel as DDP
+    _init_pg(rank, ws, path)
+    C, B, steps = 256, 8, 3
+    conf = types.SimpleNamespace(network="ResNet18", emd_size=512, sample_rate=rate, mixed_precision=False, loss_s=30.0, loss_m=0.35)
+    enc = R.ResNet18(conf)
+    spec = resnet_ref.resnet_spec(resnet_ref.BLOCKS["ResNet18"])
+    sd = recipe.fill_state(spec, 777)
+    for k, _, kind in spec:
+        if kind == "bn_w" or kind == "bn_rv":
+            sd[k].fill_(1.0)
+        elif kind in ("bn_b", "bn_rm"):
+            sd[k].zero_()
+    enc.load_state_dict(sd, strict=True)
+    enc = DDP(enc, broadcast_buffers=False, find_unused_parameters=True)
+    pfc = P.PartialFC(conf, C)
+    W = recipe.normal(778, (C, 512), 0.01)[pfc.class_start:pfc.class_start + pfc.num_local]
+    with torch.no_grad():
+        (pfc.weight if rate < 1 else pfc.weight_activated.data).copy_(W)
+    opt = torch.optim.SGD([{"params": enc.parameters()}, {"params": pfc.parameters()}], lr=0.1, momentum=0.9, weight_decay=5e-4)
+    img = recipe.images(779 + rank, B)
+    ids = recipe.labels(780 + rank, B, C)
+    arrs = dict(class_start=pfc.class_start, num_local=pfc.num_local, num_sample=pfc.num_sample)
+    losses, gnorms = [], []
+    for st in range(steps):
+        opt.zero_grad()
+        enc.train()
+        feat = F.normalize(enc(img))
+        torch.manual_seed(3000 + st + 50 * rank)
+        loss = pfc(feat, ids.clone(), opt)
+        loss.backward()
+        gn = torch.nn.utils.clip_grad_norm_(enc.parameters(), 5)
+        opt.step()
+        losses.append(loss.detach().clone())
+        gnorms.append(gn.detach().clone())
+        if rate < 1:
+            arrs["index_step%d" % st] = pfc.weight_index.clone()
+    if rate < 1:
+        pfc.update()
+    arrs.update(losses=torch.stack(losses), grad_norms=torch.stack(gnorms))
+    for k, v in enc.module.state_dict().items():
+        arrs["after." + k] = recipe.summary(v.float())
+    arrs["after.head_weight"] = recipe.summary(pfc.weight if rate < 1 else pfc.weight_activated.data)
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), **{k: (v.detach().numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in arrs.items()})
+    dist.destroy_process_group()
+
+
+def gen_train_steps_ws2():
+    for tag, rate in {"rate10": 1.0, "rate03": 0.3}.items():
+        with tempfile.TemporaryDirectory() as td:
+            mp.spawn(_train_ws2_worker, args=(2, os.path.join(td, "pg"), rate, td), nprocs=2, join=True)
+            arrs = dict(C=256, B=8, steps=3, rate=rate, lr=0.1, momentum=0.9, wd=5e-4, ws=2)
+            for r in range(2):
+                for k, v in np.load(os.path.join(td, "rank%d.npz" % r)).items():
+                    arrs["r%d_%s" % (r, k)] = v
+            save("train_step_resnet18_c256_ws2_" + tag, **arrs)
+
+
 # ----------------------------------------------------------------------------- SwinV2-style backbone
 def _swin_ref():
     """reference nets/SwinV2.py needs three symbols of timm.models.layers: stubbed, container only"""
@@ -458,6 +521,7 @@ GENS = {
     "basicblock": gen_basicblock,
     "resnet": gen_resnet,
     "train": gen_train_steps,
+    "train_ws2": gen_train_steps_ws2,
 }
 
 if __name__ == "__main__":
