@@ -12,6 +12,12 @@ SOURCES = ["misc.hip", "bn.hip", "stem.hip", "stem_fused.hip", "igemm_nt.hip", "
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-munsafe-fp-atomics",
          "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
+# experiment builds (tools/ab_libs.sh): FRHIP_VARIANT=<name> FRHIP_CXXFLAGS="-DX=1 ..." python -m frhip.build
+#   -> build/var/libfrhip_<name>.so from its own object directory; the in-tree libfrhip.so is untouched
+VARIANT = os.environ.get("FRHIP_VARIANT", "")
+if VARIANT:
+    FLAGS = FLAGS + os.environ.get("FRHIP_CXXFLAGS", "").split()
+    LIB = os.path.join(HERE, "build", "var", "libfrhip_%s.so" % VARIANT)
 
 
 def _digest(paths):
@@ -34,7 +40,7 @@ def _stale(target, deps):
 
 def build(force=False, verbose=False):
     """Compile every HIP source for gfx950 and link libfrhip.so.  Returns the library path."""
-    objdir = os.path.join(HERE, "build")
+    objdir = os.path.join(HERE, "build", "var", VARIANT) if VARIANT else os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     headers.append(os.path.join(ROOT, "include", "frhip.h"))

@@ -27,6 +27,10 @@ _FUSE_BN1 = int(os.environ.get("FRHIP_FUSE_BN1", "0"))
 # the main stream holds at the hand-over): 27.16 -> 26.9 ms on the ResNet50 step.  One hand-over per block instead of one per
 # weight gradient (fewer barrier packets, but conv2's weight gradient starts a data-gradient later) measured 27.3 -> 27.7: off.
 _WGRAD_EARLY = os.environ.get("FRHIP_WGRAD_EARLY", "1") == "1"
+# ... except for layers of at most this many channels, whose weight gradient is handed over BEHIND the data-gradient that reads the
+# same dy (experiment: on the wide early maps the BatchNorm-backward pass in front of each data-gradient is long and HBM-bound,
+# and a weight gradient that starts with the data-gradient is done before the next such pass begins)
+_WGRAD_LATE_MAXC = int(os.environ.get("FRHIP_WGRAD_LATE_MAXC", "64"))   # same-box A/B, two rounds: 26.15 / 26.13 (0) -> 26.06 / 26.04 (64), 26.11 / 26.16 (128), 26.40 / 26.37 ms (256)
 _BATCH_WGRAD = os.environ.get("FRHIP_BATCH_WGRAD", "0") == "1"
 _DTYPES = {"bf16": torch.bfloat16, "bfloat16": torch.bfloat16, "fp32": torch.float32, "float32": torch.float32}
 
@@ -559,22 +563,24 @@ def basic_block_backward(blk, s, dout, dt, bc, part2=None, next_bn=None):
             bc.wgrad(dy2, s.a1, phys_grad(G(blk.conv2.weight)), 3, 3, blk.stride, 1)
     # the side stream waits for what the main stream has enqueued at the moment of the hand-over: hand a weight gradient
     # over as soon as its operands are enqueued, i.e. BEFORE the data-gradient that reads the same dy
-    if _WGRAD_EARLY:
+    early2 = _WGRAD_EARLY and dy2.shape[3] > _WGRAD_LATE_MAXC
+    early1 = _WGRAD_EARLY and s.x.shape[3] > _WGRAD_LATE_MAXC
+    if early2:
         wgrad2()
     da1, part1 = ops.conv_dgrad(dy2, w2t, s.y1.shape, 3, 3, blk.stride, 1, bnred=(s.y1, s.st1, True))
-    if not _WGRAD_EARLY:
+    if not early2:
         wgrad2()
     dy1 = ops.bn_backward(da1, s.y1, s.st1, blk.bn1.weight.data, G(blk.bn1.weight), G(blk.bn1.bias), relu_mask=True,
                           part=part1)
     w1t = s.w1t if getattr(s, "w1t", None) is not None else ops.pack_wt(blk.conv1.physical(), dt)
-    if _WGRAD_EARLY:
+    if early1:
         bc.wgrad(dy1, s.x, phys_grad(G(blk.conv1.weight)), 3, 3, 1, 1)
     if next_bn is not None:
         dx = ops.conv_dgrad(dy1, w1t, s.x.shape, 3, 3, 1, 1, residual=shortcut, bnred=(next_bn[0], next_bn[1], len(next_bn) > 2 and bool(next_bn[2])),
                             residual_stride=sc_stride)
     else:
         dx = ops.conv_dgrad(dy1, w1t, s.x.shape, 3, 3, 1, 1, residual=shortcut, residual_stride=sc_stride)
-    if not _WGRAD_EARLY:
+    if not early1:
         bc.wgrad(dy1, s.x, phys_grad(G(blk.conv1.weight)), 3, 3, 1, 1)
     bc.flush_wgrads()
     return dx
