@@ -362,10 +362,6 @@ def main():
         torch.cuda.synchronize()
 
     use_graph = world == 1 and args.graph and not args.dist_path
-    if os.environ.get("FRHIP_BENCH_HIPRIO", "0") == "1":        # experiment: the step's own stream outranks the weight-gradient side stream
-        hp = torch.cuda.Stream(priority=-1)
-        hp.wait_stream(torch.cuda.current_stream())
-        torch.cuda.set_stream(hp)
     meter.collect = True
     model.training_step((img, ids.clone()))          # eager; also records the conv launch list for the probe
     meter.collect = False

@@ -168,7 +168,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void halo8_kernel(Halo
     ml.run(g, a, b, smem, mtile, ntile);
     const int lane = lane_id(), wave = wave_id();
     const int wm = wave / WN, wn = wave % WN;
-    const int m0 = g.m_origin + mtile * Tile::BM + wm * Tile::WROWS, n0 = ntile * Tile::BN + wn * 64;
+    const int m0 = mtile * Tile::BM + wm * Tile::WROWS, n0 = ntile * Tile::BN + wn * 64;
     const int fg = lane >> 4;
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
@@ -184,7 +184,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void halo8_kernel(Halo
     eo.fetch(nullptr, nullptr, g.M, g.Nout, m0, n0, 0, 0, &br.map);
     const char* mine = ml.template stage_out<bf16_t>(smem);
     nt_epilogue_store<bf16_t, WM, WN, Tile::WROWS, Tile::THREADS, Tile::BN>(mine, Tile::template stage_pitch<bf16_t>(), smem, g.M, g.Nout,
-                                                                            out, false, stats, br, eo, g.stat_row0 + mtile, ntile, m0, n0);
+                                                                            out, false, stats, br, eo, mtile, ntile, m0, n0);
 }
 
 static int g_fp8_halo = 1;      // 3x3 / stride-1 layers on the halo main loop (0: generic NT kernel; test hook frhip_set_fp8_halo)
@@ -200,8 +200,8 @@ static int halo8_run(const void* x8, const void* w8, const float* wscale, float 
     if (ab > 0x7fffffffLL || bb > 0x7fffffffLL) { set_error("igemm_fp8(halo): tensor exceeds the 2 GiB buffer window"); return FRHIP_EINVAL; }
     HaloGeom g;
     g.H = h; g.W = w; g.C = c; g.M = n * h * w; g.Nout = k; g.Ktot = 9 * c; g.sign = +1;
-    g.m_origin = 0; g.stat_row0 = 0; g.a_bytes = (uint32_t)ab; g.b_bytes = (uint32_t)bb;
-    g.xf_scale = nullptr; g.xf_shift = nullptr; g.wave_prio = 0; g.wide_big = 0;
+    g.a_bytes = (uint32_t)ab; g.b_bytes = (uint32_t)bb;
+    g.xf_scale = nullptr; g.xf_shift = nullptr;
     g.d_hw = make_fastdiv((uint32_t)(h * w)); g.d_w = make_fastdiv((uint32_t)w);
     const int mtiles = (g.M + Tile::BM - 1) / Tile::BM, ntiles = (k + Tile::BN - 1) / Tile::BN;
     const int lds = Tile::template lds_bytes<bf16_t>();

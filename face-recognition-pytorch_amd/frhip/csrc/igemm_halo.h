@@ -31,8 +31,6 @@ struct HaloGeom {
     int H, W, C;            // activation tensor (same spatial size in and out)
     int M, Nout, Ktot;      // N*H*W, output channels, 9*C
     int sign;               // +1 forward (offset = (r-1, s-1)), -1 data-gradient (offset = (1-r, 1-s))
-    int m_origin;           // first output pixel of m-tile 0 of THIS launch (tail launches start behind the full tiles)
-    int stat_row0;          // row of the BN-partial buffer that m-tile 0 of this launch writes
     uint32_t a_bytes, b_bytes;
     // operand transform (XF kernels only): the gathered tensor is the INPUT of a BatchNorm + ReLU and the convolution wants
     // their output -- a = relu(x * xf_scale[c] + xf_shift[c]) is formed in LDS, per 64-channel chunk, right after the window
@@ -40,8 +38,6 @@ struct HaloGeom {
     const float* xf_scale;
     const float* xf_shift;
     FastDiv d_hw, d_w;      // pixel decode of the per-tile prologue without integer division instructions
-    int wide_big;           // wide tile (igemm_halo_wide.h): m-tiles [0, wide_big) have 256 rows, the rest 192
-    int wave_prio;          // > 0: s_setprio for the whole kernel (the critical-path convolutions outrank a co-resident weight gradient)
 };
 
 template <typename T, int WM, int WN, int MT, int HBUFS>
@@ -80,9 +76,6 @@ struct HaloMainloop {
                                         const void* __restrict__ b_ptr, char* smem, int mtile, int ntile) {
         const int lane = lane_id(), wave = wave_id();
         const int wm = wave / WN, wn = wave % WN;
-        if (g.wave_prio == 1) __builtin_amdgcn_s_setprio(1);
-        else if (g.wave_prio == 2) __builtin_amdgcn_s_setprio(2);
-        else if (g.wave_prio >= 3) __builtin_amdgcn_s_setprio(3);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -90,7 +83,7 @@ struct HaloMainloop {
 
         const __amdgpu_buffer_rsrc_t ra = make_rsrc(a_ptr, g.a_bytes);
         const __amdgpu_buffer_rsrc_t rb = make_rsrc(b_ptr, g.b_bytes);
-        const int m0 = g.m_origin + mtile * BM;
+        const int m0 = mtile * BM;
         const int hrows = BM + 2 * g.W + 2;                 // rows actually needed
         const int npieces = (hrows + 7) >> 3;
         const int p_lo = m0 - g.W - 1;                      // linear pixel of halo row 0

@@ -18,11 +18,8 @@
 
 namespace frhip {
 
-// MT_ = 16-pixel sub-tiles per wave: 4 (256-row workgroup tile) or 3 (192 rows).  The LDS layout is that of the 256-row tile
-// for both, so ONE kernel holds both bodies and a launch can mix tile heights (halo_wide_plan in igemm_halo.hip).
-template <int MT_ = 4>
 struct HaloWideTile {
-    static constexpr int WAVES = 4, THREADS = 256, MT = MT_, NTW = 8;    // per wave: MT x 16 pixels, 8 x 16 channels
+    static constexpr int WAVES = 4, THREADS = 256, MT = 4, NTW = 8;      // per wave: 4 x 16 pixels, 8 x 16 channels
     static constexpr int BM = 64 * MT, BN = 128, WROWS = 16 * MT;
     static constexpr int MAXW = 28;
     static constexpr int HROWS = ((256 + 2 * MAXW + 2 + 7) / 8) * 8;     // 320
@@ -38,11 +35,10 @@ struct HaloWideTile {
     static constexpr int LDS = LOOP_BYTES > EPI_BYTES ? LOOP_BYTES : EPI_BYTES;
 };
 
-template <int MT_>
 struct HaloWideMainloop {
-    typedef HaloWideTile<MT_> Tile;
+    typedef HaloWideTile Tile;
     typedef bf16_t T;
-    typedef typename Mma<T>::Frag Frag;
+    typedef Mma<T>::Frag Frag;
     f32x4_t acc[Tile::NTW][Tile::MT];
 
     __device__ __forceinline__ void run(const HaloGeom& g, const void* __restrict__ a_ptr, const void* __restrict__ b_ptr,

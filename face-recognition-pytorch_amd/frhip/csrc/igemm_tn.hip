@@ -252,147 +252,6 @@ __global__ __launch_bounds__(TN_THREADS, 2) void tn_kernel(TnGeom g, const void*
     tn_epilogue<T, RB, NT>(acc, smem, out, g, co0, ci0, tap, taps, slot.split);
 }
 
-// ------------------------------------------------------------------------------------------------------------------
-// "Linear-shift" variant for stride-1 / same-size convolutions (3x3 p1, 1x1 p0) and plain TN GEMMs, bf16.
-// With stride 1 the input pixel of output pixel m at tap (r,s) is simply m + (r-pad)*W + (s-pad) in the linear
-// N*H*W index, so BOTH operand tiles are contiguous 64-row windows: the loader needs two adds per DMA piece and
-// no pixel decode at all.  Pixels whose neighbour falls outside the image are handled on the consumer side: the
-// transposing LDS read takes a per-lane row address, and lanes whose row is padding point at a zero block instead.
-// Each lane only tracks the (ho, wo) of the four pixel rows it addresses, advanced by 64 pixels per K step.
-template <int RB>
-__global__ __launch_bounds__(TN_THREADS, 2) void tn_lin_kernel(TnGeom g, const void* __restrict__ p_ptr,
-                                                               const void* __restrict__ q_ptr, float* __restrict__ out,
-                                                               int co_tiles, int ci_tiles, int taps) {
-    typedef bf16_t T;
-    typedef TnTile<T, RB> Tile;
-    constexpr int NT = Tile::NT;
-    constexpr int ZERO_OFF = 2 * Tile::STAGE_BYTES;          // 16 zero bytes behind the two stages
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int lane = lane_id(), wave = wave_id();
-    const TnSlot slot = tn_slot(co_tiles * ci_tiles * taps);
-    uint32_t lin = (uint32_t)slot.tile;
-    const int tap = (int)(lin % (uint32_t)taps); lin /= (uint32_t)taps;
-    const int ci_tile = (int)(lin % (uint32_t)ci_tiles), co_tile = (int)(lin / (uint32_t)ci_tiles);
-    const int dy = tap / g.S - g.pad, dx = tap % g.S - g.pad;
-    const int shift = dy * g.W + dx;
-    const int ks_begin = slot.split * g.ksteps_per_split;
-    const int ks_end = min(g.ksteps, ks_begin + g.ksteps_per_split);
-    const int wco = wave >> 1, wci = wave & 1;
-
-    f32x4_t acc[NT][NT];
-#pragma unroll
-    for (int a = 0; a < NT; ++a)
-#pragma unroll
-        for (int b = 0; b < NT; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    if (threadIdx.x == 0) *reinterpret_cast<f32x4_t*>(smem + ZERO_OFF) = f32x4_t{0.f, 0.f, 0.f, 0.f};
-
-    const __amdgpu_buffer_rsrc_t rp = make_rsrc(p_ptr, g.p_bytes);
-    const __amdgpu_buffer_rsrc_t rq = make_rsrc(q_ptr, g.q_bytes);
-    const int sub = lane / Tile::CHUNKS, phys = lane % Tile::CHUNKS;
-    const int co0 = co_tile * Tile::BC, ci0 = ci_tile * Tile::BC;
-
-    // ---- loader state: one running byte offset per DMA piece and operand (out-of-range = hardware zero fill)
-    uint32_t offp[Tile::PIECES], offq[Tile::PIECES];
-    const uint32_t incp = (uint32_t)(TN_KP * g.ldp) * 2u, incq = (uint32_t)(TN_KP * g.C) * 2u;
-    bool okp[Tile::PIECES], okq[Tile::PIECES];
-#pragma unroll
-    for (int j = 0; j < Tile::PIECES; ++j) {
-        const int row = (wave * Tile::PIECES + j) * Tile::ROWS_PER_PIECE + sub;
-        const int ce = (phys ^ tn_swz<RB>(row)) * 8;
-        const int m = ks_begin * TN_KP + row;
-        okp[j] = co0 + ce < g.ldp;
-        okq[j] = ci0 + ce < g.C;
-        offp[j] = (uint32_t)((m * g.ldp + co0 + ce) * 2);
-        offq[j] = (uint32_t)(((m + shift) * g.C + ci0 + ce) * 2);     // negative pixel index wraps above 2^31 = out of range
-    }
-    auto stage = [&](int buf) {
-        char* sp = smem + buf * Tile::STAGE_BYTES;
-        char* sq = sp + Tile::TILE_BYTES;
-#pragma unroll
-        for (int j = 0; j < Tile::PIECES; ++j) {
-            const int piece = wave * Tile::PIECES + j;
-            glds16(rp, sp + piece * 1024, okp[j] ? offp[j] : OOB_OFFSET);
-            glds16(rq, sq + piece * 1024, okq[j] ? offq[j] : OOB_OFFSET);
-            offp[j] += incp; offq[j] += incq;
-        }
-    };
-
-    // ---- consumer state: the four pixel rows (of the 64-row K step) this lane supplies addresses for
-    const int fg = lane >> 4, fj = lane & 15, fq = fj >> 2, fp = fj & 3;
-    int prow[4], pho[4], pwo[4], pm[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        prow[i] = (i >> 1) * 32 + 8 * fg + fq + 4 * (i & 1);          // i = 2*kk + half
-        const uint32_t m = (uint32_t)(ks_begin * TN_KP + prow[i]);
-        const uint32_t n = fdiv(m, g.d_howo);
-        const uint32_t rem = m - n * (uint32_t)(g.Ho * g.Wo);
-        const uint32_t ho = fdiv(rem, g.d_wo);
-        pm[i] = (int)m; pho[i] = (int)ho; pwo[i] = (int)(rem - ho * (uint32_t)g.Wo);
-    }
-    // byte offsets inside a tile of this lane's 8-byte transposed-read slot, per row and channel tile
-    int pa[4][NT], qa[4][NT];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const int cp = ((wco * Tile::WC + t * 16) >> 3) + (fp >> 1), cq = ((wci * Tile::WC + t * 16) >> 3) + (fp >> 1);
-            pa[i][t] = prow[i] * RB + ((cp ^ tn_swz<RB>(prow[i])) << 4) + 8 * (fp & 1);
-            qa[i][t] = Tile::TILE_BYTES + prow[i] * RB + ((cq ^ tn_swz<RB>(prow[i])) << 4) + 8 * (fp & 1);
-        }
-
-    typedef __attribute__((ext_vector_type(8))) short i16x8_t;
-    auto tr8 = [&](const char* lo_p, const char* hi_p) {
-        i16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4_t*)LDS_ADDR(lo_p));
-        i16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) i16x4_t*)LDS_ADDR(hi_p));
-        return __builtin_bit_cast(bf16x8_t, (i16x8_t)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
-    };
-
-    auto compute = [&](int buf) {
-        const char* base = smem + buf * Tile::STAGE_BYTES;
-        bool v[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-            v[i] = pm[i] < g.M && (unsigned)(pho[i] + dy) < (unsigned)g.H && (unsigned)(pwo[i] + dx) < (unsigned)g.W;
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            bf16x8_t pf[NT], qf[NT];
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                pf[t] = tr8(base + pa[2 * kk][t], base + pa[2 * kk + 1][t]);
-                qf[t] = tr8(v[2 * kk] ? base + qa[2 * kk][t] : smem + ZERO_OFF,
-                            v[2 * kk + 1] ? base + qa[2 * kk + 1][t] : smem + ZERO_OFF);
-            }
-#pragma unroll
-            for (int a = 0; a < NT; ++a)
-#pragma unroll
-                for (int b = 0; b < NT; ++b) Mma<T>::run(pf[a], qf[b], acc[a][b]);
-        }
-        // advance the four tracked pixels by one K step
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            int wo = pwo[i] + g.adv_wo, ho = pho[i] + g.adv_ho;
-            if (wo >= g.Wo) { wo -= g.Wo; ++ho; }
-            if (ho >= g.Ho) ho -= g.Ho;
-            pwo[i] = wo; pho[i] = ho; pm[i] += TN_KP;
-        }
-    };
-
-    if (ks_begin < ks_end) {
-        stage(0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        int cur = 0;
-        for (int ks = ks_begin; ks < ks_end - 1; ++ks) {
-            stage(cur ^ 1);
-            compute(cur);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            cur ^= 1;
-        }
-        compute(cur);
-    }
-    tn_epilogue<T, RB, NT>(acc, smem, out, g, co0, ci0, tap, taps, slot.split);
-}
 
 // ------------------------------------------------------------------------------------------------------------------
 // "All nine taps" weight-gradient for 3x3 / stride-1 / pad-1 convolutions, bf16.
@@ -760,9 +619,6 @@ static int g_tn_taps9 = 1;
 // the stand-alone-fastest choice (kernel micro-benchmarks use it).
 static int g_t9_narrow = getenv("FRHIP_T9_NARROW") ? atoi(getenv("FRHIP_T9_NARROW")) : 1;
 static int g_t9_lds_pad = getenv("FRHIP_T9_LDS_PAD") ? atoi(getenv("FRHIP_T9_LDS_PAD")) : 83968;
-static int g_t9_maxsteps = getenv("FRHIP_T9_MAXSTEPS") ? atoi(getenv("FRHIP_T9_MAXSTEPS")) : 0;
-static int g_t9_stages = getenv("FRHIP_T9_STAGES") ? atoi(getenv("FRHIP_T9_STAGES")) : 3;      // 4-wave tile, W <= 28: LDS stages
-static int g_t9_slots = getenv("FRHIP_T9_SLOTS") ? atoi(getenv("FRHIP_T9_SLOTS")) : 0;     // experiment: workgroups per weight-gradient launch (fewer than 256 leaves CUs to the main stream alone)
 template <int WCO, int WCI, int COF, int CIF, bool XF = false, int NST = 2, int QROWS = T9_QROWS>
 static int tn_taps9_launch(const TnGeom& g, const void* p, const void* q, float* out, int splits, hipStream_t stream) {
     typedef T9Cfg<WCO, WCI, COF, CIF, NST, QROWS> Cfg;
@@ -842,27 +698,6 @@ __global__ __launch_bounds__(256) void slab9_final_kernel(const float* __restric
             *o += acc[r];
         }
     }
-}
-
-static int g_tn_linear = 0;    // measured: no gain over the gather kernel (the TN main loop is not VALU-bound); kept for tests
-
-template <int RB>
-static int tn_lin_launch(const TnGeom& g, const void* p, const void* q, float* out, int taps, int splits, hipStream_t stream) {
-    typedef TnTile<bf16_t, RB> Tile;
-    const int co_tiles = (g.Kc + Tile::BC - 1) / Tile::BC, ci_tiles = (g.C + Tile::BC - 1) / Tile::BC;
-    const int lds = Tile::LDS_BYTES + 16;
-    auto kern = tn_lin_kernel<RB>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
-            set_error("igemm_tn(lin): cannot raise dynamic LDS to %d bytes", lds);
-            return FRHIP_ELAUNCH;
-        }
-        attr_done = true;
-    }
-    dim3 grid(co_tiles * ci_tiles * taps * splits);
-    hipLaunchKernelGGL(kern, grid, dim3(TN_THREADS), lds, stream, g, p, q, out, co_tiles, ci_tiles, taps);
-    return check_launch("igemm_tn(lin)");
 }
 
 template <typename T, int RB>
@@ -981,7 +816,7 @@ static int tn_run(int dtype, const void* p, const void* q, float* out, int n, in
         const bool wide = kc > 64 && !g_t9_narrow;
         const int co_t = wide ? 128 : 64;
         const long long tiles = 1LL * ((kc + co_t - 1) / co_t) * ((c + 63) / 64);
-        const int slots = g_t9_slots > 0 ? g_t9_slots : 256 * ((wide || g_t9_lds_pad > 81920) ? 1 : 2);
+        const int slots = 256 * ((wide || g_t9_lds_pad > 81920) ? 1 : 2);
         int best = 1; double best_t = 1e30;
         const int max_splits = g.ksteps / 8 > 0 ? g.ksteps / 8 : 1;
         for (int sp = 1; sp <= max_splits && sp <= 1024; ++sp) {
@@ -990,17 +825,11 @@ static int tn_run(int dtype, const void* p, const void* q, float* out, int n, in
             if (t < best_t * 0.98) { best_t = t; best = sp; }
         }
         if (splits <= 0) splits = best;
-        if (g_t9_maxsteps > 0) {          // experiment: short-lived workgroups (at most this many K steps each), as many splits as the slab workspace holds
-            int want = (g.ksteps + g_t9_maxsteps - 1) / g_t9_maxsteps;
-            const size_t cap = ws_bytes / (out_elems * sizeof(float));
-            if ((size_t)want > cap) want = (int)cap;
-            if (want > splits) splits = want;
-        }
         if (splits > g.ksteps) splits = g.ksteps;
         g.ksteps_per_split = (g.ksteps + splits - 1) / splits;
         splits = (g.ksteps + g.ksteps_per_split - 1) / g.ksteps_per_split;
         float* dst = (kc % 4 == 0) ? tn_pick_dst(g, out, splits, out_elems, ws, ws_bytes) : out;      // slab layout packs co in fours
-        const bool deep = !wide && g_t9_stages == 3 && 64 + 2 * w + 2 <= 128;      // three stages of a 128-row window
+        const bool deep = !wide && 64 + 2 * w + 2 <= 128;      // three stages of a 128-row window
         if (xf_scale) rc = wide ? tn_taps9_launch<2, 4, 4, 1, true>(g, p, q, dst, splits, stream)
                          : deep ? tn_taps9_launch<1, 4, 4, 1, true, 3, 128>(g, p, q, dst, splits, stream)
                                 : tn_taps9_launch<1, 4, 4, 1, true>(g, p, q, dst, splits, stream);
@@ -1034,8 +863,6 @@ static int tn_run(int dtype, const void* p, const void* q, float* out, int n, in
     if (splits > g.ksteps) splits = g.ksteps;
     g.ksteps_per_split = (g.ksteps + splits - 1) / splits;
     splits = (g.ksteps + g.ksteps_per_split - 1) / g.ksteps_per_split;
-    const bool linear = g_tn_linear && dtype == FRHIP_DT_BF16 && stride == 1 && g.Ho == h && g.Wo == w && r == s &&
-                        1LL * (M + 64 + 2LL * w + 2) * (ldp > c ? ldp : c) * es < 0x7fffffffLL;
     if (overwrite && splits == 1) {
         // out = result (not +=) and a single K split: the "slab" store path with slab 0 = out itself -- plain coalesced stores,
         // no zero fill by the caller and no fp32 atomic read-modify-write pass over the output (the head's 250-MB dW)
@@ -1048,9 +875,7 @@ static int tn_run(int dtype, const void* p, const void* q, float* out, int n, in
         return FRHIP_ELAUNCH;
     }
     float* dst = tn_pick_dst(g, out, splits, out_elems, ws, ws_bytes);
-    if (linear) rc = big ? tn_lin_launch<256>(g, p, q, dst, taps, splits, stream)
-                         : tn_lin_launch<128>(g, p, q, dst, taps, splits, stream);
-    else if (dtype == FRHIP_DT_BF16) rc = big ? tn_launch<bf16_t, 256>(g, p, q, dst, taps, splits, stream)
+    if (dtype == FRHIP_DT_BF16) rc = big ? tn_launch<bf16_t, 256>(g, p, q, dst, taps, splits, stream)
                                               : tn_launch<bf16_t, 128>(g, p, q, dst, taps, splits, stream);
     else rc = big ? tn_launch<float, 256>(g, p, q, dst, taps, splits, stream)
                   : tn_launch<float, 128>(g, p, q, dst, taps, splits, stream);
@@ -1061,10 +886,10 @@ static int tn_run(int dtype, const void* p, const void* q, float* out, int n, in
 
 using namespace frhip;
 
-extern "C" int frhip_set_tn_linear(int enabled) {
-    // bit 0: linear-shift kernel; bits 1-2: all-nine-taps 3x3 kernel (0 off, 1 auto = narrow layers only, 2 always)
-    const int old = g_tn_linear | (g_tn_taps9 << 1);
-    g_tn_linear = enabled & 1; g_tn_taps9 = (enabled >> 1) & 3;
+extern "C" int frhip_set_wgrad_taps9(int enabled) {
+    // 1 (default): 3x3 / stride-1 bf16 weight gradients on the nine-tap kernel; 0: on the per-tap gather kernel; < 0 queries
+    const int old = g_tn_taps9;
+    if (enabled >= 0) g_tn_taps9 = enabled ? 1 : 0;
     return old;
 }
 

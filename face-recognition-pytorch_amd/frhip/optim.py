@@ -152,6 +152,14 @@ class SGD(torch.optim.SGD):
         self._keep_early = entries
         return True
 
+    def zero_grad(self, set_to_none=True):
+        """A new step begins: an early group update whose step() never came (exception, skipped step, inspection between backward()
+        and step()) must not make the NEXT step's hook think its group is already done -- join its stream and forget it."""
+        for st in self._early.values():
+            torch.cuda.current_stream().wait_stream(st)
+        self._early = {}
+        return super().zero_grad(set_to_none=set_to_none)
+
     def _fallback(self, clip, done=()):
         """torch's own step; `done` = group indices step_group_early has already updated (their gradients are hidden meanwhile)"""
         self._norm = torch.nn.utils.clip_grad_norm_(list(clip[0]), float(clip[1])) if clip is not None else None

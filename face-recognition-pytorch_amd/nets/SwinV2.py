@@ -140,10 +140,22 @@ class CpbBatch:
         from frhip._abi import check, lib
         self.blocks = list(blocks)
         self.check, self.lib = check, lib
+        import ctypes
+        lim = [ctypes.c_int(0) for _ in range(3)]             # the kernels' compile-time limits (LDS arrays, grid.y = max heads)
+        check(lib().frhip_cpb_limits(*[ctypes.byref(v) for v in lim]), "frhip_cpb_limits")
+        max_entries, max_heads, hidden = (v.value for v in lim)
         sizes = []
         for blk in self.blocks:
             at = blk.attn
             n = at.window_size[0] * at.window_size[1]
+            entries = (2 * at.window_size[0] - 1) * (2 * at.window_size[1] - 1)
+            if entries > max_entries or at.num_heads > max_heads or at.cpb_mlp[0].out_features != hidden or n > 49:
+                raise ValueError("CpbBatch: window %s / %d heads / hidden %d exceed the position-bias kernels' limits "
+                                 "(%d table entries, %d heads, hidden width %d, 49 tokens)"
+                                 % (tuple(at.window_size), at.num_heads, at.cpb_mlp[0].out_features, max_entries, max_heads, hidden))
+            idx, tab = at.relative_position_index, at.relative_coords_table
+            if idx.dtype != torch.int64 or not idx.is_contiguous() or tab.dtype != torch.float32 or not tab.is_contiguous():
+                raise ValueError("CpbBatch: relative_position_index must be contiguous int64 and relative_coords_table contiguous fp32")
             sizes.append((at.num_heads * n * n, at.num_heads))
         pad4 = lambda v: (v + 3) // 4 * 4                     # every view starts 16-byte aligned
         total = sum(pad4(a) + pad4(b) for a, b in sizes)

@@ -31,7 +31,6 @@ _WGRAD_EARLY = os.environ.get("FRHIP_WGRAD_EARLY", "1") == "1"
 # same dy (experiment: on the wide early maps the BatchNorm-backward pass in front of each data-gradient is long and HBM-bound,
 # and a weight gradient that starts with the data-gradient is done before the next such pass begins)
 _WGRAD_LATE_MAXC = int(os.environ.get("FRHIP_WGRAD_LATE_MAXC", "64"))   # same-box A/B, two rounds: 26.15 / 26.13 (0) -> 26.06 / 26.04 (64), 26.11 / 26.16 (128), 26.40 / 26.37 ms (256)
-_BATCH_WGRAD = os.environ.get("FRHIP_BATCH_WGRAD", "0") == "1"
 _DTYPES = {"bf16": torch.bfloat16, "bfloat16": torch.bfloat16, "fp32": torch.float32, "float32": torch.float32}
 
 
@@ -234,7 +233,6 @@ class BackwardCtx:
         self.reduced_from = self.flat.numel()          # arena[reduced_from:] has been handed to RCCL
         self.works = []
         self.before_join = []                          # deferred gradient work (e.g. the batched position-bias backward)
-        self.pending = []                              # weight gradients waiting for flush_wgrads()
 
     def G(self, p):
         return self.grads[p]
@@ -258,22 +256,7 @@ class BackwardCtx:
             fn = lambda: ops.conv_wgrad_bnrelu(dy, x, bnrelu, gview, r, s, stride, pad)       # noqa: E731
         else:
             fn = lambda: ops.conv_wgrad(dy, x, gview, r, s, stride, pad)                      # noqa: E731
-        if _BATCH_WGRAD and self.side is not None:
-            self.pending.append((fn, (dy, x, gview, bnrelu)))       # launched by flush_wgrads(): one stream hand-over per block
-        else:
-            self.on_side(fn, dy, x, gview, bnrelu)
-
-    def flush_wgrads(self):
-        """launch the weight gradients queued since the last flush on the side stream, behind ONE event of the main stream
-        (every cross-stream hand-over is a barrier packet in the main queue: two per block add up over 25 blocks)"""
-        if not self.pending:
-            return
-        todo, self.pending = self.pending, []
-        self.keep.extend(t for _, t in todo)
-        self.side.wait_stream(self.main)
-        with torch.cuda.stream(self.side):
-            for fn, _ in todo:
-                fn()
+        self.on_side(fn, dy, x, gview, bnrelu)
 
     def _reduce(self, lo, hi):
         if hi <= lo:
@@ -304,7 +287,6 @@ class BackwardCtx:
             self.reduced_from = lo
 
     def join(self):
-        self.flush_wgrads()
         for fn in self.before_join:
             fn()
         self.before_join = []
@@ -582,7 +564,6 @@ def basic_block_backward(blk, s, dout, dt, bc, part2=None, next_bn=None):
         dx = ops.conv_dgrad(dy1, w1t, s.x.shape, 3, 3, 1, 1, residual=shortcut, residual_stride=sc_stride)
     if not early1:
         bc.wgrad(dy1, s.x, phys_grad(G(blk.conv1.weight)), 3, 3, 1, 1)
-    bc.flush_wgrads()
     return dx
 
 

@@ -59,20 +59,15 @@ int frhip_spin(long long ticks, frhip_stream_t stream);
 int frhip_nt_block_m(int k);
 /* number of partial rows frhip_conv_fwd writes into stats_partial for this convolution (m = n*ho*wo output pixels) */
 int frhip_conv_stat_rows(int dtype, int m, int k, int h, int w, int c, int r, int s, int stride, int pad);
-/* test hook: bit 0 enables the linear-shift (stride-1) weight-gradient kernel; bits 1-2 select the all-nine-taps 3x3
- * kernel (0 off, 1 = automatic: 64-channel layers only, 2 = always).  Default 2 (= auto, linear off).  Returns the old value */
-int frhip_set_tn_linear(int enabled);
-/* test hook.  bits 0-1: 0 disables the LDS-halo 3x3/s1 kernel (generic NT kernel is used instead), 1 automatic tile choice,
- * 2 forces the 4-wave 256x64 tile (two workgroups per CU), 3 the 8-wave 256x128 tile; bit 5 (32) enables the tail-balancing
- * second launch of smaller tiles; bit 6 (64) turns the 64 x 128-per-wave tile of the W <= 28 layers OFF (automatic mode uses it).
- * Returns the old value */
+/* test hook: 1 (default) = 3x3 / stride-1 bf16 weight gradients on the nine-tap kernel, 0 = on the per-tap gather kernel;
+ * < 0 queries.  Returns the old value */
+int frhip_set_wgrad_taps9(int enabled);
+/* test hook: 0 disables the LDS-halo 3x3/s1 kernel (generic NT kernel is used instead), 1 automatic tile choice,
+ * 2 forces the 4-wave 256x64 tile (two workgroups per CU), 3 the 8-wave 256x128 tile.  Returns the old value */
 int frhip_set_conv_halo(int enabled);
-/* test / tuning hook of the halo kernels' tile plan.  Low 16 bits: resident workgroups a launch is balanced for (default 512 = 2 per
- * CU; 0 = equal 256-row tiles only; small values make small test shapes take the mixed 256 / 192-row plan).  Bit 20 set: bits
- * 16-17 = which launches get the mixed plan (1 forward, 2 data-gradient, 3 both; default 0: none).  Bit 21 set: bits 18-19 = which
- * launches may use the 64 x 128-per-wave tile (1 forward, 2 data-gradient [default], 3 both).  Returns the old value with bits 20
- * and 21 set, so passing it back restores the previous state */
-int frhip_set_halo_wide_slots(int slots);
+/* test / tuning hook: which 3x3/s1 launches of the W <= 28 layers (bf16, automatic mode) may use the 64 x 128-per-wave halo tile:
+ * bit 0 forward, bit 1 data-gradient (default 2); < 0 queries.  Returns the old value */
+int frhip_set_halo_wide_dirs(int dirs);
 /* test / micro-benchmark hook: force the NT tile (0 auto, 1 128x128, 2 256x64, 3 256x128, 4 256x256); returns the old value */
 int frhip_set_nt_tile(int tile);
 int frhip_conv_fwd(int dtype, const void* x, const void* w, void* y, float* stats_partial,

@@ -59,12 +59,12 @@ def test_alternative_kernels_agree_at_batch_512():
     np.testing.assert_allclose(y_h.float().cpu().numpy(), y_nt.float().cpu().numpy(), rtol=2e-2, atol=2e-2)
     np.testing.assert_allclose(p_h.sum(0).cpu().numpy(), p_nt.sum(0).cpu().numpy(), rtol=1e-3, atol=1.0)
     dws = []
-    for mode in (0, 2):                     # per-tap gather kernel, nine-tap kernel
-        o = lib().frhip_set_tn_linear(mode)
+    for mode in (0, 1):                     # per-tap gather kernel, nine-tap kernel
+        o = lib().frhip_set_wgrad_taps9(mode)
         try:
             dw = torch.zeros((256, 3, 3, 256), dtype=torch.float32, device="cuda")
             ops.conv_wgrad(dy, x, dw, 3, 3, 1, 1)
             dws.append(dw)
         finally:
-            lib().frhip_set_tn_linear(o)
+            lib().frhip_set_wgrad_taps9(o)
     np.testing.assert_allclose(dws[0].cpu().numpy(), dws[1].cpu().numpy(), rtol=1e-3, atol=1e-3 * dws[0].abs().max().item())

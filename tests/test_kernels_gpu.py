@@ -151,60 +151,16 @@ def test_halo_wide_tile_is_bit_identical_to_the_four_wave_tile(case):
     rows = n * h * h
     st = ops.bn_finalize(ops.colstats(y_bn.view(rows, c)), rows, torch.ones(c).cuda(), torch.zeros(c).cuda(), None, None)
     outs = []
-    old_plan = lib().frhip_set_halo_wide_slots(0 | (3 << 18) | (1 << 21))       # equal tiles; wide tile allowed in both directions
-    for mode in (1, 2 | 64):         # auto with the wide tile / the 4-wave tile forced, wide off
-        old = lib().frhip_set_conv_halo(mode)
+    for dirs in (3, 0):              # the wide tile in both directions / nowhere (the 4-wave tile runs instead)
+        old = lib().frhip_set_halo_wide_dirs(dirs)
         y, part = ops.conv_fwd(x, w, 1, 1)
         y2, _ = ops.conv_fwd(x, w, 1, 1, want_stats=False)
         dx, bpart = ops.conv_dgrad(dy, wt, (n, h, h, c), 3, 3, 1, 1, residual=res, bnred=(y_bn, st, True))
         dx2 = ops.conv_dgrad(dy, wt, (n, h, h, c), 3, 3, 1, 1)
-        lib().frhip_set_conv_halo(old)
+        lib().frhip_set_halo_wide_dirs(old)
         outs.append((y, part, y2, dx, bpart, dx2))
     for a, b in zip(*outs):
         assert a.shape == b.shape and torch.equal(a, b)
-    # mixed tile heights (256- and 192-row tiles, as many workgroups as fill whole rounds of `slots` resident ones), on the wide
-    # tile (dirs 3) and on the 4-wave tile (wide off: conv_halo bit 6): the same outputs bit for bit; the BN partial sums come in
-    # more rows and add up to the same column sums
-    for slots in (8, 16):
-        for mode in (1, 1 | 64):
-            lib().frhip_set_halo_wide_slots(slots | (3 << 16) | (3 << 18) | (3 << 20))      # plan for forward and data-gradient
-            old = lib().frhip_set_conv_halo(mode)
-            y, part = ops.conv_fwd(x, w, 1, 1)
-            dx, bpart = ops.conv_dgrad(dy, wt, (n, h, h, c), 3, 3, 1, 1, residual=res, bnred=(y_bn, st, True))
-            lib().frhip_set_conv_halo(old)
-            assert torch.equal(y, outs[0][0]) and torch.equal(dx, outs[0][3])
-            np.testing.assert_allclose(part.sum(0).cpu().numpy(), outs[0][1].sum(0).cpu().numpy(), rtol=1e-4, atol=1e-2)
-            np.testing.assert_allclose(bpart.sum(0).cpu().numpy(), outs[0][4].sum(0).cpu().numpy(), rtol=1e-4, atol=1e-2)
-    lib().frhip_set_halo_wide_slots(old_plan)
-
-
-@pytest.mark.parametrize("case", [(48, 56, 64, 64, 1), (400, 7, 512, 512, 3), (200, 14, 256, 256, 1)])
-def test_halo_tail_balancing_equals_single_launch(case):
-    """more tiles than resident workgroups: the full rounds run 256-row tiles and a second launch covers the rest with
-    smaller tiles -- same outputs, same BN partial sums (fewer / more partial rows, equal column sums)"""
-    ops = _ops()
-    from frhip._abi import lib
-    n, h, c, k, mode = case
-    x = rnd(70, (n, h, h, c)).bfloat16().cuda()
-    w = (rnd(71, (k, 3, 3, c)) * 0.05).bfloat16().cuda()
-    dy = rnd(72, (n, h, h, k)).bfloat16().cuda()
-    wt = ops.pack_wt(w.float(), torch.bfloat16)
-    res = rnd(73, (n, h, h, c)).bfloat16().cuda()
-    y_bn = rnd(74, (n, h, h, c)).bfloat16().cuda()
-    rows = n * h * h
-    st = ops.bn_finalize(ops.colstats(y_bn.view(rows, c)), rows, torch.ones(c).cuda(), torch.zeros(c).cuda(), None, None)
-    outs = []
-    for tail in (32, 0):
-        old = lib().frhip_set_conv_halo(mode | tail)
-        y, part = ops.conv_fwd(x, w, 1, 1)
-        dx, bpart = ops.conv_dgrad(dy, wt, (n, h, h, c), 3, 3, 1, 1, residual=res, bnred=(y_bn, st, True))
-        lib().frhip_set_conv_halo(old)
-        outs.append((y, part, dx, bpart))
-    a, b = outs
-    assert a[1].shape[0] != b[1].shape[0], "the case must be large enough for a tail launch"
-    assert torch.equal(a[0], b[0]) and torch.equal(a[2], b[2])
-    for i in (1, 3):
-        np.testing.assert_allclose(a[i].sum(0).cpu().numpy(), b[i].sum(0).cpu().numpy(), rtol=1e-4, atol=1e-2)
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
@@ -260,24 +216,24 @@ def test_dgrad_compact_stride2_residual(dtype, case):
     assert torch.equal(a2, b2) and torch.equal(a2, a) and torch.equal(pa, pb)
 
 
-def test_linear_shift_wgrad_equals_generic_wgrad():
-    """stride-1 weight gradient: contiguous-window kernel (padding resolved at the LDS read) vs the gather kernel"""
+def test_nine_tap_wgrad_equals_generic_wgrad():
+    """stride-1 3x3 weight gradient: the all-nine-taps kernel (one staged window per K step, padding resolved at the LDS read)
+    vs the per-tap gather kernel"""
     ops = _ops()
     from frhip._abi import lib
     for (n, h, c, k, r) in [(3, 56, 64, 64, 3), (5, 28, 128, 128, 3), (7, 14, 256, 256, 3), (11, 7, 512, 512, 3),
-                            (4, 9, 64, 128, 1), (2, 10, 96, 192, 3), (2, 56, 64, 128, 3), (1, 5, 72, 40, 3)]:
+                            (2, 10, 96, 192, 3), (2, 56, 64, 128, 3), (1, 5, 72, 40, 3)]:
         pad = (r - 1) // 2
         x = rnd(50, (n, h, h, c)).bfloat16().cuda()
         dy = rnd(51, (n, h, h, k)).bfloat16().cuda()
         outs = []
-        for lin in (4, 1, 0):          # nine-tap kernel forced / linear-shift kernel / plain gather kernel
-            old = lib().frhip_set_tn_linear(lin)
+        for taps9 in (1, 0):
+            old = lib().frhip_set_wgrad_taps9(taps9)
             dw = torch.zeros((k, r, r, c), dtype=torch.float32, device="cuda")
             ops.conv_wgrad(dy, x, dw, r, r, 1, pad)
-            lib().frhip_set_tn_linear(old)
+            lib().frhip_set_wgrad_taps9(old)
             outs.append(dw.cpu())
-        for o in outs[:2]:
-            np.testing.assert_allclose(o.numpy(), outs[2].numpy(), rtol=1e-4, atol=1e-4 * outs[2].abs().max().item())
+        np.testing.assert_allclose(outs[0].numpy(), outs[1].numpy(), rtol=1e-4, atol=1e-4 * outs[1].abs().max().item())
 
 
 @pytest.mark.parametrize("dtype", DTYPES)

@@ -212,3 +212,40 @@ def test_sgd_step_group_early_equals_plain_step():
         opt.step_group_early(1, side)
         with pytest.raises(RuntimeError):
             opt.step(clip=(pa + ph, 5.0))                                   # a group updated early must not be in the clip set
+
+
+@pytest.mark.gpu
+def test_early_update_marker_does_not_survive_a_skipped_step():
+    """backward() armed and ran the early head update, but step() never came (exception, skipped step).  zero_grad() of
+    the next step joins the side stream and forgets the marker, so that step's early update runs again and step() does not skip a
+    group nobody updated -- against a second optimizer that simply never used the early path."""
+    from frhip.optim import SGD
+    torch.manual_seed(4)
+    a, h = [torch.randn(64, 32, device="cuda")], [torch.randn(500, 64, device="cuda")]
+    pa, ph = [torch.nn.Parameter(a[0].clone())], [torch.nn.Parameter(h[0].clone())]
+    qa, qh = [torch.nn.Parameter(a[0].clone())], [torch.nn.Parameter(h[0].clone())]
+    opt = SGD([{"params": pa}, {"params": ph}], lr=0.1, momentum=0.9, weight_decay=5e-4)
+    ref = SGD([{"params": qa}, {"params": qh}], lr=0.1, momentum=0.9, weight_decay=5e-4)
+    side = torch.cuda.Stream()
+    g0 = [torch.randn_like(a[0]), torch.randn_like(h[0])]
+    for p, g in zip(pa + ph, g0):
+        p.grad = g.clone()
+    assert opt.step_group_early(1, side) is True          # the head group is updated ...
+    with torch.no_grad():                                  # ... the reference takes the same head-only update
+        for p, g in zip(qh, g0[1:]):
+            p.grad = g.clone()
+        for p in qa:
+            p.grad = None
+    ref.step()
+    opt.zero_grad()                                        # step() is skipped; the next step begins
+    assert not opt._early
+    ref.zero_grad()
+    g1 = [torch.randn_like(a[0]), torch.randn_like(h[0])]
+    for p, q, g in zip(pa + ph, qa + qh, g1):
+        p.grad, q.grad = g.clone(), g.clone()
+    assert opt.step_group_early(1, side) is True          # not refused as "already done"
+    opt.step(clip=(pa, 5.0))
+    ref.step(clip=(qa, 5.0))
+    torch.cuda.synchronize()
+    for p, q in zip(pa + ph, qa + qh):
+        torch.testing.assert_close(p.data, q.data, rtol=1e-6, atol=1e-7)

@@ -29,12 +29,14 @@ for (b, h, c) in [(2048, 16, 128), (1024, 16, 256), (4096, 8, 512)]:
     w = (torch.randn(c, 3, 3, c, device="cuda") * 0.05).bfloat16()
     flops = 2.0 * b * h * h * c * 9 * c
     line = "B=%4d h=%2d c=%3d GF=%6.1f |" % (b, h, c, flops / 1e9)
-    for name, mode in (("wide", 1), ("4-wave", 2 | 64), ("8-wave", 3 | 64)):
+    for name, mode, dirs in (("wide", 1, 3), ("4-wave", 2, 0), ("8-wave", 3, 0)):
         lib().frhip_set_conv_halo(mode)
+        lib().frhip_set_halo_wide_dirs(dirs)
         if what == "fwd":
             us = timeit(lambda: ops.conv_fwd(x, w, 1, 1))
         else:
             us = timeit(lambda: ops.conv_dgrad(x, w, (b, h, h, c), 3, 3, 1, 1))
         line += " %s %6.1fus %5.0fTF |" % (name, us, flops / us / 1e6)
     lib().frhip_set_conv_halo(1)
+    lib().frhip_set_halo_wide_dirs(2)
     print(line, flush=True)

@@ -96,9 +96,9 @@ for (h, c, k, r, stride) in SHAPES:
     elif what == "wgrad":
         dy = torch.randn(B, ho, ho, k, device="cuda").bfloat16()
         dw = torch.zeros(k, r, r, c, device="cuda")
-        for mode in (0, 2):      # 0 = per-tap gather kernel, 2 = nine-tap kernel where it applies
-            lib().frhip_set_tn_linear(mode)
+        for mode in (0, 1):      # 0 = per-tap gather kernel, 1 = nine-tap kernel where it applies
+            lib().frhip_set_wgrad_taps9(mode)
             us = timeit(lambda: ops.conv_wgrad(dy, x, dw, r, r, stride, pad, 0))
             line += " wgrad[m%d] %6.1fus %5.0fTF |" % (mode, us, flops / us / 1e6)
-        lib().frhip_set_tn_linear(2)
+        lib().frhip_set_wgrad_taps9(1)
     print(line, flush=True)
