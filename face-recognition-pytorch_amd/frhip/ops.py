@@ -374,9 +374,21 @@ def stem_fwd(x, wp, st):
     return out, arg
 
 
-def stem_bwd(x, wp, dpool, arg, st, gamma, dgamma, dbeta, dw27, scratch=None, part=None):
+def stem_gram(x, dtype):
+    """{G = sum_p col col^T (27 x 27), s = sum_p col} of the stem's im2col columns, from the input batch alone (x rounded to `dtype`
+    as the stem kernels round it): the data-only part of the stem's weight gradient (csrc/stem_algebra.hip)"""
+    b, _, h, w = x.shape
+    part = torch.empty((lib().frhip_stem_gram_blocks(b, h, w), 567), dtype=torch.float32, device=x.device)
+    gram = torch.empty((lib().frhip_stem_gram_floats(),), dtype=torch.float32, device=x.device)
+    check(lib().frhip_stem_gram(_DT[dtype], _p(x), b, h, w, _p(part), _p(gram), _s()), "frhip_stem_gram")
+    return gram
+
+
+def stem_bwd(x, wp, dpool, arg, st, gamma, dgamma, dbeta, dw27, scratch=None, part=None, gram=None, pooled=None):
     """backward of the stem given the gradient of the pooled map: accumulates dgamma, dbeta and dw27 [64, 27] (fp32).
-    part: [rows, 2, 64] partial sums { sum d, sum d * xhat } already reduced elsewhere (skips the recompute reduction pass)"""
+    part: [rows, 2, 64] partial sums { sum d, sum d * xhat } already reduced elsewhere (skips the recompute reduction pass).
+    gram (+ pooled, the forward's output): stem_gram(x) -- the weight gradient then comes from the algebraic form (no conv
+    recompute, no scatter) instead of the recompute kernel"""
     b, _, h, w = x.shape
     dev = x.device
     nb = lib().frhip_stem_blocks(b, h, w)
@@ -391,6 +403,10 @@ def stem_bwd(x, wp, dpool, arg, st, gamma, dgamma, dbeta, dw27, scratch=None, pa
                                       _p(dgamma), _p(dbeta), _p(coef[0]), _p(coef[1]), _p(coef[2]), _s()),
           "frhip_bn_bwd_finalize")
     slabs = torch.empty((nb, 64, 32), dtype=torch.float32, device=dev)
+    if gram is not None and pooled is not None:
+        check(lib().frhip_stem_bwd_wgrad_gram(dt_of(wp), _p(x), _p(wp), _p(dpool), _p(pooled), _p(arg), _p(gram), _p(coef[0]), _p(coef[1]),
+                                              _p(coef[2]), b, h, w, _p(slabs), _p(dw27), _s()), "frhip_stem_bwd_wgrad_gram")
+        return
     check(lib().frhip_stem_bwd_wgrad(dt_of(wp), _p(x), _p(wp), _p(dpool), _p(arg), _p(coef[0]), _p(coef[1]), _p(coef[2]),
                                      _p(st.scale), _p(st.shift), b, h, w, _p(slabs), _p(dw27), _s()), "frhip_stem_bwd_wgrad")
 

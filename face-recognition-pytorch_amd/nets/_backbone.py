@@ -27,6 +27,7 @@ _FUSE_BN1 = int(os.environ.get("FRHIP_FUSE_BN1", "0"))
 # the main stream holds at the hand-over): 27.16 -> 26.9 ms on the ResNet50 step.  One hand-over per block instead of one per
 # weight gradient (fewer barrier packets, but conv2's weight gradient starts a data-gradient later) measured 27.3 -> 27.7: off.
 _WGRAD_EARLY = os.environ.get("FRHIP_WGRAD_EARLY", "1") == "1"
+_STEM_GRAM = os.environ.get("FRHIP_STEM_GRAM", "1") == "1"       # stem weight gradient from the Gram matrix of the input (no conv recompute)
 # ... except for layers of at most this many channels, whose weight gradient is handed over BEHIND the data-gradient that reads the
 # same dy (experiment: on the wide early maps the BatchNorm-backward pass in front of each data-gradient is long and HBM-bound,
 # and a weight gradient that starts with the data-gradient is done before the next such pass begins)
@@ -375,6 +376,19 @@ def stem_forward(net, x, training, sv):
         cur, arg0 = ops.stem_fwd(x, wp0, st0)
         if sv is not None:
             sv.x0, sv.wp0, sv.st0, sv.arg0, sv.col, sv.p0 = x, wp0, st0, arg0, None, cur
+            sv.gram = None
+            if training and _STEM_GRAM:
+                # the data-only part of the stem's weight gradient (csrc/stem_algebra.hip) needs x alone: it runs on the side stream
+                # under the forward pass, and the backward pass then needs no recompute of the 112 x 112 x 64 conv map
+                side = side_stream(x.device) if _OVERLAP_WGRAD else None
+                if side is None:
+                    sv.gram = ops.stem_gram(x, dt)
+                else:
+                    side.wait_stream(torch.cuda.current_stream())
+                    with torch.cuda.stream(side):
+                        sv.gram = ops.stem_gram(x, dt)
+                        sv.gram_done = torch.cuda.Event()
+                        sv.gram_done.record(side)
         return cur
     col = ops.stem_im2col(x, dt, stride)
     h, w = (h - 1) // stride + 1, (w - 1) // stride + 1
@@ -413,8 +427,12 @@ def stem_reduction_operands(net, sv):
 def stem_backward(net, sv, dout, bc, part=None):
     """part: the stem's BN-backward partial sums when the producer of dout already reduced them (stem_reduction_operands)"""
     if sv.col is None:          # recompute-style stem
+        gram = getattr(sv, "gram", None)
+        if gram is not None and getattr(sv, "gram_done", None) is not None:
+            torch.cuda.current_stream().wait_event(sv.gram_done)
+            gram.record_stream(torch.cuda.current_stream())     # allocated on the side stream, read here
         ops.stem_bwd(sv.x0, sv.wp0, dout.contiguous(), sv.arg0, sv.st0, net.bn1.weight.data, bc.G(net.bn1.weight),
-                     bc.G(net.bn1.bias), phys_grad(bc.G(net.conv1.weight)).view(64, 27), part=part)
+                     bc.G(net.bn1.bias), phys_grad(bc.G(net.conv1.weight)).view(64, 27), part=part, gram=gram, pooled=sv.p0)
         return
     da0 = ops.maxpool_bwd(dout, sv.arg0, sv.y0.shape)
     dy0 = ops.bn_backward(da0, sv.y0, sv.st0, net.bn1.weight.data, bc.G(net.bn1.weight), bc.G(net.bn1.bias), relu_mask=True)

@@ -338,6 +338,18 @@ int frhip_stem_bwd_reduce(int dtype, const float* x, const void* wp, const void*
 int frhip_stem_bwd_wgrad(int dtype, const float* x, const void* wp, const void* dpool, const uint8_t* argmax,
                          const float* ca, const float* cb, const float* cc, const float* scale, const float* shift, int b,
                          int h, int w, float* slabs, float* dw, frhip_stream_t stream);
+/* The same weight gradient without recomputing the convolution (csrc/stem_algebra.hip): dy = ca d + cb y + cc and y = W col give
+ * dW = ca D + cb (W G) + cc s with G = sum_p col col^T (27 x 27) and s = sum_p col, functions of the input batch alone, and
+ * D = sum over pooled elements with pooled > 0 of dpool x col[arg-max pixel].  frhip_stem_gram fills gram[frhip_stem_gram_floats()]
+ * = {G, s} from x (partial: scratch of frhip_stem_gram_blocks(b,h,w) x 567 floats); it needs nothing else of the step, so a caller
+ * can run it on a second stream during the forward pass.  frhip_stem_bwd_wgrad_gram then needs dpool, the pooled map the forward
+ * pass returned (ReLU mask: pooled > 0), the arg-max bytes and (ca, cb, cc) of frhip_bn_bwd_finalize; slabs as above. */
+int frhip_stem_gram_floats(void);
+int frhip_stem_gram_blocks(int b, int h, int w);
+int frhip_stem_gram(int dtype, const float* x, int b, int h, int w, float* partial, float* gram, frhip_stream_t stream);
+int frhip_stem_bwd_wgrad_gram(int dtype, const float* x, const void* wp, const void* dpool, const void* pooled,
+                              const uint8_t* argmax, const float* gram, const float* ca, const float* cb, const float* cc,
+                              int b, int h, int w, float* slabs, float* dw, frhip_stream_t stream);
 
 /* ---- per-step operand preparation of ALL conv weights in one launch (the reference casts them implicitly under autocast,
  * nets/resnet.py:23-46 + model/FR_PartialFC.py:166-170).  Per tensor w[k][rs][c] fp32: wc[k][rs][c] (forward operand) and

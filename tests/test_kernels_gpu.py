@@ -434,6 +434,14 @@ def test_recompute_stem_matches_torch(dtype, shape):
     tg = dict(rtol=2e-3, atol=2e-3) if dtype == torch.float32 else dict(rtol=5e-2, atol=5e-2 * max(1.0, g_.grad.abs().max().item()))
     np.testing.assert_allclose(dg.cpu().numpy(), g_.grad.numpy(), **tg)
     np.testing.assert_allclose(db.cpu().numpy(), b_.grad.numpy(), **tg)
+    # the algebraic weight gradient (csrc/stem_algebra.hip: dW = ca D + cb W G + cc s, no conv recompute): same bounds against torch,
+    # and against the recompute kernel above
+    dg3, db3, dw3 = torch.zeros(64, device="cuda"), torch.zeros(64, device="cuda"), torch.zeros((64, 27), device="cuda")
+    ops.stem_bwd(xd, wp, nhwc(dp).to(dtype).cuda(), arg, st, gamma.cuda(), dg3, db3, dw3, gram=ops.stem_gram(xd, dtype), pooled=pooled)
+    np.testing.assert_allclose(dw3.cpu().numpy(), ref_dw.numpy(), **t)
+    np.testing.assert_allclose(dw3.cpu().numpy(), dw.cpu().numpy(), rtol=2e-3 if dtype == torch.float32 else 2e-2,
+                               atol=(2e-4 if dtype == torch.float32 else 2e-2) * max(1.0, ref_dw.abs().max().item()))
+    assert torch.equal(dg3, dg) and torch.equal(db3, db)
     if dtype == torch.bfloat16:
         # bf16 runs the scatter-form backward by default; the gather-form kernels (the fp32 path) must agree with it
         from frhip._abi import lib
