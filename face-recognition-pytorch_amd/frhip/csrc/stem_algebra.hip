@@ -89,15 +89,21 @@ __global__ __launch_bounds__(256) void stem_gram_kernel(const float* __restrict_
         partial[(size_t)blockIdx.x * SG_OUT + o] = red[o] + red[8 * SG_VALS + o] + red[16 * SG_VALS + o] + red[24 * SG_VALS + o];
 }
 
-// gram[0..728] = G[j][j'] (j = (fr * 3 + fs) * 3 + ci, the k order of the packed stem weights), gram[729..755] = s[j]
-__global__ __launch_bounds__(256) void stem_gram_reduce_kernel(const float* __restrict__ partial, int nparts, float* __restrict__ gram) {
-    __shared__ float blk[SG_OUT];
-    for (int o = threadIdx.x; o < SG_OUT; o += 256) {
+// blk[7][81] = sum of the workgroups' partial blocks: one workgroup per role block, three lanes per output
+__global__ __launch_bounds__(256) void stem_gram_fold_kernel(const float* __restrict__ partial, int nparts, float* __restrict__ blk) {
+    __shared__ float red[3][SG_VALS];
+    const int o = threadIdx.x % SG_VALS, part = threadIdx.x / SG_VALS;
+    if (part < 3) {
         float a = 0.f;
-        for (int p = 0; p < nparts; ++p) a += partial[(size_t)p * SG_OUT + o];
-        blk[o] = a;
+        for (int p = part; p < nparts; p += 3) a += partial[(size_t)p * SG_OUT + blockIdx.x * SG_VALS + o];
+        red[part][o] = a;
     }
     __syncthreads();
+    if (threadIdx.x < SG_VALS) blk[blockIdx.x * SG_VALS + o] = red[0][o] + red[1][o] + red[2][o];
+}
+
+// gram[0..728] = G[j][j'] (j = (fr * 3 + fs) * 3 + ci, the k order of the packed stem weights), gram[729..755] = s[j]
+__global__ __launch_bounds__(256) void stem_gram_assemble_kernel(const float* __restrict__ blk, float* __restrict__ gram) {
     for (int o = threadIdx.x; o < 27 * 27 + 27; o += 256) {
         if (o < 729) {
             const int j = o / 27, j2 = o - j * 27;
@@ -131,38 +137,62 @@ __global__ __launch_bounds__(256) void stem_dgather_kernel(const float* __restri
 #pragma unroll
     for (int j = 0; j < 27; ++j) acc[j] = 0.f;
     constexpr int EPV = 16 / (int)sizeof(T), VPR = 64 / EPV;
-    for (int tile = blockIdx.x; tile < B * th * tw; tile += gridDim.x) {
+    constexpr int XN = (3 * DG_X * DG_X + 255) / 256;           // window elements per thread
+    constexpr int VN = DG_P * DG_P * VPR / 256;                 // 16-byte channel groups per thread
+    static_assert(DG_P * DG_P * VPR % 256 == 0, "tile vectors split evenly over the threads");
+    // The next tile's global operands are fetched into registers while this tile is being gathered: with one buffer and the loads
+    // in front of the barrier every tile paid two dependent HBM round trips with nothing else in flight.
+    float xr[XN];
+    Vec16<T> gr[VN], pr[VN];
+    uint64_t ar[VN];
+    bool inr[VN];
+    auto fetch = [&](int tile) {
         const int n = tile / (th * tw), rem = tile - n * th * tw;
         const int ph0 = (rem / tw) * DG_P, pw0 = (rem % tw) * DG_P;
         const float* ximg = x + (size_t)n * 3 * H * W;
-        __syncthreads();
-        for (int idx = threadIdx.x; idx < 3 * DG_X * DG_X; idx += 256) {
+#pragma unroll
+        for (int i = 0; i < XN; ++i) {
+            const int idx = threadIdx.x + i * 256;
             const int cc = idx % DG_X, rest = idx / DG_X, rr = rest % DG_X, ci = rest / DG_X;
             const int h = 2 * ph0 - 2 + rr, w = 2 * pw0 - 2 + cc;
-            const float v = ((unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W) ? ximg[((size_t)ci * H + h) * W + w] : 0.f;
-            xs[idx] = to_f32<T>(from_f32<T>(v));
+            xr[i] = (idx < 3 * DG_X * DG_X && (unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W) ? ximg[((size_t)ci * H + h) * W + w] : 0.f;
         }
-        // the tile's pooled gradients (behind the ReLU mask) and arg-max bytes, 16 bytes of channels per thread
-        for (int idx = threadIdx.x; idx < DG_P * DG_P * VPR; idx += 256) {
+#pragma unroll
+        for (int i = 0; i < VN; ++i) {
+            const int idx = threadIdx.x + i * 256;
             const int cv = idx % VPR, pp = idx / VPR, pl = pp / DG_P, pc = pp - pl * DG_P;
             const int ph = ph0 + pl, pw = pw0 + pc;
-            const bool in = ph < Hp && pw < Wp;
+            inr[i] = ph < Hp && pw < Wp;
             const size_t o = ((((size_t)n * Hp + ph) * Wp + pw) * VPR + cv) * EPV;
-            Vec16<T> g, pv;
-            uint64_t ab = 0;
-            if (in) {
-                g = *reinterpret_cast<const Vec16<T>*>(dpool + o);
-                pv = *reinterpret_cast<const Vec16<T>*>(pooled + o);
-                if constexpr (EPV == 8) ab = *reinterpret_cast<const uint64_t*>(argmax + o);
-                else ab = *reinterpret_cast<const uint32_t*>(argmax + o);
-            }
-#pragma unroll
-            for (int e = 0; e < EPV; ++e) {
-                gs[pp * 64 + cv * EPV + e] = (in && pv.get(e) > 0.f) ? g.get(e) : 0.f;
-                ab8[pp * 64 + cv * EPV + e] = (uint8_t)(ab >> (8 * e));
+            ar[i] = 0;
+            if (inr[i]) {
+                gr[i] = *reinterpret_cast<const Vec16<T>*>(dpool + o);
+                pr[i] = *reinterpret_cast<const Vec16<T>*>(pooled + o);
+                if constexpr (EPV == 8) ar[i] = *reinterpret_cast<const uint64_t*>(argmax + o);
+                else ar[i] = *reinterpret_cast<const uint32_t*>(argmax + o);
             }
         }
+    };
+    const int ntiles = B * th * tw;
+    if ((int)blockIdx.x < ntiles) fetch(blockIdx.x);
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        __syncthreads();                                          // the previous tile's gather is done with xs / gs / ab8
+#pragma unroll
+        for (int i = 0; i < XN; ++i) {
+            const int idx = threadIdx.x + i * 256;
+            if (idx < 3 * DG_X * DG_X) xs[idx] = to_f32<T>(from_f32<T>(xr[i]));
+        }
+#pragma unroll
+        for (int i = 0; i < VN; ++i) {
+            const int idx = threadIdx.x + i * 256;
+            const int cv = idx % VPR, pp = idx / VPR;
+#pragma unroll
+            for (int e = 0; e < EPV; ++e) gs[pp * 64 + cv * EPV + e] = (inr[i] && pr[i].get(e) > 0.f) ? gr[i].get(e) : 0.f;
+            if constexpr (EPV == 8) *reinterpret_cast<uint64_t*>(ab8 + pp * 64 + cv * 8) = ar[i];
+            else *reinterpret_cast<uint32_t*>(ab8 + pp * 64 + cv * 4) = (uint32_t)ar[i];
+        }
         __syncthreads();
+        if (tile + (int)gridDim.x < ntiles) fetch(tile + gridDim.x);
         for (int pp = wave; pp < DG_P * DG_P; pp += 4) {
             const int pl = pp / DG_P, pc = pp - pl * DG_P;
             const float g = gs[pp * 64 + lane];
@@ -192,20 +222,20 @@ __global__ __launch_bounds__(256) void stem_dgather_kernel(const float* __restri
 
 // dw[k][j] += ca[k] * sum_slabs D[k][j] + cb[k] * sum_j' W[k][j'] G[j'][j] + cc[k] * s[j];  one workgroup per channel k
 template <typename T>
-__global__ __launch_bounds__(256) void stem_dw_final_kernel(const float* __restrict__ slabs, int nslabs, const float* __restrict__ gram,
+__global__ __launch_bounds__(1024) void stem_dw_final_kernel(const float* __restrict__ slabs, int nslabs, const float* __restrict__ gram,
                                                             const T* __restrict__ wp, const float* __restrict__ ca,
                                                             const float* __restrict__ cb, const float* __restrict__ cc,
                                                             float* __restrict__ dw) {
-    __shared__ float red[8][32];
+    __shared__ float red[32][32];
     const int k = blockIdx.x, j = threadIdx.x & 31, part = threadIdx.x >> 5;
     float a = 0.f;
-    for (int s = part; s < nslabs; s += 8) a += slabs[(size_t)s * 2048 + k * 32 + j];
+    for (int s = part; s < nslabs; s += 32) a += slabs[(size_t)s * 2048 + k * 32 + j];
     red[part][j] = a;
     __syncthreads();
     if (threadIdx.x < 27) {
         float d = 0.f;
 #pragma unroll
-        for (int p = 0; p < 8; ++p) d += red[p][j];
+        for (int p = 0; p < 32; ++p) d += red[p][j];
         float wg = 0.f;
         for (int j2 = 0; j2 < 27; ++j2) wg = fmaf(to_f32<T>(wp[k * 32 + j2]), gram[j2 * 27 + j], wg);
         dw[k * 27 + j] += ca[k] * d + cb[k] * wg + cc[k] * gram[729 + j];
@@ -228,8 +258,9 @@ static bool sa_ok(int dtype, int b, int h, int w, const char* who) {
 extern "C" int frhip_stem_gram_floats(void) { return 27 * 27 + 27; }
 
 extern "C" int frhip_stem_gram_blocks(int b, int h, int w) {
+    // workgroups of the Gram pass; the scratch it needs is (this + 1) x 567 floats
     const int t = b * ((h + SG_ROWS - 1) / SG_ROWS);
-    return t < 1024 ? t : 1024;
+    return t < 512 ? t : 512;
 }
 
 extern "C" int frhip_stem_gram(int dtype, const float* x, int b, int h, int w, float* partial, float* gram, hipStream_t stream) {
@@ -241,7 +272,9 @@ extern "C" int frhip_stem_gram(int dtype, const float* x, int b, int h, int w, f
     else hipLaunchKernelGGL(stem_gram_kernel<float>, dim3(blocks), dim3(256), lds, stream, x, partial, b, h, w);
     int rc = check_launch("frhip_stem_gram");
     if (rc) return rc;
-    hipLaunchKernelGGL(stem_gram_reduce_kernel, dim3(1), dim3(256), 0, stream, partial, blocks, gram);
+    float* blk = partial + (size_t)blocks * SG_OUT;            // 567 more floats of the caller's scratch
+    hipLaunchKernelGGL(stem_gram_fold_kernel, dim3(7), dim3(256), 0, stream, partial, blocks, blk);
+    hipLaunchKernelGGL(stem_gram_assemble_kernel, dim3(1), dim3(256), 0, stream, blk, gram);
     return check_launch("frhip_stem_gram(reduce)");
 }
 
@@ -259,8 +292,8 @@ extern "C" int frhip_stem_bwd_wgrad_gram(int dtype, const float* x, const void* 
     int rc = check_launch("frhip_stem_bwd_wgrad_gram(gather)");
     if (rc) return rc;
     if (dtype == FRHIP_DT_BF16)
-        hipLaunchKernelGGL(stem_dw_final_kernel<bf16_t>, dim3(64), dim3(256), 0, stream, slabs, blocks, gram, (const bf16_t*)wp, ca, cb, cc, dw);
+        hipLaunchKernelGGL(stem_dw_final_kernel<bf16_t>, dim3(64), dim3(1024), 0, stream, slabs, blocks, gram, (const bf16_t*)wp, ca, cb, cc, dw);
     else
-        hipLaunchKernelGGL(stem_dw_final_kernel<float>, dim3(64), dim3(256), 0, stream, slabs, blocks, gram, (const float*)wp, ca, cb, cc, dw);
+        hipLaunchKernelGGL(stem_dw_final_kernel<float>, dim3(64), dim3(1024), 0, stream, slabs, blocks, gram, (const float*)wp, ca, cb, cc, dw);
     return check_launch("frhip_stem_bwd_wgrad_gram(final)");
 }

@@ -378,7 +378,7 @@ def stem_gram(x, dtype):
     """{G = sum_p col col^T (27 x 27), s = sum_p col} of the stem's im2col columns, from the input batch alone (x rounded to `dtype`
     as the stem kernels round it): the data-only part of the stem's weight gradient (csrc/stem_algebra.hip)"""
     b, _, h, w = x.shape
-    part = torch.empty((lib().frhip_stem_gram_blocks(b, h, w), 567), dtype=torch.float32, device=x.device)
+    part = torch.empty((lib().frhip_stem_gram_blocks(b, h, w) + 1, 567), dtype=torch.float32, device=x.device)
     gram = torch.empty((lib().frhip_stem_gram_floats(),), dtype=torch.float32, device=x.device)
     check(lib().frhip_stem_gram(_DT[dtype], _p(x), b, h, w, _p(part), _p(gram), _s()), "frhip_stem_gram")
     return gram

@@ -341,7 +341,7 @@ int frhip_stem_bwd_wgrad(int dtype, const float* x, const void* wp, const void* 
 /* The same weight gradient without recomputing the convolution (csrc/stem_algebra.hip): dy = ca d + cb y + cc and y = W col give
  * dW = ca D + cb (W G) + cc s with G = sum_p col col^T (27 x 27) and s = sum_p col, functions of the input batch alone, and
  * D = sum over pooled elements with pooled > 0 of dpool x col[arg-max pixel].  frhip_stem_gram fills gram[frhip_stem_gram_floats()]
- * = {G, s} from x (partial: scratch of frhip_stem_gram_blocks(b,h,w) x 567 floats); it needs nothing else of the step, so a caller
+ * = {G, s} from x (partial: scratch of (frhip_stem_gram_blocks(b,h,w) + 1) x 567 floats); it needs nothing else of the step, so a caller
  * can run it on a second stream during the forward pass.  frhip_stem_bwd_wgrad_gram then needs dpool, the pooled map the forward
  * pass returned (ReLU mask: pooled > 0), the arg-max bytes and (ca, cb, cc) of frhip_bn_bwd_finalize; slabs as above. */
 int frhip_stem_gram_floats(void);
