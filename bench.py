@@ -77,13 +77,13 @@ class ConvMeter:
 
         self._fwdx = ops.conv_fwd_bnrelu
 
-        def conv_fwd_bnrelu(x, st, w, stride, pad, want_stats=True):
+        def conv_fwd_bnrelu(x, st, w, stride, pad, want_stats=True, act_out=None):
             if self.collect and x.dtype == torch.bfloat16:
                 n, h, wd, c = x.shape
                 k, r, s, _ = w.shape
                 ho, wo = ops.conv_out_hw(h, wd, r, s, stride, pad)
-                self.calls.append((self._fwdx, (x, st, w, stride, pad, want_stats), 2.0 * n * ho * wo * k * r * s * c))
-            return self._fwdx(x, st, w, stride, pad, want_stats)
+                self.calls.append((self._fwdx, (x, st, w, stride, pad, want_stats, act_out), 2.0 * n * ho * wo * k * r * s * c))
+            return self._fwdx(x, st, w, stride, pad, want_stats, act_out)
 
         ops.conv_fwd, ops.conv_dgrad, ops.conv_fwd_bnrelu = conv_fwd, conv_dgrad, conv_fwd_bnrelu
 
@@ -137,13 +137,13 @@ class ConvMeter:
 
         fwdx = self._fwdx
 
-        def conv_fwd_bnrelu(x, st, w, stride, pad, want_stats=True):
+        def conv_fwd_bnrelu(x, st, w, stride, pad, want_stats=True, act_out=None):
             n, h, wd, c = x.shape
             k, r, s, _ = w.shape
             ho, wo = ops.conv_out_hw(h, wd, r, s, stride, pad)
             a, b = ev(), ev()
             a.record()
-            out = fwdx(x, st, w, stride, pad, want_stats)
+            out = fwdx(x, st, w, stride, pad, want_stats, act_out)
             b.record()
             self.instep.append((a, b, 2.0 * n * ho * wo * k * r * s * c))
             return out

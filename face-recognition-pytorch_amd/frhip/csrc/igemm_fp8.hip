@@ -201,7 +201,7 @@ static int halo8_run(const void* x8, const void* w8, const float* wscale, float 
     HaloGeom g;
     g.H = h; g.W = w; g.C = c; g.M = n * h * w; g.Nout = k; g.Ktot = 9 * c; g.sign = +1;
     g.a_bytes = (uint32_t)ab; g.b_bytes = (uint32_t)bb;
-    g.xf_scale = nullptr; g.xf_shift = nullptr;
+    g.xf_scale = nullptr; g.xf_shift = nullptr; g.xf_out = nullptr;
     g.d_hw = make_fastdiv((uint32_t)(h * w)); g.d_w = make_fastdiv((uint32_t)w);
     const int mtiles = (g.M + Tile::BM - 1) / Tile::BM, ntiles = (k + Tile::BN - 1) / Tile::BN;
     const int lds = Tile::template lds_bytes<bf16_t>();

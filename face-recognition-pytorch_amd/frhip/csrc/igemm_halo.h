@@ -37,6 +37,9 @@ struct HaloGeom {
     // has landed; the activated tensor never exists in HBM (nets/resnet.py:91-93: bn1 -> relu -> conv2)
     const float* xf_scale;
     const float* xf_shift;
+    void* xf_out;           // XF kernels: if not NULL, the activated tensor is ALSO written here (by the workgroups of channel column 0,
+                            // each its own BM rows, straight from the registers that hold the transformed pieces): the backward pass
+                            // wants it (conv2's weight gradient), and this way no separate BatchNorm-apply pass reads y1 to produce it
     FastDiv d_hw, d_w;      // pixel decode of the per-tile prologue without integer division instructions
 };
 
@@ -107,6 +110,7 @@ struct HaloMainloop {
                 float sc[8], sh[8];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) { sc[e] = g.xf_scale[c0 + 8 * lc + e]; sh[e] = g.xf_shift[c0 + 8 * lc + e]; }
+                const bool emit = g.xf_out != nullptr && ntile == 0;
                 for (int piece = wave; piece < npieces; piece += Tile::WAVES) {
                     const int p = p_lo + piece * 8 + sub;
                     if (p >= 0 && p < g.M) {
@@ -115,6 +119,8 @@ struct HaloMainloop {
 #pragma unroll
                         for (int e = 0; e < 8; ++e) { const float o = (float)v[e] * sc[e] + sh[e]; v[e] = (bf16_t)fmaxf(o, 0.f); }
                         *a = v;
+                        if (emit && p >= m0 && p < m0 + BM)          // this tile's own rows (the halo rows belong to the neighbours)
+                            *reinterpret_cast<bf16x8_t*>(reinterpret_cast<bf16_t*>(g.xf_out) + (size_t)p * g.C + c0 + 8 * lc) = v;
                     }
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

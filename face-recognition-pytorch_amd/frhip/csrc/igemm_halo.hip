@@ -158,14 +158,14 @@ bool halo_xf_applicable(int dtype, int h, int w, int c, int k, int r, int s, int
 }
 
 int halo_run(int dtype, const void* a, const void* b, void* out, const void* res, float* stats, const EpiBnRed& br,
-             int n, int h, int w, int c, int k, int sign, hipStream_t stream, const float* xf_scale, const float* xf_shift) {
+             int n, int h, int w, int c, int k, int sign, hipStream_t stream, const float* xf_scale, const float* xf_shift, void* xf_out) {
     const int es = dtype == FRHIP_DT_BF16 ? 2 : 4;
     const long long ab = 1LL * n * h * w * c * es, bb = 1LL * k * 9 * c * es;
     if (ab > 0x7fffffffLL || bb > 0x7fffffffLL) { set_error("igemm_halo: tensor exceeds the 2 GiB buffer window"); return FRHIP_EINVAL; }
     HaloGeom g;
     g.H = h; g.W = w; g.C = c; g.M = n * h * w; g.Nout = k; g.Ktot = 9 * c; g.sign = sign;
     g.a_bytes = (uint32_t)ab; g.b_bytes = (uint32_t)bb;
-    g.xf_scale = xf_scale; g.xf_shift = xf_shift;
+    g.xf_scale = xf_scale; g.xf_shift = xf_shift; g.xf_out = xf_out;
     g.d_hw = make_fastdiv((uint32_t)(h * w)); g.d_w = make_fastdiv((uint32_t)w);
     const int cfg = halo_config(dtype, c, k);
     if (xf_scale) {

@@ -11,7 +11,7 @@ int halo_stat_rows(int dtype, int m, int w, int c, int k, int sign);
 bool halo_xf_applicable(int dtype, int h, int w, int c, int k, int r, int s, int stride, int pad);
 int halo_run(int dtype, const void* a, const void* b, void* out, const void* res, float* stats, const EpiBnRed& br,
              int n, int h, int w, int c, int k, int sign, hipStream_t stream, const float* xf_scale = nullptr,
-             const float* xf_shift = nullptr);
+             const float* xf_shift = nullptr, void* xf_out = nullptr);
 
 enum { EPI_STORE = 0, EPI_ATOMIC = 1, EPI_SLAB = 2 };    // SLAB: K split y stores its fp32 partial tile to slab y of `out`
 
@@ -202,14 +202,15 @@ extern "C" int frhip_conv_bnrelu_fusable(int dtype, int h, int wd, int c, int k,
 }
 
 extern "C" int frhip_conv_fwd_bnrelu(int dtype, const void* x, const float* in_scale, const float* in_shift, const void* w, void* y,
-                                     float* stats_partial, int n, int h, int wd, int c, int k, int r, int s, int stride, int pad,
-                                     hipStream_t stream) {
-    // y = conv(relu(x * in_scale[c] + in_shift[c]), w): BatchNorm-apply + ReLU of the operand inside the kernel (bn1 -> relu -> conv2)
+                                     float* stats_partial, void* act_out, int n, int h, int wd, int c, int k, int r, int s, int stride,
+                                     int pad, hipStream_t stream) {
+    // y = conv(relu(x * in_scale[c] + in_shift[c]), w): BatchNorm-apply + ReLU of the operand inside the kernel (bn1 -> relu -> conv2);
+    // act_out (optional, shaped like x): the activated tensor, written on the way for the backward pass
     if (!in_scale || !in_shift || !halo_xf_applicable(dtype, h, wd, c, k, r, s, stride, pad)) {
         set_error("frhip_conv_fwd_bnrelu: not fusable for this shape (ask frhip_conv_bnrelu_fusable first)");
         return FRHIP_EINVAL;
     }
-    return halo_run(dtype, x, w, y, nullptr, stats_partial, NO_BNRED, n, h, wd, c, k, +1, stream, in_scale, in_shift);
+    return halo_run(dtype, x, w, y, nullptr, stats_partial, NO_BNRED, n, h, wd, c, k, +1, stream, in_scale, in_shift, act_out);
 }
 
 static int dgrad_run(int dtype, const void* dy, const void* wt, void* dx, const void* residual, float* stats,

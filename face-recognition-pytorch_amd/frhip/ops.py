@@ -101,8 +101,9 @@ def conv_bnrelu_fusable(x, w, stride, pad):
     return hit
 
 
-def conv_fwd_bnrelu(x, st, w, stride, pad, want_stats=True):
-    """y = conv(relu(x * st.scale + st.shift), w) without materialising the activated tensor (x = the BatchNorm's input)"""
+def conv_fwd_bnrelu(x, st, w, stride, pad, want_stats=True, act_out=None):
+    """y = conv(relu(x * st.scale + st.shift), w) without a separate BatchNorm-apply pass (x = the BatchNorm's input); act_out (like
+    x, optional) receives the activated tensor on the way"""
     n, h, wd, c = x.shape
     k, r, s, c2 = w.shape
     assert c == c2 and x.dtype == w.dtype
@@ -112,8 +113,8 @@ def conv_fwd_bnrelu(x, st, w, stride, pad, want_stats=True):
     if want_stats:
         rows = lib().frhip_conv_stat_rows(dt_of(x), n * ho * wo, k, h, wd, c, r, s, stride, pad)
         part = torch.empty((rows, 2, k), dtype=torch.float32, device=x.device)
-    check(lib().frhip_conv_fwd_bnrelu(dt_of(x), _p(x), _p(st.scale), _p(st.shift), _p(w), _p(y), _p(part), n, h, wd, c, k, r, s,
-                                      stride, pad, _s()), "frhip_conv_fwd_bnrelu")
+    check(lib().frhip_conv_fwd_bnrelu(dt_of(x), _p(x), _p(st.scale), _p(st.shift), _p(w), _p(y), _p(part), _p(act_out), n, h, wd, c, k,
+                                      r, s, stride, pad, _s()), "frhip_conv_fwd_bnrelu")
     return y, part
 
 

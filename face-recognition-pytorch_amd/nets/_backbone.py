@@ -504,6 +504,11 @@ def basic_block_forward(blk, xin, dt, training, save, wprep=None, q8=None):
     if f1:
         a1, a18 = ops.bn_apply_q8(y1, st1, relu=True)
         y2, p2 = ops.conv_fwd_fp8(a18, *q8.packs[blk.conv2], blk.stride, 1, want_stats=training)
+    elif _FUSE_BN1 == 3 and ops.conv_bnrelu_fusable(y1, w2, blk.stride, 1):
+        # conv2 forms a1 = relu(bn1(y1)) in LDS from y1 and writes it out on the way (the backward pass reads it): no BatchNorm-apply
+        # launch, no second read of y1, the backward pass unchanged
+        a1 = torch.empty_like(y1) if save else None
+        y2, p2 = ops.conv_fwd_bnrelu(y1, st1, w2, blk.stride, 1, want_stats=training, act_out=a1)
     elif _FUSE_BN1 and ops.conv_bnrelu_fusable(y1, w2, blk.stride, 1):
         # a1 = relu(bn1(y1)) is never written: conv2 (and, in the backward pass, its weight gradient) form it in LDS from y1
         a1 = None

@@ -214,9 +214,12 @@ int frhip_head_bwd_dt(int dtype, const void* ehat, const void* what, const int* 
  * INPUT x and form relu(x * in_scale[c] + in_shift[c]) in LDS.  bf16, 3x3 / stride 1 / pad 1; *_fusable() tells whether a
  * shape is served (otherwise use frhip_bn_apply + the plain entry points).  Results are bit-identical to the unfused pair. ---- */
 int frhip_conv_bnrelu_fusable(int dtype, int h, int wd, int c, int k, int r, int s, int stride, int pad);
+/* act_out (may be NULL): [n,h,wd,c] like x -- the activated tensor relu(x * in_scale + in_shift) is written there on the way (each
+ * row once, by the workgroups of output-channel column 0) for a backward pass that wants it: the forward pass then has neither
+ * the BatchNorm-apply launch nor its re-read of x, and the backward pass is the unfused one */
 int frhip_conv_fwd_bnrelu(int dtype, const void* x, const float* in_scale, const float* in_shift, const void* w, void* y,
-                          float* stats_partial, int n, int h, int wd, int c, int k, int r, int s, int stride, int pad,
-                          frhip_stream_t stream);
+                          float* stats_partial, void* act_out, int n, int h, int wd, int c, int k, int r, int s, int stride,
+                          int pad, frhip_stream_t stream);
 int frhip_conv_wgrad_bnrelu_fusable(int dtype, int n, int h, int w, int c, int k, int r, int s, int stride, int pad);
 int frhip_conv_wgrad_bnrelu(int dtype, const void* dy, const void* x, const float* in_scale, const float* in_shift,
                             float* dw, int n, int h, int w, int c, int k, int r, int s, int stride, int pad, int splits,

@@ -497,6 +497,11 @@ def test_conv_with_folded_bn_relu_is_bit_identical_to_the_separate_pass(shape):
     y_fus, p_fus = ops.conv_fwd_bnrelu(y1, st, wt, 1, 1, want_stats=True)
     assert torch.equal(y_fus, y_ref)
     assert p_fus.shape == p_ref.shape and torch.equal(p_fus, p_ref)
+    # ... and with the activated tensor written out on the way (what the forward pass of a training step uses): every row exactly
+    # once (poisoned buffer), the same bits as the separate pass, the convolution's results unchanged
+    a1_out = torch.full_like(y1, float("nan"))
+    y_fo, p_fo = ops.conv_fwd_bnrelu(y1, st, wt, 1, 1, want_stats=True, act_out=a1_out)
+    assert torch.equal(a1_out, a1) and torch.equal(y_fo, y_ref) and torch.equal(p_fo, p_ref)
     dw_ref = torch.zeros((k, 3, 3, c), device="cuda")
     dw_fus = torch.zeros((k, 3, 3, c), device="cuda")
     ops.conv_wgrad(dy, a1, dw_ref, 3, 3, 1, 1)
