@@ -26,11 +26,14 @@ template <typename T> struct EW {
 // Column statistics of a [rows][C] tensor: partial[blk][0][c] = sum x, partial[blk][1][c] = sum x^2.
 // Optional second operand turns it into the BN-backward reduction:
 //   d_eff = dout * (relu ? (y*scale+shift > 0) : 1);  partial = { sum d_eff, sum d_eff * (y-mean)*invstd }.
-template <typename T, bool BWD>
+// RS: every group of `rows_per` consecutive rows (a sample) carries a factor rowscale[group] on the gradient (stochastic depth: the
+// branch was scaled by it in the forward pass, nets/AlterNet_SwinV2_FAN.py DropPath) -- d = dout * rowscale[r / rows_per].
+template <typename T, bool BWD, bool RS = false>
 __global__ __launch_bounds__(EW_THREADS) void colreduce_kernel(const T* __restrict__ x, const T* __restrict__ y,
                                                                const float* __restrict__ mean, const float* __restrict__ invstd,
                                                                const float* __restrict__ mscale, const float* __restrict__ mshift,
-                                                               float* __restrict__ partial, int rows, int C) {
+                                                               float* __restrict__ partial, int rows, int C,
+                                                               const float* __restrict__ rowscale = nullptr, int rows_per = 1) {
     constexpr int EPV = EW<T>::EPV;
     const int vpr = C / EPV;                     // vectors per row (<= 256, divides 256)
     const int cg = threadIdx.x % vpr, rl = threadIdx.x / vpr, rlanes = EW_THREADS / vpr;
@@ -48,10 +51,12 @@ __global__ __launch_bounds__(EW_THREADS) void colreduce_kernel(const T* __restri
         const Vec16<T> a = *reinterpret_cast<const Vec16<T>*>(x + idx);
         if (BWD) {
             const Vec16<T> b = *reinterpret_cast<const Vec16<T>*>(y + idx);
+            float ks = 1.f;
+            if constexpr (RS) ks = rowscale[r / rows_per];
 #pragma unroll
             for (int e = 0; e < EPV; ++e) {
                 const float yy = b.get(e);
-                const float d = (yy * ms[e] + mb[e] > 0.f) ? a.get(e) : 0.f;
+                const float d = (yy * ms[e] + mb[e] > 0.f) ? a.get(e) * ks : 0.f;
                 s1[e] += d; s2[e] += d * (yy - mu[e]) * is[e];
             }
         } else {
@@ -186,11 +191,12 @@ static size_t EW_NT_BYTES = (size_t)(getenv("FRHIP_EW_NT_MB") ? atoi(getenv("FRH
 // tensor the convolution has just written: 26.34 vs 26.40 ms over four same-box A/B rounds, 26.67 vs 26.73 over two more.)
 static int g_ew_nt = getenv("FRHIP_EW_NT") ? atoi(getenv("FRHIP_EW_NT")) : 1;
 
-template <typename T, bool NTL, bool NTS>
+template <typename T, bool NTL, bool NTS, bool RS = false>
 __global__ __launch_bounds__(EW_THREADS) void bn_apply_kernel(const T* __restrict__ y, const float* __restrict__ scale,
                                                               const float* __restrict__ shift, const T* __restrict__ res,
                                                               const float* __restrict__ rscale, const float* __restrict__ rshift,
-                                                              int relu, T* __restrict__ out, int rows, int C) {
+                                                              int relu, T* __restrict__ out, int rows, int C,
+                                                              const float* __restrict__ rowscale = nullptr, int rows_per = 1) {
     constexpr int EPV = EW<T>::EPV;
     const int vpr = C / EPV;
     const int cg = threadIdx.x % vpr, rl = threadIdx.x / vpr, rlanes = EW_THREADS / vpr;
@@ -204,7 +210,16 @@ __global__ __launch_bounds__(EW_THREADS) void bn_apply_kernel(const T* __restric
     for (int r = blockIdx.x * rlanes + rl; r < rows; r += gridDim.x * rlanes) {
         const size_t idx = (size_t)r * C + cg * EPV;
         Vec16<T> a = ew_load<T, NTL>(y + idx);
-        if (res) {
+        if constexpr (RS) {           // out = res + rowscale[sample] * (y * scale + shift): the normalised branch under stochastic depth
+            const float ks = rowscale[r / rows_per];
+            Vec16<T> rv;
+            if (res) rv = ew_load<T, NTL>(res + idx);
+#pragma unroll
+            for (int e = 0; e < EPV; ++e) {
+                float o = (a.get(e) * sc[e] + sh[e]) * ks + (res ? rv.get(e) * rs[e] + rb[e] : 0.f);
+                a.set(e, relu ? fmaxf(o, 0.f) : o);
+            }
+        } else if (res) {
             const Vec16<T> rv = ew_load<T, NTL>(res + idx);
 #pragma unroll
             for (int e = 0; e < EPV; ++e) {
@@ -223,12 +238,13 @@ __global__ __launch_bounds__(EW_THREADS) void bn_apply_kernel(const T* __restric
 }
 
 // dy = ca * d_eff + cb * y + cc,  d_eff = dout * mask
-template <typename T, bool NTL, bool NTS>
+template <typename T, bool NTL, bool NTS, bool RS = false>
 __global__ __launch_bounds__(EW_THREADS) void bn_bwd_apply_kernel(const T* __restrict__ dout, const T* __restrict__ y,
                                                                   const float* __restrict__ ca, const float* __restrict__ cb,
                                                                   const float* __restrict__ cc, const float* __restrict__ mscale,
                                                                   const float* __restrict__ mshift, T* __restrict__ dy,
-                                                                  int rows, int C) {
+                                                                  int rows, int C, const float* __restrict__ rowscale = nullptr,
+                                                                  int rows_per = 1) {
     constexpr int EPV = EW<T>::EPV;
     const int vpr = C / EPV;
     const int cg = threadIdx.x % vpr, rl = threadIdx.x / vpr, rlanes = EW_THREADS / vpr;
@@ -243,10 +259,12 @@ __global__ __launch_bounds__(EW_THREADS) void bn_bwd_apply_kernel(const T* __res
         const size_t idx = (size_t)r * C + cg * EPV;
         const Vec16<T> d = ew_load<T, NTL>(dout + idx);
         Vec16<T> b = ew_load<T, NTL>(y + idx);
+        float ks = 1.f;
+        if constexpr (RS) ks = rowscale[r / rows_per];
 #pragma unroll
         for (int e = 0; e < EPV; ++e) {
             const float yy = b.get(e);
-            const float de = (yy * ms[e] + mb[e] > 0.f) ? d.get(e) : 0.f;
+            const float de = (yy * ms[e] + mb[e] > 0.f) ? d.get(e) * ks : 0.f;
             b.set(e, a_[e] * de + b_[e] * yy + c_[e]);
         }
         ew_store<T, NTS>(dy + idx, b);
@@ -400,6 +418,50 @@ extern "C" int frhip_bn_bwd_finalize(const float* partial, int nparts, float* sc
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((c + 63) / 64), dim3(fin_threads(nparts)), 0, stream, p, nparts, c, count, gamma,
                        mean, invstd, dgamma, dbeta, ca, cb, cc);
     return check_launch("frhip_bn_bwd_finalize");
+}
+
+// Stochastic-depth variants (nets/AlterNet_SwinV2_FAN.py: x + drop_path(norm(branch))): rowscale[g] multiplies the normalised branch
+// (forward) / the incoming gradient (backward) of the rows_per consecutive rows of sample g.  Plain-load instantiations only.
+extern "C" int frhip_bn_apply_rs(int dtype, const void* y, const float* scale, const float* shift, const void* res,
+                                 const float* rowscale, int rows_per, void* out, int rows, int c, hipStream_t stream) {
+    if (!shape_ok(dtype, c, "frhip_bn_apply_rs")) return FRHIP_EINVAL;
+    if (!rowscale || rows_per <= 0) { set_error("frhip_bn_apply_rs: rowscale and rows_per are required"); return FRHIP_EINVAL; }
+    const int blocks = ew_row_blocks(rows, c, dtype);
+    if (dtype == FRHIP_DT_BF16)
+        hipLaunchKernelGGL((bn_apply_kernel<bf16_t, false, false, true>), dim3(blocks), dim3(EW_THREADS), 0, stream, (const bf16_t*)y, scale,
+                           shift, (const bf16_t*)res, nullptr, nullptr, 0, (bf16_t*)out, rows, c, rowscale, rows_per);
+    else
+        hipLaunchKernelGGL((bn_apply_kernel<float, false, false, true>), dim3(blocks), dim3(EW_THREADS), 0, stream, (const float*)y, scale,
+                           shift, (const float*)res, nullptr, nullptr, 0, (float*)out, rows, c, rowscale, rows_per);
+    return check_launch("frhip_bn_apply_rs");
+}
+
+extern "C" int frhip_bn_bwd_reduce_rs(int dtype, const void* dout, const void* y, const float* mean, const float* invstd,
+                                      const float* rowscale, int rows_per, int rows, int c, float* partial, hipStream_t stream) {
+    if (!shape_ok(dtype, c, "frhip_bn_bwd_reduce_rs")) return FRHIP_EINVAL;
+    if (!rowscale || rows_per <= 0) { set_error("frhip_bn_bwd_reduce_rs: rowscale and rows_per are required"); return FRHIP_EINVAL; }
+    const int blocks = frhip_colreduce_blocks(rows, c, dtype);
+    if (dtype == FRHIP_DT_BF16)
+        hipLaunchKernelGGL((colreduce_kernel<bf16_t, true, true>), dim3(blocks), dim3(EW_THREADS), 0, stream, (const bf16_t*)dout,
+                           (const bf16_t*)y, mean, invstd, nullptr, nullptr, partial, rows, c, rowscale, rows_per);
+    else
+        hipLaunchKernelGGL((colreduce_kernel<float, true, true>), dim3(blocks), dim3(EW_THREADS), 0, stream, (const float*)dout,
+                           (const float*)y, mean, invstd, nullptr, nullptr, partial, rows, c, rowscale, rows_per);
+    return check_launch("frhip_bn_bwd_reduce_rs");
+}
+
+extern "C" int frhip_bn_bwd_apply_rs(int dtype, const void* dout, const void* y, const float* ca, const float* cb, const float* cc,
+                                     const float* rowscale, int rows_per, void* dy, int rows, int c, hipStream_t stream) {
+    if (!shape_ok(dtype, c, "frhip_bn_bwd_apply_rs")) return FRHIP_EINVAL;
+    if (!rowscale || rows_per <= 0) { set_error("frhip_bn_bwd_apply_rs: rowscale and rows_per are required"); return FRHIP_EINVAL; }
+    const int blocks = ew_row_blocks(rows, c, dtype);
+    if (dtype == FRHIP_DT_BF16)
+        hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_t, false, false, true>), dim3(blocks), dim3(EW_THREADS), 0, stream, (const bf16_t*)dout,
+                           (const bf16_t*)y, ca, cb, cc, nullptr, nullptr, (bf16_t*)dy, rows, c, rowscale, rows_per);
+    else
+        hipLaunchKernelGGL((bn_bwd_apply_kernel<float, false, false, true>), dim3(blocks), dim3(EW_THREADS), 0, stream, (const float*)dout,
+                           (const float*)y, ca, cb, cc, nullptr, nullptr, (float*)dy, rows, c, rowscale, rows_per);
+    return check_launch("frhip_bn_bwd_apply_rs");
 }
 
 extern "C" int frhip_bn_apply(int dtype, const void* y, const float* scale, const float* shift, const void* res,

@@ -266,10 +266,16 @@ def bn_eval_affine(gamma, beta, running_mean, running_var, eps=1e-5):
     return st
 
 
-def bn_apply(y, st, relu=False, res=None, res_st=None, out=None):
+def bn_apply(y, st, relu=False, res=None, res_st=None, out=None, rowscale=None, rows_per=0):
+    """rowscale [groups] fp32 + rows_per: out = res + rowscale[row // rows_per] * (y * scale + shift) (stochastic depth)"""
     c = y.shape[-1]
     rows = y.numel() // c
     out = torch.empty_like(y) if out is None else out
+    if rowscale is not None:
+        assert not relu and res_st is None and rowscale.dtype == torch.float32 and rows == rowscale.numel() * rows_per
+        check(lib().frhip_bn_apply_rs(dt_of(y), _p(y), _p(st.scale), _p(st.shift), _p(res), _p(rowscale), rows_per, _p(out), rows, c,
+                                      _s()), "frhip_bn_apply_rs")
+        return out
     check(lib().frhip_bn_apply(dt_of(y), _p(y), _p(st.scale), _p(st.shift), _p(res),
                                _p(res_st.scale) if res_st is not None else None,
                                _p(res_st.shift) if res_st is not None else None,
@@ -277,12 +283,29 @@ def bn_apply(y, st, relu=False, res=None, res_st=None, out=None):
     return out
 
 
-def bn_backward(dout, y, st, gamma, dgamma, dbeta, relu_mask=False, out=None, scratch=None, part=None):
+def bn_backward(dout, y, st, gamma, dgamma, dbeta, relu_mask=False, out=None, scratch=None, part=None, rowscale=None, rows_per=0):
     """dy of BN (optionally through the ReLU that follows it); accumulates dgamma/dbeta (fp32, caller-zeroed).
-    part: BN-backward partial sums already produced by conv_dgrad(bnred=...) for this (dout, y) pair."""
+    part: BN-backward partial sums already produced by conv_dgrad(bnred=...) for this (dout, y) pair.
+    rowscale / rows_per: the BatchNorm's output was scaled per sample in the forward pass (bn_apply(rowscale=...)): dout is scaled
+    likewise inside the reduction and the apply pass"""
     c = y.shape[-1]
     rows = y.numel() // c
     dev = y.device
+    if rowscale is not None:
+        assert not relu_mask and part is None and rowscale.dtype == torch.float32 and rows == rowscale.numel() * rows_per
+        nb = _colreduce_blocks(rows, c, dt_of(y))
+        part = torch.empty((nb, 2, c), dtype=torch.float32, device=dev)
+        check(lib().frhip_bn_bwd_reduce_rs(dt_of(y), _p(dout), _p(y), _p(st.mean), _p(st.invstd), _p(rowscale), rows_per, rows, c,
+                                           _p(part), _s()), "frhip_bn_bwd_reduce_rs")
+        coef = torch.empty((3, c), dtype=torch.float32, device=dev)
+        if scratch is None:
+            scratch = torch.empty((64 * 2 * c,), dtype=torch.float32, device=dev)
+        check(lib().frhip_bn_bwd_finalize(_p(part), nb, _p(scratch), c, float(rows), _p(gamma), _p(st.mean), _p(st.invstd),
+                                          _p(dgamma), _p(dbeta), _p(coef[0]), _p(coef[1]), _p(coef[2]), _s()), "frhip_bn_bwd_finalize")
+        dy = torch.empty_like(y) if out is None else out
+        check(lib().frhip_bn_bwd_apply_rs(dt_of(y), _p(dout), _p(y), _p(coef[0]), _p(coef[1]), _p(coef[2]), _p(rowscale), rows_per,
+                                          _p(dy), rows, c, _s()), "frhip_bn_bwd_apply_rs")
+        return dy
     ms = _p(st.scale) if relu_mask else None
     mb = _p(st.shift) if relu_mask else None
     if part is None:

@@ -82,14 +82,14 @@ class SwinTransformerBlock(nn.Module):
         self.norm2 = _BN(dim)
 
 
-def attn_block_forward(blk, x, dt, training, save, wprep=None, q8=None):
+def attn_block_forward(blk, x, dt, training, save, wprep=None, q8=None, keep=None):
     b, h, w, c = x.shape
     m = b * h * w
     at = blk.attn
     x2 = x.view(m, c)
     fp8 = q8 is not None and dt == torch.bfloat16 and Fp8Ctx.eligible(c)        # qkv / proj with both operands in fp8
     wqkv, wqkv_t = _S._lin_operands(at.qkv, dt, wprep)
-    qb = torch.cat([at.q_bias.data, torch.zeros_like(at.v_bias.data), at.v_bias.data])
+    qb = _S.qkv_bias(at)
     if fp8:
         qkv, _ = ops.linear_fwd_fp8(q8.take(x).view(m, c), *q8.packs[at.qkv], bias=qb)
     else:
@@ -102,13 +102,15 @@ def attn_block_forward(blk, x, dt, training, save, wprep=None, q8=None):
     else:
         po, _, part2 = ops.linear_fwd(ao, wproj, at.proj.bias.data, want_stats=training)   # + norm2's batch statistics
     st2 = bn_forward_state(blk.norm2, part2, m, training)
-    keep = None
+    if not (training and blk.drop_path_rate > 0):
+        keep = None
     if training and blk.drop_path_rate > 0:
-        # stochastic depth: one Bernoulli(keep) per sample scales the whole normalised branch (timm DropPath)
-        kp = 1.0 - blk.drop_path_rate
-        keep = (torch.rand(b, device=x.device) < kp).to(x.dtype) / kp
-        branch = ops.bn_apply(po, st2).view(b, h * w * c) * keep[:, None]
-        out = (x.view(b, -1) + branch).view(b, h, w, c)
+        # stochastic depth: one Bernoulli(keep) per sample scales the whole normalised branch (timm DropPath); the factor rides in the
+        # BatchNorm-apply pass (frhip_bn_apply_rs) instead of separate multiply and add passes over the tensor
+        if keep is None:
+            kp = 1.0 - blk.drop_path_rate
+            keep = (torch.rand(b, device=x.device) < kp).float() / kp
+        out = ops.bn_apply(po, st2, res=x2, rowscale=keep, rows_per=h * w).view(b, h, w, c)
     elif fp8:
         out, out8 = ops.bn_apply_q8(po, st2, res=x2)
         out = out.view(b, h, w, c)
@@ -130,8 +132,8 @@ def attn_block_backward(blk, s, dout, dt, bc):
     m = b * h * w
     at = blk.attn
     d2 = dout.reshape(m, c)
-    dbranch = d2 if s.keep is None else (d2.view(b, -1) * s.keep[:, None]).view(m, c).contiguous()
-    dpo = ops.bn_backward(dbranch, s.po, s.st2, blk.norm2.weight.data, G(blk.norm2.weight), G(blk.norm2.bias))
+    dpo = ops.bn_backward(d2, s.po, s.st2, blk.norm2.weight.data, G(blk.norm2.weight), G(blk.norm2.bias),
+                          rowscale=s.keep, rows_per=h * w)
     # proj.bias only shifts the input of a training-mode BatchNorm: analytically zero gradient (nets/SwinV2.py), left at zero
     bc.on_side(lambda: ops.gemm_tn(dpo, s.ao, G(at.proj.weight)), dpo, s.ao)
     dao = ops.gemm_nt(dpo, _S._transposed(s.wproj, s.wproj_t))
@@ -219,11 +221,21 @@ class AlterNet(nn.Module):
             lin = [l for b in layers if not isinstance(b, BasicBlock) for l in (b.attn.qkv, b.attn.proj)]
             q8 = Fp8Ctx([(c, c.physical()) for c in convs if Fp8Ctx.eligible(c.cin)] +
                         [(l, l.weight.data) for l in lin if Fp8Ctx.eligible(l.weight.shape[1])])
+        # stochastic-depth draws of every attention block in one go (four launches per step instead of four per block)
+        keeps, ki = None, 0
+        if training:
+            rates = [m.drop_path_rate for m in layers if not isinstance(m, BasicBlock)]
+            if any(r > 0 for r in rates):
+                kp = getattr(self, "_keep_prob", None)
+                if kp is None or kp.device != cur.device or kp.shape[0] != len(rates):
+                    kp = self._keep_prob = (1.0 - torch.tensor(rates, dtype=torch.float32).view(-1, 1)).to(cur.device)
+                keeps = (torch.rand((len(rates), cur.shape[0]), device=cur.device) < kp).float() / kp
         for mod in layers:
             if isinstance(mod, BasicBlock):
                 cur, s = basic_block_forward(mod, cur, dt, training, save, wprep, q8)
             else:
-                cur, s = attn_block_forward(mod, cur, dt, training, save, lprep, q8)
+                cur, s = attn_block_forward(mod, cur, dt, training, save, lprep, q8, keep=keeps[ki] if keeps is not None else None)
+                ki += 1
             saved.append(s)
         if cur.shape[1] != 6 or cur.shape[2] != 6:
             raise NotImplementedError("AdaptiveAvgPool2d((6,6)) is the identity only for 192x192 inputs")

@@ -246,13 +246,29 @@ def position_bias_backward(blk, s, bc):
         bc.before_join.append(lambda: batch.flush_backward(bc))
 
 
+def qkv_bias(at):
+    """[q_bias, 0, v_bias] (reference nets/SwinV2.py:141-143 concatenates it in every forward) without a launch: q_bias and v_bias are
+    kept as views of ONE 3C buffer whose middle third stays zero, so whatever updates the parameters in place (optimizer,
+    load_state_dict, broadcast) updates the buffer.  Re-established when something replaced the parameters' storage (.cuda(), .to())."""
+    c = at.q_bias.numel()
+    qb = getattr(at, "_qkv_bias_buf", None)
+    if (qb is None or qb.device != at.q_bias.device or qb.dtype != at.q_bias.dtype or at.q_bias.data_ptr() != qb.data_ptr()
+            or at.v_bias.data_ptr() != qb.data_ptr() + 2 * c * qb.element_size()):
+        qb = torch.zeros(3 * c, dtype=at.q_bias.dtype, device=at.q_bias.device)
+        qb[:c].copy_(at.q_bias.data)
+        qb[2 * c:].copy_(at.v_bias.data)
+        at.q_bias.data, at.v_bias.data = qb[:c], qb[2 * c:]
+        at._qkv_bias_buf = qb
+    return qb
+
+
 def swin_block_forward(blk, x, dt, training, save, wprep=None):
     b, h, w, c = x.shape
     m = b * h * w
     at = blk.attn
     x2 = x.view(m, c)
     wqkv, wqkv_t = _lin_operands(at.qkv, dt, wprep)
-    qb = torch.cat([at.q_bias.data, torch.zeros_like(at.v_bias.data), at.v_bias.data])
+    qb = qkv_bias(at)
     qkv, _, _ = ops.linear_fwd(x2, wqkv, qb)                                  # bias add in the GEMM epilogue
     cpb_batch, _, bias, scale, dbias_buf, dscale_buf = position_bias(blk)
     ao = ops.winattn_fwd(qkv, bias, scale, b, h, w, at.num_heads)

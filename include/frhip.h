@@ -151,6 +151,16 @@ int frhip_bn_bwd_finalize(const float* partial, int nparts, float* scratch, int 
 int frhip_bn_bwd_apply(int dtype, const void* dout, const void* y, const float* ca, const float* cb,
                        const float* cc, const float* mask_scale, const float* mask_shift, void* dy,
                        int rows, int c, frhip_stream_t stream);
+/* stochastic depth around a normalised branch (timm DropPath as used by nets/AlterNet_SwinV2_FAN.py:407-450: x + drop_path(norm(f(x)))):
+ * rowscale[g] (0 or 1/keep, fp32) multiplies the rows_per consecutive rows of sample g -- out = res + rowscale * (y*scale+shift) in the
+ * forward pass, d = dout * rowscale in the BatchNorm-backward reduction and apply.  One pass each instead of separate full-tensor
+ * multiply / add launches. */
+int frhip_bn_apply_rs(int dtype, const void* y, const float* scale, const float* shift, const void* res, const float* rowscale,
+                      int rows_per, void* out, int rows, int c, frhip_stream_t stream);
+int frhip_bn_bwd_reduce_rs(int dtype, const void* dout, const void* y, const float* mean, const float* invstd, const float* rowscale,
+                           int rows_per, int rows, int c, float* partial, frhip_stream_t stream);
+int frhip_bn_bwd_apply_rs(int dtype, const void* dout, const void* y, const float* ca, const float* cb, const float* cc,
+                          const float* rowscale, int rows_per, void* dy, int rows, int c, frhip_stream_t stream);
 /* out_accum[c] += sum over partial rows of partial[p][which][c]  (fc bias gradient = column sum) */
 int frhip_sum_partials(const float* partial, int nparts, int c, int which, float* out_accum, frhip_stream_t stream);
 int frhip_add_bias(float* x, const float* bias, int rows, int c, frhip_stream_t stream);

@@ -511,3 +511,30 @@ def test_conv_with_folded_bn_relu_is_bit_identical_to_the_separate_pass(shape):
     a_ref = torch.relu(y1.float().cpu() * st.scale.cpu() + st.shift.cpu()).bfloat16().float()
     ref = torch.nn.functional.conv2d(a_ref.permute(0, 3, 1, 2), wt.float().cpu().permute(0, 3, 1, 2), None, 1, 1).permute(0, 2, 3, 1)
     assert float((y_fus.float().cpu() - ref).abs().max()) <= 2e-2 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_batchnorm_passes_with_a_per_sample_scale(dtype):
+    """stochastic depth around a normalised branch (nets/AlterNet_SwinV2_FAN.py: x + drop_path(norm(f(x)))): the per-sample factor inside
+    the BatchNorm-apply / backward-reduce / backward-apply passes (frhip_bn_*_rs) against separate full-tensor multiplies"""
+    ops = _ops()
+    b, hw, c = 6, 35, 128
+    rows = b * hw
+    y = q(rnd(60, (rows, c)), dtype).to(dtype).cuda()
+    res = q(rnd(61, (rows, c)), dtype).to(dtype).cuda()
+    dout = q(rnd(62, (rows, c)), dtype).to(dtype).cuda()
+    gamma, beta = (1 + 0.1 * rnd(63, (c,))).cuda(), (0.1 * rnd(64, (c,))).cuda()
+    keep = torch.tensor([1.25, 0.0, 1.25, 1.25, 0.0, 1.25], dtype=torch.float32).cuda()
+    st = ops.bn_finalize(ops.colstats(y), rows, gamma, beta, None, None)
+    out = ops.bn_apply(y, st, res=res, rowscale=keep, rows_per=hw)
+    ref = res.float() + keep.repeat_interleave(hw)[:, None] * (y.float() * st.scale + st.shift)
+    np.testing.assert_allclose(out.float().cpu().numpy(), ref.cpu().numpy(), **tol(dtype, 2.0))
+    dg, db = torch.zeros(c, device="cuda"), torch.zeros(c, device="cuda")
+    dy = ops.bn_backward(dout, y, st, gamma, dg, db, rowscale=keep, rows_per=hw)
+    dscaled = (dout.float() * keep.repeat_interleave(hw)[:, None]).to(dtype)          # exact: the factors are 0 and 1.25 ... rounded once
+    dg2, db2 = torch.zeros(c, device="cuda"), torch.zeros(c, device="cuda")
+    dy2 = ops.bn_backward(dscaled, y, st, gamma, dg2, db2)
+    t = dict(rtol=2e-3, atol=2e-3) if dtype == torch.float32 else dict(rtol=3e-2, atol=3e-2 * max(1.0, dg2.abs().max().item()))
+    np.testing.assert_allclose(dg.cpu().numpy(), dg2.cpu().numpy(), **t)
+    np.testing.assert_allclose(db.cpu().numpy(), db2.cpu().numpy(), **t)
+    np.testing.assert_allclose(dy.float().cpu().numpy(), dy2.float().cpu().numpy(), **tol(dtype, 3.0))
