@@ -38,6 +38,7 @@ import os
 # test hook: take the multi-rank branch (all-gather, all-reduces, reduce-scatter) even in a 1-rank group, so the
 # RCCL call sequence can be exercised on a single-GPU box
 _FORCE_COLLECTIVES = os.environ.get("FRHIP_FORCE_COLLECTIVES", "0") == "1"
+_PFC_SAMPLE_KERNEL = os.environ.get("FRHIP_PFC_SAMPLE_KERNEL", "1") == "1"
 _EARLY_HEAD_UPDATE = os.environ.get("FRHIP_EARLY_HEAD_UPDATE", "1") == "1"
 
 
@@ -89,6 +90,14 @@ class HipHeadKernels:
 
     def gather_rows(self, table, index):
         return self.ops.gather_rows(table, index)
+
+    def pfc_sample_max_local(self):
+        return self.ops.lib().frhip_pfc_sample_max_local()
+
+    def pfc_sample(self, labels, class_start, num_local, u, num_sample, index_out, rel_out, count_out):
+        ops = self.ops
+        ops.check(ops.lib().frhip_pfc_sample(ops._p(labels), labels.numel(), int(class_start), num_local, ops._p(u), num_sample,
+                                             ops._p(index_out), ops._p(rel_out), ops._p(count_out), ops._s()), "frhip_pfc_sample")
 
     def scatter_rows(self, rows, index, table):
         self.ops.scatter_rows(rows.contiguous(), index, table)
@@ -316,12 +325,22 @@ class _PartialFCBase(torch.nn.Module):
             else:
                 index = positive
             labels[index_positive] = torch.searchsorted(index, labels[index_positive])
+        self._install_sample(index, optimizer)
+
+    def _install_sample(self, index, optimizer):
+        """rows `index` of the shard become this step's parameter (reference :120-129)"""
         self.weight_index = index
         k = self.kernels
         self.weight_activated = torch.nn.Parameter(k.gather_rows(self.weight, index))
         for nm in self._state_names:
             setattr(self, "weight_activated_" + nm, k.gather_rows(getattr(self, "weight_" + nm), index))
         self._install_optimizer_state(optimizer)
+
+    def _sample_kernel_ok(self, dev):
+        """one launch of frhip_pfc_sample (csrc/pfc_sample.hip) instead of the ~25 torch launches of the label side"""
+        k = self.kernels
+        return (_PFC_SAMPLE_KERNEL and dev.type == "cuda" and getattr(k, "pfc_sample", None) is not None
+                and self.num_local <= k.pfc_sample_max_local())
 
     def _draw_perm(self, dev):
         """torch.rand(num_local) from the CPU generator (the reference's draws, :110) delivered to the device through a
@@ -357,6 +376,30 @@ class _PartialFCBase(torch.nn.Module):
             labels = lab.clone()
         n_pos, check = None, None
         rng_before = self._rng_state() if (self.sample_rate < 1 and optimizer is not None) else None
+        if self.sample_rate < 1 and optimizer is not None and self._sample_kernel_ok(labels.device):
+            # the whole label side in one kernel: distinct positives, the sampled rows (all positives + the rows with the largest
+            # draws, ascending) and the labels re-expressed as positions in that list.  Optimistic like the torch route below: the
+            # count travels to a pinned slot and forward() verifies num_sample >= #positives a backbone pass later.
+            self.update()
+            self.step += 1
+            dev = labels.device
+            u = self._draw_perm(dev)
+            index = torch.empty(self.num_sample, dtype=torch.int64, device=dev)
+            ready = torch.empty(labels.numel(), dtype=torch.int32, device=dev)
+            count = torch.empty(1, dtype=torch.int64, device=dev)
+            self.kernels.pfc_sample(labels, self.class_start, self.num_local, u, self.num_sample, index, ready, count)
+            pins = getattr(self, "_npos_pins", None)
+            if pins is None:
+                pins = self._npos_pins = [torch.zeros(1, dtype=torch.int64, pin_memory=True) for _ in range(4)]
+                self._npos_turn = 0
+            pin = pins[self._npos_turn % len(pins)]
+            self._npos_turn += 1
+            pin.copy_(count, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            self._install_sample(index, optimizer)
+            self._prep = (local_labels.data_ptr(), labels, 0, ready, [ev, pin, rng_before, None, None], rng_before)
+            return
         if self.sample_rate < 1:
             mask = (self.class_start <= labels) & (labels < self.class_start + self.num_local)
             hits = torch.zeros(self.num_local + 1, dtype=torch.int32, device=labels.device)
@@ -437,6 +480,10 @@ class _PartialFCBase(torch.nn.Module):
                 self._set_rng_state(rng_state)             # (it draws nothing; the optimistic draw is handed back)
                 self.step -= 1
                 with torch.no_grad():
+                    if rel is None:                        # the sampling kernel only reported the count: labels from scratch
+                        glab = prep[1].view(-1, 1)
+                        index_positive = (self.class_start <= glab) & (glab < self.class_start + self.num_local)
+                        rel = torch.where(index_positive, glab - self.class_start, torch.full_like(glab, -1))
                     self.sample(rel, index_positive, optimizer, None)
                 ready = rel.view(-1).to(torch.int32).contiguous()
         batch_size = local_embeddings.size(0)

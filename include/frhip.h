@@ -187,6 +187,17 @@ int frhip_unpack_stem_grad(const float* dwp, float* dw, int k, int kin, int kp, 
 int frhip_fc_permute(int dtype, const float* w, void* wp, int nout, int c, int hw, frhip_stream_t stream);
 int frhip_fc_unpermute_grad(const float* dwp, float* dw, int nout, int c, int hw, frhip_stream_t stream);
 /* PartialFC sampled rows: weight[index] gather (nets/PartialFC.py:120-121) / write-back (:142-143) */
+/* PartialFC.sample (nets/PartialFC.py:108-121) + the shard-relative labels (:188-193) in one launch: labels[n] int64 GLOBAL class ids
+ * of the gathered batch, u[num_local] the uniform draws (torch.rand on the CPU generator, :110), num_sample rows to keep.  Writes
+ * *n_positive = distinct classes of this shard in the batch; if that is <= num_sample: index_out[num_sample] = the sampled rows
+ * ascending (all positives + the rows with the largest draws; equal draws at the cut: lowest row first) and rel_out[n] = position of
+ * the label's class in index_out, or -1 when another rank owns it.  If n_positive > num_sample (reference: `index = positive`, another
+ * output length) n_positive is written, rel_out = -1 and index_out = 0 .. num_sample-1 (valid rows, to be discarded), and the caller
+ * takes that branch itself.  num_local <=
+ * frhip_pfc_sample_max_local(). */
+int frhip_pfc_sample_max_local(void);
+int frhip_pfc_sample(const int64_t* labels, int n, long long class_start, int num_local, const float* u, int num_sample,
+                     int64_t* index_out, int* rel_out, int64_t* n_positive, frhip_stream_t stream);
 int frhip_gather_rows(const float* src, const int64_t* index, float* dst, int n, int d, frhip_stream_t stream);
 int frhip_scatter_rows(const float* src, const int64_t* index, float* dst, int n, int d, frhip_stream_t stream);
 

@@ -136,3 +136,45 @@ def test_dist_cross_entropy_module_matches_reference_fixture(golden):
     (loss * float(g["upstream"])).backward()
     np.testing.assert_allclose(loss.item(), g["loss"], rtol=1e-5)
     np.testing.assert_allclose(z.grad.cpu().numpy(), g["grad"], rtol=1e-4, atol=1e-7)
+
+
+@pytest.mark.parametrize("case", [(1003, 300, 64, 0), (15250, 1525, 4096, 0), (122000, 12200, 512, 0), (4003, 400, 96, 4003 * 2),
+                                  (500, 37, 200, 0), (77, 77, 30, 0), (4096, 1, 8, 0)])
+def test_pfc_sample_kernel_matches_the_torch_formulation(case):
+    """frhip_pfc_sample (one launch) against the reference's formulation of PartialFC.sample (nets/PartialFC.py:108-121: unique ->
+    rand -> perm[positive] = 2 -> topk -> sort -> searchsorted) on the same draws: the sampled row SET, the relabelled targets and
+    the count of distinct positives, bit-exact; and the `more positives than rows` case is reported, not sampled."""
+    from frhip import ops
+    from frhip._abi import lib
+    num_local, k, n, class_start = case
+    g = torch.Generator().manual_seed(sum(case))
+    for trial in range(3):
+        # global labels: some owned by this shard (with repeats), some not
+        lab = torch.randint(class_start - num_local // 2, class_start + num_local + num_local // 2, (n,), generator=g)
+        if trial == 1:
+            lab[: n // 2] = lab[0]                                   # heavy repeats
+        if trial == 2:
+            lab[:] = class_start - 5                                 # nothing owned: pure negatives
+        u = torch.rand(num_local, generator=g)
+        labd, ud = lab.cuda(), u.cuda()
+        index = torch.empty(k, dtype=torch.int64, device="cuda")
+        rel = torch.empty(n, dtype=torch.int32, device="cuda")
+        cnt = torch.empty(1, dtype=torch.int64, device="cuda")
+        ops.check(lib().frhip_pfc_sample(ops._p(labd), n, class_start, num_local, ops._p(ud), k, ops._p(index), ops._p(rel), ops._p(cnt),
+                                         ops._s()), "frhip_pfc_sample")
+        owned = (lab >= class_start) & (lab < class_start + num_local)
+        positive = torch.unique(lab[owned] - class_start, sorted=True)
+        assert int(cnt.item()) == positive.numel()
+        if positive.numel() > k:
+            assert (rel.cpu() == -1).all()
+            continue
+        perm = u.clone()
+        perm[positive] = 2.0
+        ref_index = torch.topk(perm, k=k)[1].sort()[0]
+        # a tie exactly at the cut would make the set depend on top-k's internal order: the seeds above have none
+        kth = perm[ref_index].min()
+        assert (perm == kth).sum() == 1 or kth == 2.0
+        assert torch.equal(index.cpu(), ref_index)
+        ref_rel = torch.full((n,), -1, dtype=torch.int64)
+        ref_rel[owned] = torch.searchsorted(ref_index, lab[owned] - class_start)
+        assert torch.equal(rel.cpu().long(), ref_rel)
