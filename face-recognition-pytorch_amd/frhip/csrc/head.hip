@@ -65,7 +65,8 @@ __global__ __launch_bounds__(256, 2) void head_kernel(NtGeom g, const void* __re
                                                              float* __restrict__ part_sum, float* __restrict__ ztarget,
                                                              const float* __restrict__ rowmax, const float* __restrict__ rowsum,
                                                              float gscale, const float* __restrict__ upstream,
-                                                             void* __restrict__ dt, int ldt, int mtiles, int ntiles) {
+                                                             void* __restrict__ dt, int ldt, void* __restrict__ dtt, int ldtt,
+                                                             int mtiles, int ntiles) {
     typedef NtTile<T, 2, 2> Tile;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const uint32_t lin = xcd_remap(blockIdx.x, gridDim.x);
@@ -144,6 +145,23 @@ __global__ __launch_bounds__(256, 2) void head_kernel(NtGeom g, const void* __re
             const int row = it * RPI + rsub, m = m0 + row;
             if (m < g.M && n < ldt)         // columns in [Nout, ldt) hold zeros (dT pitch padding)
                 *reinterpret_cast<Vec16<T>*>(o + (size_t)m * ldt + n) = *reinterpret_cast<const Vec16<T>*>(mine + row * P + chunk * 16);
+        }
+        if (dtt) {
+            // the same tile transposed, dTt[class][sample] (pitch ldtt, multiple of the 16-byte vector): the embedding-gradient GEMM
+            // contracts over classes and wants class-major rows -- written here, a separate transpose pass (125 MB read + written at
+            // 122 000 classes) is not needed.  Lane = class row of the tile, eight 16-byte vectors of samples each.
+            T* ot = reinterpret_cast<T*>(dtt);
+            const int cls = n0 + lane;
+            if (cls < g.Nout) {
+#pragma unroll
+                for (int v = 0; v < 64 / EPV; ++v) {
+                    Vec16<T> tv;
+#pragma unroll
+                    for (int e = 0; e < EPV; ++e) tv.v[e] = *reinterpret_cast<const T*>(mine + (v * EPV + e) * P + lane * (int)sizeof(T));
+                    const int mcol = m0 + v * EPV;
+                    if (mcol < ldtt) *reinterpret_cast<Vec16<T>*>(ot + (size_t)cls * ldtt + mcol) = tv;      // rows past M hold zeros (masked above)
+                }
+            }
         }
     }
 }
@@ -236,7 +254,7 @@ __global__ void head_loss_kernel(const float* __restrict__ q, int N, float* __re
 template <typename T, bool FWD>
 static int head_launch(const NtGeom& g, const void* ehat, const void* what, const int* labels, const MarginConst& mc,
                        float* pmax, float* psum, float* zt, const float* rmax, const float* rsum, float gscale,
-                       const float* upstream, void* dt, int ldt, hipStream_t stream) {
+                       const float* upstream, void* dt, int ldt, void* dtt, int ldtt, hipStream_t stream) {
     typedef NtTile<T, 2, 2> Tile;
     const int mtiles = (g.M + Tile::BM - 1) / Tile::BM, ntiles = (g.Nout + Tile::BN - 1) / Tile::BN;
     const int lds = Tile::template lds_bytes<T>();
@@ -250,7 +268,7 @@ static int head_launch(const NtGeom& g, const void* ehat, const void* what, cons
         attr_done = true;
     }
     hipLaunchKernelGGL(kern, dim3(mtiles * ntiles), dim3(256), lds, stream, g, ehat, what, labels, mc, pmax, psum,
-                       zt, rmax, rsum, gscale, upstream, dt, ldt, mtiles, ntiles);
+                       zt, rmax, rsum, gscale, upstream, dt, ldt, dtt, ldtt, mtiles, ntiles);
     return check_launch("head");
 }
 
@@ -306,8 +324,8 @@ extern "C" int frhip_head_fwd(int dtype, const void* ehat, const void* what, con
     int rc = head_geom(g, dtype, n, classes, d, "frhip_head_fwd");
     if (rc) return rc;
     const MarginConst mc = margin_const(s, m);
-    if (dtype == FRHIP_DT_BF16) rc = head_launch<bf16_t, true>(g, ehat, what, labels, mc, part_max, part_sum, ztarget, nullptr, nullptr, 0.f, nullptr, nullptr, 0, stream);
-    else rc = head_launch<float, true>(g, ehat, what, labels, mc, part_max, part_sum, ztarget, nullptr, nullptr, 0.f, nullptr, nullptr, 0, stream);
+    if (dtype == FRHIP_DT_BF16) rc = head_launch<bf16_t, true>(g, ehat, what, labels, mc, part_max, part_sum, ztarget, nullptr, nullptr, 0.f, nullptr, nullptr, 0, nullptr, 0, stream);
+    else rc = head_launch<float, true>(g, ehat, what, labels, mc, part_max, part_sum, ztarget, nullptr, nullptr, 0.f, nullptr, nullptr, 0, nullptr, 0, stream);
     if (rc) return rc;
     hipLaunchKernelGGL(head_rowreduce_kernel, dim3((n + 15) / 16), dim3(256), 0, stream, part_max, part_sum,
                        frhip_head_groups(classes), n, rowmax, rowsum);
@@ -345,13 +363,14 @@ extern "C" int frhip_head_loss(const float* q, int n, float* loss, hipStream_t s
 
 extern "C" int frhip_head_bwd_dt(int dtype, const void* ehat, const void* what, const int* labels, int n, int classes,
                                  int d, float s, float m, const float* rowmax, const float* rowsum, float gscale,
-                                 const float* upstream, void* dt, int ldt, hipStream_t stream) {
+                                 const float* upstream, void* dt, int ldt, void* dtt, int ldtt, hipStream_t stream) {
     NtGeom g;
     int rc = head_geom(g, dtype, n, classes, d, "frhip_head_bwd_dt");
     if (rc) return rc;
     const int epv = dtype == FRHIP_DT_BF16 ? 8 : 4;
     if (ldt < classes || (ldt % epv)) { set_error("frhip_head_bwd_dt: bad dT pitch %d", ldt); return FRHIP_EINVAL; }
+    if (dtt && (ldtt < n || (ldtt % epv))) { set_error("frhip_head_bwd_dt: bad transposed pitch %d", ldtt); return FRHIP_EINVAL; }
     const MarginConst mc = margin_const(s, m);
-    if (dtype == FRHIP_DT_BF16) return head_launch<bf16_t, false>(g, ehat, what, labels, mc, nullptr, nullptr, nullptr, rowmax, rowsum, gscale, upstream, dt, ldt, stream);
-    return head_launch<float, false>(g, ehat, what, labels, mc, nullptr, nullptr, nullptr, rowmax, rowsum, gscale, upstream, dt, ldt, stream);
+    if (dtype == FRHIP_DT_BF16) return head_launch<bf16_t, false>(g, ehat, what, labels, mc, nullptr, nullptr, nullptr, rowmax, rowsum, gscale, upstream, dt, ldt, dtt, ldtt, stream);
+    return head_launch<float, false>(g, ehat, what, labels, mc, nullptr, nullptr, nullptr, rowmax, rowsum, gscale, upstream, dt, ldt, dtt, ldtt, stream);
 }

@@ -594,15 +594,20 @@ def head_loss(q):
     return loss
 
 
-def head_bwd_dt(ehat, what, labels_i32, s, m, rmax, rsum, gscale, upstream=None):
+def head_bwd_dt(ehat, what, labels_i32, s, m, rmax, rsum, gscale, upstream=None, transposed=False):
+    """dT [n][classes padded]; transposed=True: also dTt [classes][n padded] from the same launch -> (dT, dTt)"""
     n, d = ehat.shape
     classes = what.shape[0]
     e = epv(ehat.dtype)
     ldt = (classes + e - 1) // e * e
     dt = torch.empty((n, ldt), dtype=ehat.dtype, device=ehat.device)
+    dtt, ldtt = None, 0
+    if transposed:
+        ldtt = (n + e - 1) // e * e
+        dtt = torch.empty((classes, ldtt), dtype=ehat.dtype, device=ehat.device)
     check(lib().frhip_head_bwd_dt(dt_of(ehat), _p(ehat), _p(what), _p(labels_i32), n, classes, d, s, m, _p(rmax),
-                                  _p(rsum), gscale, _p(upstream), _p(dt), ldt, _s()), "frhip_head_bwd_dt")
-    return dt
+                                  _p(rsum), gscale, _p(upstream), _p(dt), ldt, _p(dtt), ldtt, _s()), "frhip_head_bwd_dt")
+    return (dt, dtt) if transposed else dt
 
 
 # ------------------------------------------------------------------------------------------ explicit-logit margin / CE

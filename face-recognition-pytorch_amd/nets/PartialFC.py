@@ -77,10 +77,10 @@ class HipHeadKernels:
         ops = self.ops
         n, d = ehat.shape
         classes = what.shape[0]
-        dt = ops.head_bwd_dt(ehat, what, labels_i32, s, m, rmax, rsum, 1.0 / n_global, upstream)
-        dtt = ops.transpose2d(dt, pad_to=8)
+        # dT and its transpose from ONE launch (the embedding gradient contracts over classes, the weight gradient over samples)
+        dt, dtt = ops.head_bwd_dt(ehat, what, labels_i32, s, m, rmax, rsum, 1.0 / n_global, upstream, transposed=True)
         d_eh = torch.zeros((n, d), dtype=torch.float32, device=ehat.device)
-        ops.gemm_tn(dtt[:classes], what, d_eh, kc=n)
+        ops.gemm_tn(dtt, what, d_eh, kc=n)
         d_e = ops.l2norm_bwd(d_eh, ehat, enorm, out_scale=e_scale)
         if on_de is not None:
             on_de(d_e)

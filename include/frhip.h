@@ -225,10 +225,12 @@ int frhip_head_merge_stats(const float* gathered, int world_size, int n, float* 
                            frhip_stream_t stream);
 int frhip_head_loss(const float* q, int n, float* loss, frhip_stream_t stream);
 /* dT[n][ldt] = d loss / d cos (after clamp/margin/scale chain rule); gscale = 1 / N_global, times the device
- * scalar *upstream when it is not NULL (the reference syncs the host here: loss_gradient.item(), nets/PartialFC.py:484) */
+ * scalar *upstream when it is not NULL (the reference syncs the host here: loss_gradient.item(), nets/PartialFC.py:484).
+ * dtt (may be NULL): the same matrix class-major, dtt[classes][ldtt] (ldtt >= n, a multiple of the 16-byte vector; columns >= n zero),
+ * which the embedding-gradient GEMM (contraction over classes) reads -- written from the same tiles, no transpose pass */
 int frhip_head_bwd_dt(int dtype, const void* ehat, const void* what, const int* labels, int n, int classes,
                       int d, float s, float m, const float* rowmax, const float* rowsum, float gscale,
-                      const float* upstream, void* dt, int ldt, frhip_stream_t stream);
+                      const float* upstream, void* dt, int ldt, void* dtt, int ldtt, frhip_stream_t stream);
 
 /* ---- bn1 -> relu -> conv2 of a BasicBlock (nets/resnet.py:91-93) WITHOUT the activated tensor: the BatchNorm-apply + ReLU
  * is folded into the operand path of the convolution (forward) and of its weight gradient, which read the saved BatchNorm

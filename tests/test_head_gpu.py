@@ -17,11 +17,13 @@ def _run_head(ops, dtype, emb, w_act, ll, s, m, upstream=1.0):
     zt, rmax, rsum = ops.head_fwd(eh, wh, lab, s, m)
     qv = ops.head_target_prob(zt, lab, rmax, rsum)
     loss = ops.head_loss(qv)
-    dt = ops.head_bwd_dt(eh, wh, lab, s, m, rmax, rsum, upstream / n)
+    dt, dtt_fused = ops.head_bwd_dt(eh, wh, lab, s, m, rmax, rsum, upstream / n, transposed=True)
     classes = w_act.shape[0]
     d_wh = torch.zeros((classes, emb.shape[1]), dtype=torch.float32, device="cuda")
     ops.gemm_tn(dt, eh, d_wh, kc=classes)
     dtt = ops.transpose2d(dt, pad_to=8)             # [ldt][n rounded up to 8]
+    # the class-major copy the product path takes from the head kernel itself: the same bits, zero pad columns
+    assert torch.equal(dtt_fused[:, :n], dtt[:classes, :n]) and not dtt_fused[:, n:].any()
     d_eh = torch.zeros((n, emb.shape[1]), dtype=torch.float32, device="cuda")
     ops.gemm_tn(dtt[:classes], wh, d_eh, kc=n)
     d_e = ops.l2norm_bwd(d_eh, eh, en)
