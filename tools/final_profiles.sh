@@ -12,7 +12,7 @@ cd $R
 # PMC traffic passes first: bench.py reports roofline.traffic only from a pass whose kernel-source digest matches this tree
 rm -rf $R/gpurun_out/pmc
 bash tools/pmc_traffic.sh > $OUT/pmc.log 2>&1
-python tools/pmc_traffic_report.py gpurun_out/pmc ${TAG:-r02} > $OUT/pmc_report.log 2>&1
+python tools/pmc_traffic_report.py gpurun_out/pmc ${TAG:-r03} > $OUT/pmc_report.log 2>&1
 python bench.py > $OUT/bench.json 2> $OUT/bench.log
 tail -1 $OUT/bench.json | cut -c1-200
 export FRHIP_BENCH_INSTEP=0
