@@ -1,4 +1,4 @@
-"""The bench line the round ends with (profiles/r02_final_bench.json = stdout of `python bench.py` on the MI355X box) carries
+"""The bench line the round ends with (profiles/r03_final_bench.json = stdout of `python bench.py` on the MI355X box) carries
 every field of the driver's contract, with the metric and workload BASELINE.json names."""
 import json
 import os
@@ -7,7 +7,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_committed_bench_line_has_the_contract_fields():
-    line = json.load(open(os.path.join(ROOT, "profiles", "r02_final_bench.json")))
+    line = json.load(open(os.path.join(ROOT, "profiles", "r03_final_bench.json")))
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in line, k
@@ -25,6 +25,12 @@ def test_committed_bench_line_has_the_contract_fields():
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
     assert c["kind"] == "port" and c["cores"] >= 1
+    # BASELINE cfg 4 / cfg 5 timed in the same process behind the headline: reported beside it, never as `value`
+    ex = line["extra_configs"]
+    assert [e["workload"].split(":")[0] for e in ex] == ["BASELINE cfg 4", "BASELINE cfg 5", "BASELINE cfg 5"]
+    assert [e["dtype"] for e in ex] == ["bf16", "bf16", "fp8-weights"]
+    for e in ex:
+        assert "error" not in e and e["value"] > 0 and abs(e["value"] - int(e["workload"].split("B=")[1].split(",")[0]) * 1e3 / e["ms_per_step"]) / e["value"] < 1e-3
 
 
 def test_bench_cli_defaults_match_the_contract():
