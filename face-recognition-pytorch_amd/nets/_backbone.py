@@ -509,7 +509,7 @@ def basic_block_forward(blk, xin, dt, training, save, wprep=None, q8=None):
         # launch, no second read of y1, the backward pass unchanged
         a1 = torch.empty_like(y1) if save else None
         y2, p2 = ops.conv_fwd_bnrelu(y1, st1, w2, blk.stride, 1, want_stats=training, act_out=a1)
-    elif _FUSE_BN1 and ops.conv_bnrelu_fusable(y1, w2, blk.stride, 1):
+    elif _FUSE_BN1 in (1, 2) and ops.conv_bnrelu_fusable(y1, w2, blk.stride, 1):
         # a1 = relu(bn1(y1)) is never written: conv2 (and, in the backward pass, its weight gradient) form it in LDS from y1
         a1 = None
         y2, p2 = ops.conv_fwd_bnrelu(y1, st1, w2, blk.stride, 1, want_stats=training)
