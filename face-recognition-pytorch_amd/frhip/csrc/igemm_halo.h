@@ -200,6 +200,7 @@ struct HaloMainloop {
         auto load_frags = [&](auto set_c, auto h_c, auto hb_c, auto slot_c, auto tap_c) {
             constexpr int SET = decltype(set_c)::value, HH = decltype(h_c)::value, HB = decltype(hb_c)::value,
                           SLOT = decltype(slot_c)::value, TAP = decltype(tap_c)::value;
+            (void)xf; (void)wf; (void)xcur;      // named outside the constexpr branches so that the generic lambda captures them
             // second K half = chunk index ^ 4  <=>  byte offset ^ 64 (the zero row is 128 B, so ^64 stays inside it)
 #pragma unroll
             for (int t = 0; t < 4; ++t) {

@@ -7,13 +7,33 @@
 
 namespace frhip {
 
-template <typename T, int WM, int WN, int MT, int HBUFS, bool XF = false>
+// Diagnostic build only (-DFRHIP_CLOCK_STAMP=1, tools/clock_probe.py): lane 0 of wave 0 stamps the shader-clock counter
+// (s_memtime) and the constant 100-MHz counter (s_memrealtime) around the main loop; the quotient is the clock the chip holds
+// INSIDE the kernel (MI355X_MICROARCH "DVFS give-back" item 6).  The stamps go to a buffer of their own that nothing else reads.
+#ifndef FRHIP_CLOCK_STAMP
+#define FRHIP_CLOCK_STAMP 0
+#endif
+#if FRHIP_CLOCK_STAMP
+__device__ unsigned long long g_clock_stamps[2 * 8192];
+#endif
+
+template <typename T, int WM, int WN, int MT, int HBUFS, bool XF = false, bool LEAN = false>
 __device__ __forceinline__ void halo_body(const HaloGeom& g, const void* __restrict__ a, const void* __restrict__ b,
                                           void* __restrict__ out, const void* __restrict__ res, float* __restrict__ stats,
                                           const EpiBnRed& br, char* smem, int mtile, int ntile) {
     typedef HaloTile<T, WM, WN, MT, HBUFS> Tile;
     HaloMainloop<T, WM, WN, MT, HBUFS, XF> ml;
+#if FRHIP_CLOCK_STAMP
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+#endif
     ml.run(g, a, b, smem, mtile, ntile);
+#if FRHIP_CLOCK_STAMP
+    if (threadIdx.x == 0) {
+        const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+        g_clock_stamps[2 * (blockIdx.x & 8191)] = t1 - t0;
+        g_clock_stamps[2 * (blockIdx.x & 8191) + 1] = r1 - r0;
+    }
+#endif
     if constexpr (FRHIP_ABL & 16) {
         if (g.M >= 0) {
 #pragma unroll
@@ -27,25 +47,34 @@ __device__ __forceinline__ void halo_body(const HaloGeom& g, const void* __restr
     const int wm = wave / WN, wn = wave % WN;
     const int m0 = mtile * Tile::BM + wm * Tile::WROWS, n0 = ntile * Tile::BN + wn * 64;
     EpiOperands<T, Tile::WROWS> eo;
-    eo.fetch(res, (stats || br.gelu_bwd) ? br.y : nullptr, g.M, g.Nout, m0, n0, br.res_h, br.res_w, &br.map);
-    const char* mine = ml.template stage_out<T>(smem);
-    nt_epilogue_store<T, WM, WN, Tile::WROWS, Tile::THREADS, Tile::BN>(mine, Tile::template stage_pitch<T>(), smem, g.M, g.Nout,
-                                                                       out, res != nullptr, stats, br, eo, mtile, ntile, m0, n0);
+    if constexpr (LEAN) {
+        eo.fetch_fast(res, stats ? br.y : nullptr, g.M, g.Nout, m0, n0);
+        const char* mine = ml.template stage_out<T>(smem);
+        nt_epilogue_store_fast<T, WM, WN, Tile::WROWS, Tile::THREADS, Tile::BN>(mine, Tile::template stage_pitch<T>(), smem, g.M, g.Nout,
+                                                                                out, res != nullptr, stats, br, eo, mtile, ntile);
+    } else {
+        eo.fetch(res, (stats || br.gelu_bwd) ? br.y : nullptr, g.M, g.Nout, m0, n0, br.res_h, br.res_w, &br.map);
+        const char* mine = ml.template stage_out<T>(smem);
+        nt_epilogue_store<T, WM, WN, Tile::WROWS, Tile::THREADS, Tile::BN>(mine, Tile::template stage_pitch<T>(), smem, g.M, g.Nout,
+                                                                           out, res != nullptr, stats, br, eo, mtile, ntile, m0, n0);
+    }
 }
 
-template <typename T, int WM, int WN, int MT, int HBUFS, bool XF = false>
-__global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void halo_kernel(HaloGeom g, const void* __restrict__ a,
+// LEAN: the host found every tile whole and the layout dense (epi_lean_ok): lean store epilogue only
+template <typename T, int WM, int WN, int MT, int HBUFS, bool XF = false, bool LEAN = false>
+__global__ __launch_bounds__(64 * WM * WN, 2) void halo_kernel(HaloGeom g, const void* __restrict__ a,
                                                                          const void* __restrict__ b, void* __restrict__ out,
                                                                          const void* __restrict__ res, float* __restrict__ stats,
                                                                          EpiBnRed br, int mtiles, int ntiles) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const uint32_t lin = xcd_remap(blockIdx.x, gridDim.x);
     const int ntile = (int)(lin % (uint32_t)ntiles), mtile = (int)(lin / (uint32_t)ntiles);
-    halo_body<T, WM, WN, MT, HBUFS, XF>(g, a, b, out, res, stats, br, smem, mtile, ntile);
+    halo_body<T, WM, WN, MT, HBUFS, XF, LEAN>(g, a, b, out, res, stats, br, smem, mtile, ntile);
 }
 
 // 4 waves, 256 pixels x 128 channels, a 64 x 128 tile per wave (igemm_halo_wide.h).  The store epilogue is the shared one, run
 // once per 64-channel half of the tile: to it the workgroup looks like two <4 x 1>-wave tiles of 64 channels.
+template <bool LEAN>
 __global__ __launch_bounds__(256, 2) void halo_wide_kernel(HaloGeom g, const void* __restrict__ a, const void* __restrict__ b,
                                                            void* __restrict__ out, const void* __restrict__ res,
                                                            float* __restrict__ stats, EpiBnRed br, int mtiles, int ntiles) {
@@ -56,32 +85,54 @@ __global__ __launch_bounds__(256, 2) void halo_wide_kernel(HaloGeom g, const voi
     const int ntile = (int)(lin % (uint32_t)ntiles), mtile = (int)(lin / (uint32_t)ntiles);
     const int m_tile0 = mtile * Tile::BM;
     HaloWideMainloop ml;
+#if FRHIP_CLOCK_STAMP
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+#endif
     ml.run(g, a, b, smem, m_tile0, ntile);
+#if FRHIP_CLOCK_STAMP
+    if (threadIdx.x == 0) {
+        const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+        g_clock_stamps[2 * (blockIdx.x & 8191)] = t1 - t0;
+        g_clock_stamps[2 * (blockIdx.x & 8191) + 1] = r1 - r0;
+    }
+#endif
     const int m0 = m_tile0 + wave_id() * Tile::WROWS;
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
         const int n0 = ntile * Tile::BN + half * 64;
         EpiOperands<T, Tile::WROWS> eo;
-        eo.fetch(res, (stats || br.gelu_bwd) ? br.y : nullptr, g.M, g.Nout, m0, n0, br.res_h, br.res_w, &br.map);
-        const char* mine = ml.stage_out(smem, half);
-        nt_epilogue_store<T, 4, 1, Tile::WROWS, Tile::THREADS, 64>(mine, Tile::stage_pitch, smem, g.M, g.Nout, out, res != nullptr,
-                                                                   stats, br, eo, mtile, ntile * 2 + half, m0, n0);
+        if constexpr (LEAN) {
+            eo.fetch_fast(res, stats ? br.y : nullptr, g.M, g.Nout, m0, n0);
+            const char* mine = ml.stage_out(smem, half);
+            nt_epilogue_store_fast<T, 4, 1, Tile::WROWS, Tile::THREADS, 64>(mine, Tile::stage_pitch, smem, g.M, g.Nout, out, res != nullptr,
+                                                                            stats, br, eo, mtile, ntile * 2 + half);
+        } else {
+            eo.fetch(res, (stats || br.gelu_bwd) ? br.y : nullptr, g.M, g.Nout, m0, n0, br.res_h, br.res_w, &br.map);
+            const char* mine = ml.stage_out(smem, half);
+            nt_epilogue_store<T, 4, 1, Tile::WROWS, Tile::THREADS, 64>(mine, Tile::stage_pitch, smem, g.M, g.Nout, out, res != nullptr,
+                                                                       stats, br, eo, mtile, ntile * 2 + half, m0, n0);
+        }
     }
 }
+
+// FRHIP_EPI_LEAN=0: always the general store epilogue (A/B switch; the lean kernels are bit-identical)
+static int g_epi_lean = getenv("FRHIP_EPI_LEAN") ? atoi(getenv("FRHIP_EPI_LEAN")) : 1;
 
 static int halo_wide_launch(const HaloGeom& g, const void* a, const void* b, void* out, const void* res, float* stats,
                             const EpiBnRed& br, hipStream_t stream) {
     typedef HaloWideTile Tile;
     const int mtiles = (g.M + Tile::BM - 1) / Tile::BM, ntiles = (g.Nout + Tile::BN - 1) / Tile::BN;
-    static bool attr_done = false;
-    if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(halo_wide_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, Tile::LDS) != hipSuccess) {
+    const bool lean = g_epi_lean && epi_lean_ok(true, g.M, g.Nout, Tile::BM, Tile::BN, br);
+    auto kern = lean ? halo_wide_kernel<true> : halo_wide_kernel<false>;
+    static bool attr_done[2] = {false, false};
+    if (!attr_done[lean]) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, Tile::LDS) != hipSuccess) {
             set_error("igemm_halo: cannot raise dynamic LDS to %d bytes", Tile::LDS);
             return FRHIP_ELAUNCH;
         }
-        attr_done = true;
+        attr_done[lean] = true;
     }
-    hipLaunchKernelGGL(halo_wide_kernel, dim3(mtiles * ntiles), dim3(Tile::THREADS), Tile::LDS, stream, g, a, b, out, res, stats, br, mtiles, ntiles);
+    hipLaunchKernelGGL(kern, dim3(mtiles * ntiles), dim3(Tile::THREADS), Tile::LDS, stream, g, a, b, out, res, stats, br, mtiles, ntiles);
     return check_launch("igemm_halo_wide");
 }
 
@@ -91,14 +142,19 @@ static int halo_launch(const HaloGeom& g, const void* a, const void* b, void* ou
     typedef HaloTile<T, WM, WN, MT, HBUFS> Tile;
     const int mtiles = (g.M + Tile::BM - 1) / Tile::BM, ntiles = (g.Nout + Tile::BN - 1) / Tile::BN;
     const int lds = Tile::template lds_bytes<T>();
-    auto kern = halo_kernel<T, WM, WN, MT, HBUFS, XF>;
-    static bool attr_done = false;
-    if (!attr_done) {
+    // lean epilogue: the 4-wave bf16 tile (what the training step runs); the other configurations keep the general one
+    constexpr bool HAS_LEAN = sizeof(T) == 2 && WM == 4 && WN == 1 && MT == 4 && HBUFS == 1 && !XF;
+    bool lean = false;
+    if constexpr (HAS_LEAN) lean = g_epi_lean && epi_lean_ok(true, g.M, g.Nout, Tile::BM, Tile::BN, br);
+    auto kern = halo_kernel<T, WM, WN, MT, HBUFS, XF, false>;
+    if constexpr (HAS_LEAN) { if (lean) kern = halo_kernel<T, WM, WN, MT, HBUFS, XF, true>; }
+    static bool attr_done[2] = {false, false};
+    if (!attr_done[lean]) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
             set_error("igemm_halo: cannot raise dynamic LDS to %d bytes", lds);
             return FRHIP_ELAUNCH;
         }
-        attr_done = true;
+        attr_done[lean] = true;
     }
     hipLaunchKernelGGL(kern, dim3(mtiles * ntiles), dim3(Tile::THREADS), lds, stream, g, a, b, out, res, stats, br, mtiles, ntiles);
     return check_launch("igemm_halo");
@@ -183,6 +239,14 @@ int halo_run(int dtype, const void* a, const void* b, void* out, const void* res
 }
 
 }  // namespace frhip
+
+#if FRHIP_CLOCK_STAMP
+// diagnostic build only: copies the (shader-clock ticks, 100-MHz ticks) pairs of the last launch's workgroups to the host
+extern "C" int frhip_dbg_clock_read(unsigned long long* host, int pairs) {
+    if (pairs > 8192) pairs = 8192;
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(frhip::g_clock_stamps), sizeof(unsigned long long) * 2 * pairs) == hipSuccess ? 0 : -1;
+}
+#endif
 
 extern "C" int frhip_set_halo_wide_dirs(int dirs) {
     // which launches may use the 64 x 128-per-wave tile: bit 0 forward, bit 1 data-gradient (default 2); < 0 queries

@@ -265,6 +265,11 @@ struct EpiOperands {
     int M, Nout, m0, n, rsub;
     int res_h, res_w;
     OutMap map;
+    // Lean path (LEAN kernels: bf16, every tile whole, dense layout -- what every body convolution of a ResNet step is): the wave's
+    // rows are addressed as 32-bit buffer offsets -- one lane offset + a scalar row step -- instead of a 64-bit index per row and
+    // lane (PMC: the general epilogue was ~1 070 VALU instructions per wave and tile against 288 MFMAs in the 64-channel layers).
+    uint32_t voff, vstep;
+    static constexpr bool CAN_FAST = PRE && sizeof(T) == 2;
     // element index of residual row for output row m, or -1 when that pixel receives no residual
     __device__ __forceinline__ long long res_index(int m) const {
         if (res_w == 0) return (long long)m * Nout + n;
@@ -301,6 +306,32 @@ struct EpiOperands {
             }
         }
     }
+    // LEAN kernels only (the host checked: bf16, every tile whole, dense rows, no bias / GELU / row map, < 2 GiB): residual and
+    // saved-BatchNorm-input rows by 32-bit buffer offsets
+    __device__ __forceinline__ void fetch_fast(const void* __restrict__ res, const void* __restrict__ ybn, int M_, int Nout_,
+                                               int m0_, int n0) {
+        static_assert(CAN_FAST, "lean epilogue: bf16 tiles of at most 64 rows per wave");
+        const int lane = lane_id();
+        M = M_; Nout = Nout_; m0 = m0_; res_h = 0; res_w = 0; map.wc = 0;
+        n = n0 + (lane % LPR) * EPV; rsub = lane / LPR;
+        r = reinterpret_cast<const T*>(res);
+        y = reinterpret_cast<const T*>(ybn);
+        const uint32_t bytes = (uint32_t)M * (uint32_t)Nout * (uint32_t)sizeof(T);
+        voff = ((uint32_t)(m0 + rsub) * (uint32_t)Nout + (uint32_t)n) * (uint32_t)sizeof(T);
+        vstep = (uint32_t)RPI * (uint32_t)Nout * (uint32_t)sizeof(T);
+        if (r) {
+            const __amdgpu_buffer_rsrc_t rr = make_rsrc(res, bytes);
+#pragma unroll
+            for (int it = 0; it < ITERS; ++it)
+                rv[it].v = __builtin_bit_cast(decltype(rv[it].v), __builtin_amdgcn_raw_buffer_load_b128(rr, voff, it * vstep, 0));
+        }
+        if (y) {
+            const __amdgpu_buffer_rsrc_t ry = make_rsrc(ybn, bytes);
+#pragma unroll
+            for (int it = 0; it < ITERS; ++it)
+                yv[it].v = __builtin_bit_cast(decltype(yv[it].v), __builtin_amdgcn_raw_buffer_load_b128(ry, voff, it * vstep, 0));
+        }
+    }
     // valid for rows inside the tensor only
     __device__ __forceinline__ Vec16<T> res_row(int it) const {
         if constexpr (PRE) return rv[it];
@@ -318,6 +349,12 @@ struct EpiOperands {
     }
 };
 
+// host side: may a launch use the LEAN kernels?  (bm x bn = the workgroup's tile)
+inline bool epi_lean_ok(bool bf16, long long M, int Nout, int bm, int bn, const EpiBnRed& br) {
+    return bf16 && M % bm == 0 && Nout % bn == 0 && br.map.wc == 0 && br.res_w == 0 && !br.bias && !br.act && !br.gelu_bwd &&
+           M * Nout * 2 < 0x7fffffffLL;
+}
+
 // Output rows of the store epilogue go out with non-temporal stores: a conv / linear output is written once and read one
 // kernel later by a streaming pass (which reads it non-temporally as well), so it should not push the weights and the next
 // operand out of L2 on its way.  Step-level A/B (tools/ab_libs.sh, three passes on one box): ResNet50 28.06 / 27.90 / 28.07 ->
@@ -328,6 +365,102 @@ struct EpiOperands {
 template <typename T> __device__ __forceinline__ void epi_store_row(T* p, const Vec16<T>& v) {
     if constexpr (EPI_NT_STORE) __builtin_nontemporal_store(v.v, reinterpret_cast<decltype(v.v)*>(p));
     else *reinterpret_cast<Vec16<T>*>(p) = v;
+}
+
+// Tail of the statistics: per-lane partial sums s1 / s2 (EPV channels each) -> the workgroup's row of per-tile partials.
+// Rows beyond M were gathered as zeros and contribute 0.  Fixed order (lane bits 3, 4, 5, then the WM waves): deterministic.
+template <typename T, int WM, int WN, int THREADS, int BN>
+__device__ __forceinline__ void epi_stats_tail(float (&s1)[16 / (int)sizeof(T)], float (&s2)[16 / (int)sizeof(T)], char* smem, int Nout,
+                                               float* __restrict__ stats, int mtile, int ntile) {
+    constexpr int EPV = 16 / (int)sizeof(T), LPR = 64 / EPV;
+    const int lane = lane_id(), wave = wave_id();
+    const int chunk = lane % LPR;
+#pragma unroll
+    for (int e = 0; e < EPV; ++e) {
+        if constexpr (LPR <= 8) { s1[e] = lane_sum_bit3(s1[e]); s2[e] = lane_sum_bit3(s2[e]); }
+        if constexpr (LPR <= 16) { s1[e] = lane_sum_bit4(s1[e]); s2[e] = lane_sum_bit4(s2[e]); }
+        s1[e] = lane_sum_bit5(s1[e]); s2[e] = lane_sum_bit5(s2[e]);
+    }
+    static_assert(LPR == 8 || LPR == 16, "lanes per 64-channel row");
+    __syncthreads();                                // staging area is free again
+    float* red = reinterpret_cast<float*>(smem);   // [wave][2][64]
+    if (lane < LPR) {
+#pragma unroll
+        for (int e = 0; e < EPV; ++e) {
+            red[(wave * 2 + 0) * 64 + chunk * EPV + e] = s1[e];
+            red[(wave * 2 + 1) * 64 + chunk * EPV + e] = s2[e];
+        }
+    }
+    __syncthreads();
+    // one thread per (wn, stat, channel): sum over the WM waves that share wn
+    for (int t = threadIdx.x; t < WN * 2 * 64; t += THREADS) {
+        const int c = t & 63, st = (t >> 6) & 1, w_n = t >> 7;
+        float a = 0.f;
+#pragma unroll
+        for (int w_m = 0; w_m < WM; ++w_m) a += red[((w_m * WN + w_n) * 2 + st) * 64 + c];
+        const int nn = ntile * BN + w_n * 64 + c;
+        if (nn < Nout) stats[((size_t)mtile * 2 + st) * Nout + nn] = a;
+    }
+}
+
+// Lean store epilogue (LEAN kernels, operands by EpiOperands::fetch_fast): bf16, every tile whole, dense rows, no bias / GELU /
+// row map.  Same values, same summation order as the general path below (results and partial sums are bit-identical); what is gone
+// is the per-row 64-bit index arithmetic, the per-row bounds checks and the layout cases: one buffer descriptor, one lane offset, a
+// scalar row step.
+template <typename T, int WM, int WN, int WROWS, int THREADS, int BN>
+__device__ __forceinline__ void nt_epilogue_store_fast(const char* mine, int P, char* smem, int M, int Nout, void* __restrict__ out,
+                                                       bool has_res, float* __restrict__ stats, const EpiBnRed& br,
+                                                       const EpiOperands<T, WROWS>& ops, int mtile, int ntile) {
+    constexpr int EPV = 16 / (int)sizeof(T), LPR = 64 / EPV, RPI = 64 / LPR, ITERS = WROWS / RPI;
+    const int lane = lane_id();
+    const int chunk = lane % LPR, rsub = lane / LPR;
+    const __amdgpu_buffer_rsrc_t ro = make_rsrc(out, (uint32_t)M * (uint32_t)Nout * (uint32_t)sizeof(T));
+    const char* src = mine + rsub * P + chunk * 16;
+    float s1[EPV], s2[EPV];
+#pragma unroll
+    for (int e = 0; e < EPV; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
+    auto put = [&](int it, const Vec16<T>& v) {
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v.v), ro, ops.voff, it * ops.vstep, EPI_NT_STORE ? 2 : 0);
+    };
+    if (stats && br.y) {
+        const int n = ops.n;
+        float mu[EPV], is[EPV], ms[EPV], mb[EPV];
+#pragma unroll
+        for (int e = 0; e < EPV; ++e) {
+            mu[e] = br.mean[n + e]; is[e] = br.invstd[n + e];
+            ms[e] = br.mscale ? br.mscale[n + e] : 0.f; mb[e] = br.mscale ? br.mshift[n + e] : 1.f;
+        }
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            Vec16<T> v = *reinterpret_cast<const Vec16<T>*>(src + it * RPI * P);
+            if (has_res) {
+#pragma unroll
+                for (int e = 0; e < EPV; ++e) v.set(e, v.get(e) + ops.rv[it].get(e));
+            }
+            put(it, v);
+#pragma unroll
+            for (int e = 0; e < EPV; ++e) {
+                const float yy = ops.yv[it].get(e);
+                const float d = (yy * ms[e] + mb[e] > 0.f) ? v.get(e) : 0.f;
+                s1[e] += d; s2[e] += d * (yy - mu[e]) * is[e];
+            }
+        }
+    } else {
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            Vec16<T> v = *reinterpret_cast<const Vec16<T>*>(src + it * RPI * P);
+            if (has_res) {
+#pragma unroll
+                for (int e = 0; e < EPV; ++e) v.set(e, v.get(e) + ops.rv[it].get(e));
+            }
+            put(it, v);
+            if (stats) {
+#pragma unroll
+                for (int e = 0; e < EPV; ++e) { const float x = v.get(e); s1[e] += x; s2[e] += x * x; }
+            }
+        }
+    }
+    if (stats) epi_stats_tail<T, WM, WN, THREADS, BN>(s1, s2, smem, Nout, stats, mtile, ntile);
 }
 
 // Shared store epilogue: the wave's (WROWS x 64) tile sits in its LDS staging area `mine` as T (row = pixel).
@@ -342,7 +475,7 @@ __device__ __forceinline__ void nt_epilogue_store(const char* mine, int P, char*
     constexpr int EPV = 16 / (int)sizeof(T);          // elements per 16-byte vector
     constexpr int LPR = 64 / EPV;                     // lanes per 64-channel row
     constexpr int RPI = 64 / LPR;                     // rows per wave instruction
-    const int lane = lane_id(), wave = wave_id();
+    const int lane = lane_id();
     const int chunk = lane % LPR, rsub = lane / LPR;
     const int n = n0 + chunk * EPV;
     float s1[EPV], s2[EPV];
@@ -427,35 +560,7 @@ __device__ __forceinline__ void nt_epilogue_store(const char* mine, int P, char*
             for (int e = 0; e < EPV; ++e) { const float x = v.get(e); s1[e] += x; s2[e] += x * x; }
         }
     }
-    if (stats) {
-        // rows beyond M were gathered as zeros -> contribute 0.  Reduce over the lanes that share `chunk`.
-#pragma unroll
-        for (int e = 0; e < EPV; ++e) {
-            if constexpr (LPR <= 8) { s1[e] = lane_sum_bit3(s1[e]); s2[e] = lane_sum_bit3(s2[e]); }
-            if constexpr (LPR <= 16) { s1[e] = lane_sum_bit4(s1[e]); s2[e] = lane_sum_bit4(s2[e]); }
-            s1[e] = lane_sum_bit5(s1[e]); s2[e] = lane_sum_bit5(s2[e]);
-        }
-        static_assert(LPR == 8 || LPR == 16, "lanes per 64-channel row");
-        __syncthreads();                                // staging area is free again
-        float* red = reinterpret_cast<float*>(smem);   // [wave][2][64]
-        if (lane < LPR) {
-#pragma unroll
-            for (int e = 0; e < EPV; ++e) {
-                red[(wave * 2 + 0) * 64 + chunk * EPV + e] = s1[e];
-                red[(wave * 2 + 1) * 64 + chunk * EPV + e] = s2[e];
-            }
-        }
-        __syncthreads();
-        // one thread per (wn, stat, channel): sum over the WM waves that share wn
-        for (int t = threadIdx.x; t < WN * 2 * 64; t += THREADS) {
-            const int c = t & 63, st = (t >> 6) & 1, w_n = t >> 7;
-            float a = 0.f;
-#pragma unroll
-            for (int w_m = 0; w_m < WM; ++w_m) a += red[((w_m * WN + w_n) * 2 + st) * 64 + c];
-            const int nn = ntile * BN + w_n * 64 + c;
-            if (nn < Nout) stats[((size_t)mtile * 2 + st) * Nout + nn] = a;
-        }
-    }
+    if (stats) epi_stats_tail<T, WM, WN, THREADS, BN>(s1, s2, smem, Nout, stats, mtile, ntile);
 }
 
 }  // namespace frhip

@@ -24,6 +24,8 @@ for item in filter(None, os.environ.get("ABL_DEFS", "").split(";")):
     EXTRA[nm] = flags.split(",")
 if EXTRA:
     VARIANTS = {nm: 0 for nm in EXTRA}
+if os.environ.get("ABL_ONLY"):          # ABL_ONLY=full,nodma,noepi: subset of the variants
+    VARIANTS = {nm: VARIANTS[nm] for nm in os.environ["ABL_ONLY"].split(",")}
 
 
 def build():
