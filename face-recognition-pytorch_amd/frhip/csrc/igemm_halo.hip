@@ -143,7 +143,7 @@ static int halo_launch(const HaloGeom& g, const void* a, const void* b, void* ou
     const int mtiles = (g.M + Tile::BM - 1) / Tile::BM, ntiles = (g.Nout + Tile::BN - 1) / Tile::BN;
     const int lds = Tile::template lds_bytes<T>();
     // lean epilogue: the 4-wave bf16 tile (what the training step runs); the other configurations keep the general one
-    constexpr bool HAS_LEAN = sizeof(T) == 2 && WM == 4 && WN == 1 && MT == 4 && HBUFS == 1 && !XF;
+    constexpr bool HAS_LEAN = sizeof(T) == 2 && WM == 4 && WN == 1 && MT == 4 && HBUFS == 1;
     bool lean = false;
     if constexpr (HAS_LEAN) lean = g_epi_lean && epi_lean_ok(true, g.M, g.Nout, Tile::BM, Tile::BN, br);
     auto kern = halo_kernel<T, WM, WN, MT, HBUFS, XF, false>;

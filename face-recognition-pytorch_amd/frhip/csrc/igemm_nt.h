@@ -403,6 +403,74 @@ __device__ __forceinline__ void epi_stats_tail(float (&s1)[16 / (int)sizeof(T)],
     }
 }
 
+// ---- per-channel sums over a wave's staged tile on the MATRIX pipe (LEAN kernels, bf16).
+// The tile sits in LDS as [64 rows][64 channels] bf16 with pitch P.  A transposed read (ds_read_b64_tr_b16) hands lane (g, j) the
+// eight rows 8g .. 8g+7 (of a 32-row K group) of channel c0 + j -- which is both the A and the B operand of an MFMA that
+// contracts over rows: with F the fragment of tile X and F' the fragment of tile Z (same rows, same channels),
+//     mfma(F, F')[i][j]  = sum_rows X[row][c0+i] * Z[row][c0+j]   -> diagonal = sum x*z per channel (products exact, fp32 sums)
+//     mfma(ONES, F)[i][j] = sum_rows X[row][c0+j]                 -> every row i holds the column sums
+// 16 transposed reads + 16 MFMAs per wave replace 64 x (unpack, add, fma) per lane and the 48-step cross-lane reduction: the
+// general epilogue's statistics were ~300 of its VALU instructions.  D layout: lane (g, j) holds rows 4g .. 4g+3 of column j, so
+// the diagonal element of channel c0 + j is register j & 3 of the lane with g == j >> 2; the column sum is in every lane.
+__device__ __forceinline__ bf16x8_t epi_tr_frag(const char* tile, int P, int r0, int c0, int lane) {
+    const int g = lane >> 4, j = lane & 15, q = j >> 2, p = j & 3;
+    const char* pa = tile + (r0 + 8 * g + q) * P + (c0 + 4 * p) * 2;
+    typedef __attribute__((address_space(3))) i16x4_t* lds_p;
+    const i16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)LDS_ADDR(pa));
+    const i16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)LDS_ADDR(pa + 4 * P));
+    typedef __attribute__((ext_vector_type(8))) short i16x8_t;
+    return __builtin_bit_cast(bf16x8_t, (i16x8_t)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+// S[cb][*] = column sums of X (channels 16 cb + j), G[cb] = 16 x 16 block of X^T Z around the diagonal; X at tx, Z at tz (may be tx)
+template <int WROWS>
+__device__ __forceinline__ void epi_mfma_sums(const char* tx, const char* tz, int P, f32x4_t (&S)[4], f32x4_t (&G)[4]) {
+    const int lane = lane_id();
+    bf16x8_t ones;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = (bf16_t)1.0f;
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) { S[cb] = f32x4_t{0.f, 0.f, 0.f, 0.f}; G[cb] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+    for (int ks = 0; ks < WROWS / 32; ++ks)
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) {
+            const bf16x8_t fx = epi_tr_frag(tx, P, 32 * ks, 16 * cb, lane);
+            const bf16x8_t fz = (tz == tx) ? fx : epi_tr_frag(tz, P, 32 * ks, 16 * cb, lane);
+            S[cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, fx, S[cb], 0, 0, 0);
+            G[cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fx, fz, G[cb], 0, 0, 0);
+        }
+}
+// this lane's diagonal element of G (valid in the lanes with (lane & 15) >> 2 == lane >> 4)
+__device__ __forceinline__ float epi_diag(const f32x4_t& g, int lane) {
+    const int e = lane & 3;
+    return e == 0 ? g[0] : (e == 1 ? g[1] : (e == 2 ? g[2] : g[3]));
+}
+// per-wave sums -> the workgroup's row of per-tile partials (sum over the WM waves that share wn, fixed order)
+template <int WM, int WN, int THREADS, int BN>
+__device__ __forceinline__ void epi_stats_tail_mfma(const float (&a1)[4], const float (&a2)[4], char* smem, int Nout,
+                                                    float* __restrict__ stats, int mtile, int ntile) {
+    const int lane = lane_id(), wave = wave_id();
+    const int g = lane >> 4, j = lane & 15;
+    __syncthreads();                                // staging areas are free again
+    float* red = reinterpret_cast<float*>(smem);   // [wave][2][64]
+    if ((j >> 2) == g) {
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) {
+            red[(wave * 2 + 0) * 64 + 16 * cb + j] = a1[cb];
+            red[(wave * 2 + 1) * 64 + 16 * cb + j] = a2[cb];
+        }
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < WN * 2 * 64; t += THREADS) {
+        const int c = t & 63, st = (t >> 6) & 1, w_n = t >> 7;
+        float a = 0.f;
+#pragma unroll
+        for (int w_m = 0; w_m < WM; ++w_m) a += red[((w_m * WN + w_n) * 2 + st) * 64 + c];
+        const int nn = ntile * BN + w_n * 64 + c;
+        if (nn < Nout) stats[((size_t)mtile * 2 + st) * Nout + nn] = a;
+    }
+}
+
 // Lean store epilogue (LEAN kernels, operands by EpiOperands::fetch_fast): bf16, every tile whole, dense rows, no bias / GELU /
 // row map.  Same values, same summation order as the general path below (results and partial sums are bit-identical); what is gone
 // is the per-row 64-bit index arithmetic, the per-row bounds checks and the layout cases: one buffer descriptor, one lane offset, a
@@ -454,11 +522,19 @@ __device__ __forceinline__ void nt_epilogue_store_fast(const char* mine, int P, 
                 for (int e = 0; e < EPV; ++e) v.set(e, v.get(e) + ops.rv[it].get(e));
             }
             put(it, v);
-            if (stats) {
-#pragma unroll
-                for (int e = 0; e < EPV; ++e) { const float x = v.get(e); s1[e] += x; s2[e] += x * x; }
-            }
+            if (has_res && stats)        // the statistics describe the STORED tensor: put the sum back for the matrix-pipe pass
+                *reinterpret_cast<Vec16<T>*>(const_cast<char*>(src) + it * RPI * P) = v;
         }
+        if (stats) {
+            // forward statistics { sum x, sum x^2 } of the stored tile on the matrix pipe
+            f32x4_t S[4], G[4];
+            epi_mfma_sums<WROWS>(mine, mine, P, S, G);
+            float a1[4], a2[4];
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) { a1[cb] = S[cb][0]; a2[cb] = epi_diag(G[cb], lane); }
+            epi_stats_tail_mfma<WM, WN, THREADS, BN>(a1, a2, smem, Nout, stats, mtile, ntile);
+        }
+        return;
     }
     if (stats) epi_stats_tail<T, WM, WN, THREADS, BN>(s1, s2, smem, Nout, stats, mtile, ntile);
 }
