@@ -116,7 +116,7 @@ __global__ __launch_bounds__(256, 2) void halo_wide_kernel(HaloGeom g, const voi
 }
 
 // FRHIP_EPI_LEAN=0: always the general store epilogue (A/B switch; the lean kernels are bit-identical)
-static int g_epi_lean = getenv("FRHIP_EPI_LEAN") ? atoi(getenv("FRHIP_EPI_LEAN")) : 1;
+int g_epi_lean = getenv("FRHIP_EPI_LEAN") ? atoi(getenv("FRHIP_EPI_LEAN")) : 1;
 
 static int halo_wide_launch(const HaloGeom& g, const void* a, const void* b, void* out, const void* res, float* stats,
                             const EpiBnRed& br, hipStream_t stream) {
@@ -247,6 +247,12 @@ extern "C" int frhip_dbg_clock_read(unsigned long long* host, int pairs) {
     return hipMemcpyFromSymbol(host, HIP_SYMBOL(frhip::g_clock_stamps), sizeof(unsigned long long) * 2 * pairs) == hipSuccess ? 0 : -1;
 }
 #endif
+
+extern "C" int frhip_set_epi_lean(int enabled) {
+    const int old = frhip::g_epi_lean;
+    if (enabled >= 0) frhip::g_epi_lean = enabled != 0;
+    return old;
+}
 
 extern "C" int frhip_set_halo_wide_dirs(int dirs) {
     // which launches may use the 64 x 128-per-wave tile: bit 0 forward, bit 1 data-gradient (default 2); < 0 queries

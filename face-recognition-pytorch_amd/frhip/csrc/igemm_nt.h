@@ -484,20 +484,20 @@ __device__ __forceinline__ void nt_epilogue_store_fast(const char* mine, int P, 
     const int chunk = lane % LPR, rsub = lane / LPR;
     const __amdgpu_buffer_rsrc_t ro = make_rsrc(out, (uint32_t)M * (uint32_t)Nout * (uint32_t)sizeof(T));
     const char* src = mine + rsub * P + chunk * 16;
-    float s1[EPV], s2[EPV];
-#pragma unroll
-    for (int e = 0; e < EPV; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
     auto put = [&](int it, const Vec16<T>& v) {
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v.v), ro, ops.voff, it * ops.vstep, EPI_NT_STORE ? 2 : 0);
     };
     if (stats && br.y) {
+        // BatchNorm-backward partials { sum d, sum d * (y - mean) * invstd }, d = the stored gradient behind the ReLU mask, on the
+        // matrix pipe: the masked gradient tile stays in the wave's staging area, the saved BatchNorm input rows (already in
+        // registers) go to a second one, and  sum d (y - mean) invstd = invstd * (sum d y - mean * sum d)  per channel from
+        // ones x D and the diagonal of D^T Y.  What is left on the VALU is the mask (5 instructions per element; none without ReLU).
+        const bool masked = br.mscale != nullptr;
         const int n = ops.n;
-        float mu[EPV], is[EPV], ms[EPV], mb[EPV];
+        char* ydst = const_cast<char*>(src) + WM * WN * WROWS * P;
+        float ms[EPV], mb[EPV];
 #pragma unroll
-        for (int e = 0; e < EPV; ++e) {
-            mu[e] = br.mean[n + e]; is[e] = br.invstd[n + e];
-            ms[e] = br.mscale ? br.mscale[n + e] : 0.f; mb[e] = br.mscale ? br.mshift[n + e] : 1.f;
-        }
+        for (int e = 0; e < EPV; ++e) { ms[e] = masked ? br.mscale[n + e] : 0.f; mb[e] = masked ? br.mshift[n + e] : 1.f; }
 #pragma unroll
         for (int it = 0; it < ITERS; ++it) {
             Vec16<T> v = *reinterpret_cast<const Vec16<T>*>(src + it * RPI * P);
@@ -506,13 +506,35 @@ __device__ __forceinline__ void nt_epilogue_store_fast(const char* mine, int P, 
                 for (int e = 0; e < EPV; ++e) v.set(e, v.get(e) + ops.rv[it].get(e));
             }
             put(it, v);
+            const Vec16<T> yy = ops.yv[it];
+            if (masked) {
+                u32x4_t vb = __builtin_bit_cast(u32x4_t, v.v);
+                const u32x4_t yb = __builtin_bit_cast(u32x4_t, yy.v);
 #pragma unroll
-            for (int e = 0; e < EPV; ++e) {
-                const float yy = ops.yv[it].get(e);
-                const float d = (yy * ms[e] + mb[e] > 0.f) ? v.get(e) : 0.f;
-                s1[e] += d; s2[e] += d * (yy - mu[e]) * is[e];
+                for (int w = 0; w < 4; ++w) {
+                    const float ylo = __uint_as_float(yb[w] << 16), yhi = __uint_as_float(yb[w] & 0xffff0000u);
+                    const uint32_t klo = (ylo * ms[2 * w] + mb[2 * w] > 0.f) ? 0x0000ffffu : 0u;
+                    const uint32_t khi = (yhi * ms[2 * w + 1] + mb[2 * w + 1] > 0.f) ? 0xffff0000u : 0u;
+                    vb[w] &= (klo | khi);
+                }
+                *reinterpret_cast<u32x4_t*>(const_cast<char*>(src) + it * RPI * P) = vb;
+            } else if (has_res) {
+                *reinterpret_cast<Vec16<T>*>(const_cast<char*>(src) + it * RPI * P) = v;
             }
+            *reinterpret_cast<Vec16<T>*>(ydst + it * RPI * P) = yy;
         }
+        f32x4_t S[4], G[4];
+        epi_mfma_sums<WROWS>(mine, mine + WM * WN * WROWS * P, P, S, G);
+        float a1[4], a2[4];
+        const int n0 = ntile * BN + (wave_id() % WN) * 64, j = lane & 15;
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) {
+            const int c = n0 + 16 * cb + j;
+            a1[cb] = S[cb][0];
+            a2[cb] = br.invstd[c] * (epi_diag(G[cb], lane) - br.mean[c] * a1[cb]);
+        }
+        epi_stats_tail_mfma<WM, WN, THREADS, BN>(a1, a2, smem, Nout, stats, mtile, ntile);
+        return;
     } else {
 #pragma unroll
         for (int it = 0; it < ITERS; ++it) {
@@ -534,9 +556,7 @@ __device__ __forceinline__ void nt_epilogue_store_fast(const char* mine, int P, 
             for (int cb = 0; cb < 4; ++cb) { a1[cb] = S[cb][0]; a2[cb] = epi_diag(G[cb], lane); }
             epi_stats_tail_mfma<WM, WN, THREADS, BN>(a1, a2, smem, Nout, stats, mtile, ntile);
         }
-        return;
     }
-    if (stats) epi_stats_tail<T, WM, WN, THREADS, BN>(s1, s2, smem, Nout, stats, mtile, ntile);
 }
 
 // Shared store epilogue: the wave's (WROWS x 64) tile sits in its LDS staging area `mine` as T (row = pixel).

@@ -68,6 +68,10 @@ int frhip_set_conv_halo(int enabled);
 /* test / tuning hook: which 3x3/s1 launches of the W <= 28 layers (bf16, automatic mode) may use the 64 x 128-per-wave halo tile:
  * bit 0 forward, bit 1 data-gradient (default 2); < 0 queries.  Returns the old value */
 int frhip_set_halo_wide_dirs(int dirs);
+/* test hook: 1 (default) = launches whose tiles are all whole and whose layout is dense (bf16) run the LEAN kernel instantiations
+ * (32-bit buffer-offset store epilogue, BatchNorm sums on the matrix pipe); 0 = always the general store epilogue; < 0 queries.
+ * Outputs are bit-identical either way, the per-tile partial sums agree to fp32 summation order.  Returns the old value */
+int frhip_set_epi_lean(int enabled);
 /* test / micro-benchmark hook: force the NT tile (0 auto, 1 128x128, 2 256x64, 3 256x128, 4 256x256); returns the old value */
 int frhip_set_nt_tile(int tile);
 int frhip_conv_fwd(int dtype, const void* x, const void* w, void* y, float* stats_partial,

@@ -194,6 +194,56 @@ def test_dgrad_epilogue_bn_backward_reduction(dtype, case):
     np.testing.assert_allclose(a, b, rtol=2e-4, atol=2e-4 * max(1.0, np.abs(b).max()))
 
 
+@pytest.mark.parametrize("case", [(4, 56, 64), (16, 28, 128), (64, 14, 256), (256, 7, 512), (4, 8, 64), (16, 8, 128)])
+def test_lean_epilogue_against_the_general_one_and_float64(case):
+    """Launches made of whole tiles run the LEAN kernels (frhip_set_epi_lean): 32-bit buffer-offset stores and the BatchNorm sums
+    on the matrix pipe (ones x D, diagonal of D^T Y; the backward sum as invstd * (sum d y - mean * sum d)).  Outputs must be the
+    bits of the general epilogue; the per-channel sums are held against float64 sums over the STORED tensor and may not be further
+    from them than 4x the general epilogue's own error (+ 1e-6 of the sum of magnitudes)."""
+    ops = _ops()
+    from frhip._abi import lib
+    n, h, c = case
+    dt = torch.bfloat16
+    x = rnd(70, (n, h, h, c)).to(dt).cuda()
+    w = (rnd(71, (c, 3, 3, c)) * 0.05)
+    wp, wt = w.to(dt).cuda(), ops.pack_wt(w.cuda(), dt)
+    res = rnd(72, (n, h, h, c)).to(dt).cuda()
+    y_bn = (rnd(73, (n, h, h, c)) * 0.7 + 1.5).to(dt).cuda()          # a mean of two standard deviations: exercises the cancellation
+    rows = n * h * h
+    assert rows % 256 == 0
+    st = ops.bn_finalize(ops.colstats(y_bn.view(rows, c)), rows, (1 + 0.1 * rnd(74, (c,))).cuda(), (0.1 * rnd(75, (c,))).cuda(), None, None)
+    out = {}
+    for lean in (0, 1):
+        old = lib().frhip_set_epi_lean(lean)
+        try:
+            y, p = ops.conv_fwd(x, wp, 1, 1)
+            out[lean] = [(y, p)]
+            for mask in (False, True):
+                for r in (None, res):
+                    out[lean].append(ops.conv_dgrad(x, wt, (n, h, h, c), 3, 3, 1, 1, residual=r, bnred=(y_bn, st, mask)))
+        finally:
+            lib().frhip_set_epi_lean(old)
+    yb = y_bn.double().view(rows, c)
+    mean, invstd, sc, sh = st.mean.double(), st.invstd.double(), st.scale.double(), st.shift.double()
+    for i, ((t0, p0), (t1, p1)) in enumerate(zip(out[0], out[1])):
+        assert torch.equal(t0, t1), i
+        assert p0.shape == p1.shape
+        d = t1.double().view(rows, c)
+        if i == 0:
+            want = torch.stack([d.sum(0), (d * d).sum(0)])
+            mag = torch.stack([d.abs().sum(0), (d * d).sum(0)])
+        else:
+            if (i - 1) // 2 == 1:
+                d = d * ((y_bn.float().view(rows, c) * st.scale + st.shift) > 0)       # the mask as the kernels form it (fp32)
+            xh = (yb - mean) * invstd
+            want = torch.stack([d.sum(0), (d * xh).sum(0)])
+            mag = torch.stack([d.abs().sum(0), (d * xh).abs().sum(0)])
+        e0 = (p0.double().sum(0) - want).abs()
+        e1 = (p1.double().sum(0) - want).abs()
+        lim = 4 * e0.max() + 1e-6 * mag.max()
+        assert float(e1.max()) <= float(lim), (i, float(e0.max()), float(e1.max()), float(mag.max()))
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("case", [(3, 14, 64, 64), (2, 28, 128, 128), (2, 9, 64, 64)])
 def test_dgrad_compact_stride2_residual(dtype, case):
