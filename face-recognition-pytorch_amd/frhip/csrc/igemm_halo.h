@@ -79,11 +79,7 @@ struct HaloMainloop {
                                         const void* __restrict__ b_ptr, char* smem, int mtile, int ntile) {
         const int lane = lane_id(), wave = wave_id();
         const int wm = wave / WN, wn = wave % WN;
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < MT; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-
+        // no zero fill of the accumulators: the first K half of the first tap writes them with a literal-zero C operand
         const __amdgpu_buffer_rsrc_t ra = make_rsrc(a_ptr, g.a_bytes);
         const __amdgpu_buffer_rsrc_t rb = make_rsrc(b_ptr, g.b_bytes);
         const int m0 = mtile * BM;
@@ -94,11 +90,12 @@ struct HaloMainloop {
         const uint32_t chunk_bytes = (uint32_t)(((lane & 7) ^ sub) * 16);
         const int nchunks = g.C / BKE;
 
+        const uint32_t row0_off = (uint32_t)((p_lo + sub) * g.C) * (uint32_t)sizeof(T) + chunk_bytes;    // this lane's row of piece 0
         // one 1-KiB halo piece: rows 8*piece .. 8*piece+7 of chunk c0 into buffer hb
         auto halo_piece = [&](int hb, int piece, int c0) {
-            const int r = piece * 8 + sub;
-            const int p = p_lo + r;
-            const uint32_t off = (p >= 0 && p < g.M) ? (uint32_t)(p * g.C + c0) * (uint32_t)sizeof(T) + chunk_bytes : OOB_OFFSET;
+            // rows outside the tensor need no test: p < 0 wraps to an offset beyond 2 GiB, p >= M lies beyond a_bytes -- the buffer
+            // range check zero-fills both (a_bytes = M * C * sizeof(T) < 2^31)
+            const uint32_t off = row0_off + (uint32_t)(piece * 8 * g.C + c0) * (uint32_t)sizeof(T);
             glds16<HALO_A_AUX>(ra, smem + hb * Tile::HALO_BYTES + piece * 1024, off);
         };
         // XF: BatchNorm + ReLU of the pieces THIS wave loaded (after its own vmcnt(0), before the barrier that publishes them).
@@ -158,7 +155,18 @@ struct HaloMainloop {
         static_assert(Tile::HALO_BYTES < 65536, "packed fragment offsets");
         uint32_t xa[9][(MT + 1) / 2];
         {
+            // row(mt, tap) = q_mt + tc_tap with tc_tap = W + 1 + dy W + dx wave-uniform, and q_mt & 7 == fi & 7 (tile and wave bases are
+            // multiples of 16), so the byte offset splits into a per-mt and a per-tap term: 128 q_mt + [128 tc + ((fg ^ ((fi + tc) & 7)) << 4)];
+            // the validity of a tap is an AND of four per-row predicates (scalar mask arithmetic).  4 + 9 address terms, then one
+            // add and one select per (mt, tap) instead of the whole expression 36 times.
             const int HW = g.H * g.W;
+            uint32_t tt[9];
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int tc = g.W + 1 + g.sign * ((tap / 3 - 1) * g.W + (tap % 3 - 1));
+                tt[tap] = (uint32_t)(tc * NT_ROWB) + (uint32_t)((fg ^ ((fi + tc) & 7)) << 4);
+            }
+            const uint32_t zoff = (uint32_t)(Tile::ZROW + (fg << 4));
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 const int q = wm * Tile::WROWS + mt * 16 + fi;
@@ -166,12 +174,15 @@ struct HaloMainloop {
                 int y = 0, x = 0;
                 const bool live = m < g.M;
                 if (live) { const int rem = m - (int)fdiv((uint32_t)m, g.d_hw) * HW; y = (int)fdiv((uint32_t)rem, g.d_w); x = rem - y * g.W; }
+                // predicates in the direction of the gather: "dn" = the row y + 1 exists, ...; sign = -1 swaps the roles
+                const bool up = live && y > 0, dn = live && y < g.H - 1, lf = live && x > 0, rt = live && x < g.W - 1;
+                const bool vy[3] = {g.sign > 0 ? up : dn, live, g.sign > 0 ? dn : up};
+                const bool vx[3] = {g.sign > 0 ? lf : rt, live, g.sign > 0 ? rt : lf};
+                const uint32_t aq = (uint32_t)(q * NT_ROWB);
 #pragma unroll
                 for (int tap = 0; tap < 9; ++tap) {
-                    const int dy = g.sign * (tap / 3 - 1), dx = g.sign * (tap % 3 - 1);
-                    const bool ok = live && (unsigned)(y + dy) < (unsigned)g.H && (unsigned)(x + dx) < (unsigned)g.W;
-                    const int row = q + g.W + 1 + dy * g.W + dx;
-                    const uint32_t off = ok ? (uint32_t)(row * NT_ROWB + ((fg ^ (row & 7)) << 4)) : (uint32_t)(Tile::ZROW + (fg << 4));
+                    const bool ok = vy[tap / 3] && vx[tap % 3];
+                    const uint32_t off = ok ? aq + tt[tap] : zoff;
                     if (mt & 1) xa[tap][mt >> 1] |= off << 16;
                     else xa[tap][mt >> 1] = off;
                 }
@@ -232,6 +243,19 @@ struct HaloMainloop {
                     else Mma<T>::run(wf[SET][nt], xf[SET][mt], acc[nt][mt]);
                 }
         };
+        // first K half of (chunk 0, tap 0): C = 0 (an inline constant of the instruction) instead of 16 * MT zeroed registers
+        auto mfma_set_first = [&](auto set_c) {
+            constexpr int SET = decltype(set_c)::value;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) {
+                    f32x4_t z = f32x4_t{0.f, 0.f, 0.f, 0.f};
+                    if constexpr (FRHIP_ABL & 2) { Frag fa = wf[SET][nt], fb = xf[SET][mt]; asm volatile("" :: "v"(fa), "v"(fb)); }
+                    else Mma<T>::run(wf[SET][nt], xf[SET][mt], z);
+                    acc[nt][mt] = z;
+                }
+        };
         // ask the scheduler to spread the (4 + MT) fragment reads of a half between its 4*MT MFMAs
         auto interleave = [&]() {
             constexpr int NREAD = (4 + MT) * (int)(sizeof(Frag) / 16), NMFMA = 4 * MT * (sizeof(T) == 2 ? 1 : (sizeof(T) == 1 ? 2 : 4));
@@ -276,7 +300,8 @@ struct HaloMainloop {
                     }
                 }
                 load_frags(I1{}, I1{}, hb_c, std::integral_constant<int, TAP % Tile::WRING>{}, tap_c);   // (9*ch + TAP) % 3 == TAP % 3
-                mfma_set(I0{});
+                if (TAP == 0 && ch == 0) mfma_set_first(I0{});
+                else mfma_set(I0{});
                 interleave();
                 // everything but this iteration's pieces has landed -> weights of the next iteration are in LDS
                 if constexpr (FRHIP_ABL & 8) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
