@@ -45,10 +45,7 @@ struct HaloWideMainloop {
                                         char* smem, int m0, int ntile) {
         constexpr int MT = Tile::MT, BKE = 64;
         const int lane = lane_id(), wave = wave_id();
-#pragma unroll
-        for (int i = 0; i < Tile::NTW; ++i)
-#pragma unroll
-            for (int j = 0; j < MT; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        // no zero fill of the 128 accumulator registers: the first K half of (chunk 0, tap 0) multiplies into a literal-zero C operand
         const __amdgpu_buffer_rsrc_t ra = make_rsrc(a_ptr, g.a_bytes);
         const __amdgpu_buffer_rsrc_t rb = make_rsrc(b_ptr, g.b_bytes);
         const int hrows = Tile::BM + 2 * g.W + 2;
@@ -58,12 +55,11 @@ struct HaloWideMainloop {
         const uint32_t chunk_bytes = (uint32_t)(((lane & 7) ^ sub) * 16);
         const int nchunks = g.C / BKE;
 
+        const uint32_t row0_off = (uint32_t)((p_lo + sub) * g.C) * 2u + chunk_bytes;       // this lane's row of piece 0
         auto halo_load = [&](int c0) {
-            for (int piece = wave; piece < npieces; piece += Tile::WAVES) {
-                const int p = p_lo + piece * 8 + sub;
-                const uint32_t off = (p >= 0 && p < g.M) ? (uint32_t)(p * g.C + c0) * 2u + chunk_bytes : OOB_OFFSET;
-                glds16(ra, smem + piece * 1024, off);
-            }
+            // rows outside the tensor: a negative pixel wraps beyond 2 GiB, p >= M lies beyond a_bytes -- the buffer range check zero-fills
+            for (int piece = wave; piece < npieces; piece += Tile::WAVES)
+                glds16(ra, smem + piece * 1024, row0_off + (uint32_t)(piece * 8 * g.C + c0) * 2u);
         };
         uint32_t brow_off[Tile::B_PIECES];
 #pragma unroll
@@ -86,7 +82,15 @@ struct HaloWideMainloop {
         static_assert(Tile::HALO_BYTES < 65536, "packed fragment offsets");
         uint32_t xa[9][(MT + 1) / 2];
         {
+            // offset(mt, tap) = 128 q_mt + [128 tc_tap + swizzle(tap)], validity = AND of per-row predicates: see igemm_halo.h
             const int HW = g.H * g.W;
+            uint32_t tt[9];
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int tc = g.W + 1 + g.sign * ((tap / 3 - 1) * g.W + (tap % 3 - 1));
+                tt[tap] = (uint32_t)(tc * NT_ROWB) + (uint32_t)((fg ^ ((fi + tc) & 7)) << 4);
+            }
+            const uint32_t zoff = (uint32_t)(Tile::ZROW + (fg << 4));
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 const int q = wave * Tile::WROWS + mt * 16 + fi;
@@ -94,12 +98,14 @@ struct HaloWideMainloop {
                 int y = 0, x = 0;
                 const bool live = m < g.M;
                 if (live) { const int rem = m - (int)fdiv((uint32_t)m, g.d_hw) * HW; y = (int)fdiv((uint32_t)rem, g.d_w); x = rem - y * g.W; }
+                const bool up = live && y > 0, dn = live && y < g.H - 1, lf = live && x > 0, rt = live && x < g.W - 1;
+                const bool vy[3] = {g.sign > 0 ? up : dn, live, g.sign > 0 ? dn : up};
+                const bool vx[3] = {g.sign > 0 ? lf : rt, live, g.sign > 0 ? rt : lf};
+                const uint32_t aq = (uint32_t)(q * NT_ROWB);
 #pragma unroll
                 for (int tap = 0; tap < 9; ++tap) {
-                    const int dy = g.sign * (tap / 3 - 1), dx = g.sign * (tap % 3 - 1);
-                    const bool ok = live && (unsigned)(y + dy) < (unsigned)g.H && (unsigned)(x + dx) < (unsigned)g.W;
-                    const int row = q + g.W + 1 + dy * g.W + dx;
-                    const uint32_t off = ok ? (uint32_t)(row * NT_ROWB + ((fg ^ (row & 7)) << 4)) : (uint32_t)(Tile::ZROW + (fg << 4));
+                    const bool ok = vy[tap / 3] && vx[tap % 3];
+                    const uint32_t off = ok ? aq + tt[tap] : zoff;
                     if (mt & 1) xa[tap][mt >> 1] |= off << 16;
                     else xa[tap][mt >> 1] = off;
                 }
@@ -141,6 +147,18 @@ struct HaloWideMainloop {
 #pragma unroll
                 for (int t = 0; t < 4; ++t) Mma<T>::run(wf[SET][t], xf[HH][mt], acc[Q * 4 + t][mt]);
         };
+        // K half 0 of (chunk 0, tap 0): C = 0 as an inline constant of the instruction
+        auto mfma16_first = [&](auto set_c, auto q_c) {
+            constexpr int SET = decltype(set_c)::value, Q = decltype(q_c)::value;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    f32x4_t z = f32x4_t{0.f, 0.f, 0.f, 0.f};
+                    Mma<T>::run(wf[SET][t], xf[0][mt], z);
+                    acc[Q * 4 + t][mt] = z;
+                }
+        };
         typedef std::integral_constant<int, 0> I0;
         typedef std::integral_constant<int, 1> I1;
 
@@ -163,10 +181,11 @@ struct HaloWideMainloop {
             load_x(I0{}, tap_c);
             load_w(I0{}, I0{}, I0{});
             load_w(I1{}, I0{}, I1{});
-            mfma16(I0{}, I0{}, I0{});
+            const bool first = TAP == 0 && ch == 0;
+            if (first) mfma16_first(I0{}, I0{}); else mfma16(I0{}, I0{}, I0{});
             load_x(I1{}, tap_c);
             load_w(I0{}, I1{}, I0{});
-            mfma16(I1{}, I0{}, I1{});
+            if (first) mfma16_first(I1{}, I1{}); else mfma16(I1{}, I0{}, I1{});
             load_w(I1{}, I1{}, I1{});
             mfma16(I0{}, I1{}, I0{});
             mfma16(I1{}, I1{}, I1{});
