@@ -69,6 +69,12 @@ struct EpiBnRed {
     // gelu_bwd != 0 (data-gradient of a Linear that feeds a GELU): out = gemm o gelu'(y), y = the saved pre-activation
     // (same shape as out); the forward-style statistics then carry the column sums of out = the bias gradient
     int gelu_bwd;
+    // eval-mode BatchNorm folded into the store (inference, model/FR_PartialFC.py:205-211: encoder.eval()): the convolution result,
+    // rounded to T as the unfused pair would store it, goes through out = [relu](v * aff_scale[n] + aff_shift[n] + residual) -- the
+    // arithmetic of bn_apply_kernel -- and only that tensor is written.  No statistics in this mode.
+    const float* aff_scale;
+    const float* aff_shift;
+    int aff_relu;
 };
 
 // WM x WN waves; each wave owns (MT*16) pixel rows x 64 channels (4 MFMA tiles wide).
@@ -535,6 +541,22 @@ __device__ __forceinline__ void nt_epilogue_store_fast(const char* mine, int P, 
         }
         epi_stats_tail_mfma<WM, WN, THREADS, BN>(a1, a2, smem, Nout, stats, mtile, ntile);
         return;
+    } else if (br.aff_scale) {
+        // eval-mode BatchNorm folded into the store (see EpiBnRed): no statistics
+        float asc[EPV], ash[EPV];
+#pragma unroll
+        for (int e = 0; e < EPV; ++e) { asc[e] = br.aff_scale[ops.n + e]; ash[e] = br.aff_shift[ops.n + e]; }
+#pragma unroll
+        for (int it = 0; it < ITERS; ++it) {
+            Vec16<T> v = *reinterpret_cast<const Vec16<T>*>(src + it * RPI * P);
+#pragma unroll
+            for (int e = 0; e < EPV; ++e) {
+                float o = v.get(e) * asc[e] + ash[e];
+                if (has_res) o += ops.rv[it].get(e);
+                v.set(e, br.aff_relu ? fmaxf(o, 0.f) : o);
+            }
+            put(it, v);
+        }
     } else {
 #pragma unroll
         for (int it = 0; it < ITERS; ++it) {
@@ -609,9 +631,13 @@ __device__ __forceinline__ void nt_epilogue_store(const char* mine, int P, char*
             }
         }
     } else {
-        float bb[EPV];
+        float bb[EPV], asc[EPV], ash[EPV];
 #pragma unroll
-        for (int e = 0; e < EPV; ++e) bb[e] = (br.bias && n + e < Nout) ? br.bias[n + e] : 0.f;
+        for (int e = 0; e < EPV; ++e) {
+            bb[e] = (br.bias && n + e < Nout) ? br.bias[n + e] : 0.f;
+            asc[e] = (br.aff_scale && n + e < Nout) ? br.aff_scale[n + e] : 1.f;
+            ash[e] = (br.aff_scale && n + e < Nout) ? br.aff_shift[n + e] : 0.f;
+        }
         T* ao = reinterpret_cast<T*>(br.act);
 #pragma unroll
         for (int it = 0; it < WROWS / RPI; ++it) {
@@ -619,7 +645,16 @@ __device__ __forceinline__ void nt_epilogue_store(const char* mine, int P, char*
             const int m = m0 + row;
             Vec16<T> v = *reinterpret_cast<const Vec16<T>*>(mine + row * P + chunk * 16);
             if (m < M && n < Nout) {
-                if (has_res) {
+                if (br.aff_scale) {
+                    Vec16<T> rr;
+                    if (has_res) rr = ops.res_row(it);
+#pragma unroll
+                    for (int e = 0; e < EPV; ++e) {
+                        float o = v.get(e) * asc[e] + ash[e];
+                        if (has_res) o += rr.get(e);
+                        v.set(e, br.aff_relu ? fmaxf(o, 0.f) : o);
+                    }
+                } else if (has_res) {
                     const Vec16<T> rr = ops.res_row(it);
 #pragma unroll
                     for (int e = 0; e < EPV; ++e) v.set(e, v.get(e) + rr.get(e));

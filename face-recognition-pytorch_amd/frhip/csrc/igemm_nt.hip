@@ -197,6 +197,22 @@ extern "C" int frhip_conv_fwd(int dtype, const void* x, const void* w, void* y, 
     return nt_dispatch(dtype, g, x, w, y, nullptr, stats_partial, NO_BNRED, 1, false, stream);
 }
 
+extern "C" int frhip_conv_fwd_affine(int dtype, const void* x, const void* w, void* y, const float* scale, const float* shift, int relu,
+                                     const void* residual, int n, int h, int wd, int c, int k, int r, int s, int stride, int pad,
+                                     hipStream_t stream) {
+    // y = [relu](conv(x, w) * scale[k] + shift[k] + residual): eval-mode BatchNorm (frhip_bn_eval_affine) folded into the store epilogue
+    if (!scale || !shift) { set_error("frhip_conv_fwd_affine: scale and shift are required"); return FRHIP_EINVAL; }
+    NtGeom g;
+    const int ho = (h + 2 * pad - r) / stride + 1, wo = (wd + 2 * pad - s) / stride + 1;
+    int rc = fill_geom(g, dtype, n, h, wd, c, ho, wo, k, r, s, stride, pad, 0, "frhip_conv_fwd_affine");
+    if (rc) return rc;
+    EpiBnRed br = NO_BNRED;
+    br.aff_scale = scale; br.aff_shift = shift; br.aff_relu = relu;
+    if (halo_applicable(dtype, h, wd, c, k, r, s, stride, pad))
+        return halo_run(dtype, x, w, y, residual, nullptr, br, n, h, wd, c, k, +1, stream);
+    return nt_dispatch(dtype, g, x, w, y, residual, nullptr, br, 1, false, stream);
+}
+
 extern "C" int frhip_conv_bnrelu_fusable(int dtype, int h, int wd, int c, int k, int r, int s, int stride, int pad) {
     return halo_xf_applicable(dtype, h, wd, c, k, r, s, stride, pad) ? 1 : 0;
 }

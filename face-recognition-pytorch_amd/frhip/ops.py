@@ -52,6 +52,21 @@ def conv_fwd(x, w, stride, pad, want_stats=True):
     return y, part
 
 
+def conv_fwd_affine(x, w, st, stride, pad, relu=False, residual=None):
+    """inference: y = [relu](conv(x, w) * st.scale + st.shift + residual) -- eval-mode BatchNorm (bn_eval_affine) folded into the
+    convolution's store epilogue; residual shaped like y"""
+    n, h, wd, c = x.shape
+    k, r, s, c2 = w.shape
+    assert c == c2 and x.dtype == w.dtype
+    ho, wo = conv_out_hw(h, wd, r, s, stride, pad)
+    y = torch.empty((n, ho, wo, k), dtype=x.dtype, device=x.device)
+    if residual is not None and (tuple(residual.shape) != tuple(y.shape) or residual.dtype != y.dtype):
+        raise ValueError("conv_fwd_affine: residual must have the shape and dtype of the output")
+    check(lib().frhip_conv_fwd_affine(dt_of(x), _p(x), _p(w), _p(y), _p(st.scale), _p(st.shift), int(relu), _p(residual),
+                                      n, h, wd, c, k, r, s, stride, pad, _s()), "frhip_conv_fwd_affine")
+    return y
+
+
 def conv_dgrad(dy, wt, x_shape, r, s, stride, pad, residual=None, out=None, bnred=None, residual_stride=1):
     """dy [N,Ho,Wo,K], wt [C,R,S,K] -> dx [N,H,W,C] (+ residual).
 

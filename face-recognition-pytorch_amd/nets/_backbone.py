@@ -23,6 +23,8 @@ _STEM_FUSED_REDUCE = os.environ.get("FRHIP_STEM_FUSED_REDUCE", "1") == "1"     #
 # 2: folded into the forward kernel only; the backward pass re-forms a1 with a BatchNorm-apply pass on the SIDE stream right in front
 #    of conv2's weight gradient, where it hides beside the main stream's matrix work (the forward pass has nothing to hide it under)
 _FUSE_BN1 = int(os.environ.get("FRHIP_FUSE_BN1", "0"))
+# inference: eval-mode BatchNorms folded into the store epilogues of the convolutions (0: separate BatchNorm-apply passes)
+_EVAL_FOLD = os.environ.get("FRHIP_EVAL_FOLD", "1") == "1"
 # hand a weight gradient to the side stream BEFORE the data-gradient of the same dy is enqueued (the side stream waits for what
 # the main stream holds at the hand-over): 27.16 -> 26.9 ms on the ResNet50 step.  One hand-over per block instead of one per
 # weight gradient (fewer barrier packets, but conv2's weight gradient starts a data-gradient later) measured 27.3 -> 27.7: off.
@@ -491,6 +493,19 @@ def basic_block_forward(blk, xin, dt, training, save, wprep=None, q8=None):
     passes that feed them write the fp8 operand copy themselves.  Everything saved for the backward pass stays as in the
     bf16 path (the backward kernels read the bf16 tensors)."""
     cin, planes = blk.conv1.cin, blk.conv2.cout
+    if not training and not save and q8 is None and _EVAL_FOLD:
+        # inference: the eval-mode BatchNorms are affine maps with fixed coefficients -- they ride in the store epilogues of the
+        # convolutions that feed them (frhip_conv_fwd_affine); no BatchNorm-apply pass, no intermediate conv output tensor
+        w1, _ = _operands(blk.conv1, dt, wprep)
+        w2, _ = _operands(blk.conv2, dt, wprep)
+        a1 = ops.conv_fwd_affine(xin, w1, bn_forward_state(blk.bn1, None, 0, False), 1, 1, relu=True)
+        res = xin
+        if blk.downsample is not None:
+            dconv, dbn = blk.downsample[0], blk.downsample[1]
+            wd, _ = _operands(dconv, dt, wprep)
+            res = ops.conv_fwd_affine(xin, wd, bn_forward_state(dbn, None, 0, False), dconv.stride, 0)
+        out = ops.conv_fwd_affine(a1, w2, bn_forward_state(blk.bn2, None, 0, False), blk.stride, 1, residual=res)
+        return out, None
     f1 = q8 is not None and dt == torch.bfloat16 and Fp8Ctx.eligible(cin)      # conv1, conv2 and the shortcut conv all read cin channels
     fo = q8 is not None and dt == torch.bfloat16 and Fp8Ctx.eligible(planes)   # the block output feeds a GEMM of `planes` channels
     w1, w1t = _operands(blk.conv1, dt, wprep)

@@ -74,6 +74,13 @@ int frhip_set_halo_wide_dirs(int dirs);
 int frhip_set_epi_lean(int enabled);
 /* test / micro-benchmark hook: force the NT tile (0 auto, 1 128x128, 2 256x64, 3 256x128, 4 256x256); returns the old value */
 int frhip_set_nt_tile(int tile);
+/* Inference (model/FR_PartialFC.py:205-211: encoder.eval(); nets/resnet.py:89-103 with BatchNorm in eval mode): convolution with the
+ * eval-mode BatchNorm folded into its store epilogue, y = [relu](conv(x, w) * scale[k] + shift[k] + residual), scale / shift from
+ * frhip_bn_eval_affine, residual (optional) shaped like y.  The convolution result is rounded to the compute dtype before the
+ * affine map, as the unfused pair frhip_conv_fwd + frhip_bn_apply stores it: same values, one tensor pass less per BatchNorm. */
+int frhip_conv_fwd_affine(int dtype, const void* x, const void* w, void* y, const float* scale, const float* shift, int relu,
+                          const void* residual, int n, int h, int wd, int c, int k, int r, int s, int stride, int pad,
+                          frhip_stream_t stream);
 int frhip_conv_fwd(int dtype, const void* x, const void* w, void* y, float* stats_partial,
                    int n, int h, int wd, int c, int k, int r, int s, int stride, int pad, frhip_stream_t stream);
 /* dx[n,h,w,c] = conv_transpose(dy[n,ho,wo,k], w) (+ residual[n,h,w,c] if not NULL); wt = frhip_pack_wt(w) = [c][r][s][k].

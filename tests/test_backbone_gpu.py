@@ -52,6 +52,29 @@ def test_resnet50_eval_fp32(golden):
     np.testing.assert_allclose(y.cpu().numpy(), golden("resnet50_b2_eval")["out"], rtol=1e-3, atol=2e-4)
 
 
+@pytest.mark.parametrize("name,batch", [("ResNet18", 16), ("ResNet50", 64)])
+def test_eval_with_folded_batchnorm_matches_the_separate_passes(monkeypatch, name, batch):
+    """Inference (reference model/FR_PartialFC.py:205-211, encoder.eval()): the eval-mode BatchNorms ride in the store epilogues of the
+    convolutions (frhip_conv_fwd_affine; nets._backbone._EVAL_FOLD) -- lean kernels where the batch makes whole tiles, the general
+    epilogue elsewhere.  Same arithmetic as conv + BatchNorm-apply on the rounded conv output; only the shortcut convolution's
+    BatchNorm is rounded once more (its output is a tensor now: four bf16 roundings of 2^-9 in a ResNet, carried through 25 blocks).
+    bf16: embeddings within 2 % of the separate passes (the suite's whole-network bf16 tolerance is 5 %), cosine >= 0.9999."""
+    import nets._backbone as bb
+    net, _ = _net(name, "bf16", 777)
+    net.eval()
+    x = recipe.images(778, batch).cuda()
+    outs = []
+    for fold in (False, True):
+        monkeypatch.setattr(bb, "_EVAL_FOLD", fold)
+        with torch.no_grad():
+            outs.append(net(x).float())
+    a, b = outs
+    assert torch.isfinite(b).all()
+    rel = float((a - b).norm() / a.norm())
+    cos = torch.nn.functional.cosine_similarity(a, b, dim=1)
+    assert rel <= 2e-2 and float(cos.min()) >= 0.9999, (rel, float(cos.min()))
+
+
 def test_resnet18_bf16_tracks_fp32():
     """bf16 MFMA path: same code, bf16 storage.  Embeddings stay within bf16 noise of the fp32 path and the
     parameter gradients point the same way (cosine > 0.99 per tensor for the large tensors)."""
