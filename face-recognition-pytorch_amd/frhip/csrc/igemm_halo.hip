@@ -204,6 +204,16 @@ static int halo_config(int dtype, int c, int k) {
     return narrow ? 1 : 2;
 }
 
+// would halo_run take a LEAN kernel for this forward problem?  (frhip_conv_fwd_affine: the folded BatchNorm lives in the lean epilogue)
+bool halo_lean_applies(int dtype, int n, int h, int w, int c, int k, int sign) {
+    if (!g_epi_lean || dtype != FRHIP_DT_BF16) return false;
+    const long long M = 1LL * n * h * w;
+    const int cfg = halo_config_w(dtype, w, c, k, sign) == 3 ? 3 : halo_config(dtype, c, k);
+    const int bn = cfg == 3 ? HaloWideTile::BN : 64;
+    if (cfg != 3 && cfg != 0) return false;
+    return M % 256 == 0 && k % bn == 0 && M * k * 2 < 0x7fffffffLL;
+}
+
 // rows of the BN-partial buffer a halo launch writes for an output of m pixels
 int halo_stat_rows(int, int m, int, int, int, int) { return (m + 255) / 256; }
 

@@ -71,7 +71,8 @@ struct EpiBnRed {
     int gelu_bwd;
     // eval-mode BatchNorm folded into the store (inference, model/FR_PartialFC.py:205-211: encoder.eval()): the convolution result,
     // rounded to T as the unfused pair would store it, goes through out = [relu](v * aff_scale[n] + aff_shift[n] + residual) -- the
-    // arithmetic of bn_apply_kernel -- and only that tensor is written.  No statistics in this mode.
+    // arithmetic of bn_apply_kernel -- and only that tensor is written.  No statistics in this mode.  LEAN kernels only: launches
+    // that are not made of whole tiles run conv + frhip_bn_apply (frhip_conv_fwd_affine decides).
     const float* aff_scale;
     const float* aff_shift;
     int aff_relu;
@@ -373,42 +374,6 @@ template <typename T> __device__ __forceinline__ void epi_store_row(T* p, const 
     else *reinterpret_cast<Vec16<T>*>(p) = v;
 }
 
-// Tail of the statistics: per-lane partial sums s1 / s2 (EPV channels each) -> the workgroup's row of per-tile partials.
-// Rows beyond M were gathered as zeros and contribute 0.  Fixed order (lane bits 3, 4, 5, then the WM waves): deterministic.
-template <typename T, int WM, int WN, int THREADS, int BN>
-__device__ __forceinline__ void epi_stats_tail(float (&s1)[16 / (int)sizeof(T)], float (&s2)[16 / (int)sizeof(T)], char* smem, int Nout,
-                                               float* __restrict__ stats, int mtile, int ntile) {
-    constexpr int EPV = 16 / (int)sizeof(T), LPR = 64 / EPV;
-    const int lane = lane_id(), wave = wave_id();
-    const int chunk = lane % LPR;
-#pragma unroll
-    for (int e = 0; e < EPV; ++e) {
-        if constexpr (LPR <= 8) { s1[e] = lane_sum_bit3(s1[e]); s2[e] = lane_sum_bit3(s2[e]); }
-        if constexpr (LPR <= 16) { s1[e] = lane_sum_bit4(s1[e]); s2[e] = lane_sum_bit4(s2[e]); }
-        s1[e] = lane_sum_bit5(s1[e]); s2[e] = lane_sum_bit5(s2[e]);
-    }
-    static_assert(LPR == 8 || LPR == 16, "lanes per 64-channel row");
-    __syncthreads();                                // staging area is free again
-    float* red = reinterpret_cast<float*>(smem);   // [wave][2][64]
-    if (lane < LPR) {
-#pragma unroll
-        for (int e = 0; e < EPV; ++e) {
-            red[(wave * 2 + 0) * 64 + chunk * EPV + e] = s1[e];
-            red[(wave * 2 + 1) * 64 + chunk * EPV + e] = s2[e];
-        }
-    }
-    __syncthreads();
-    // one thread per (wn, stat, channel): sum over the WM waves that share wn
-    for (int t = threadIdx.x; t < WN * 2 * 64; t += THREADS) {
-        const int c = t & 63, st = (t >> 6) & 1, w_n = t >> 7;
-        float a = 0.f;
-#pragma unroll
-        for (int w_m = 0; w_m < WM; ++w_m) a += red[((w_m * WN + w_n) * 2 + st) * 64 + c];
-        const int nn = ntile * BN + w_n * 64 + c;
-        if (nn < Nout) stats[((size_t)mtile * 2 + st) * Nout + nn] = a;
-    }
-}
-
 // ---- per-channel sums over a wave's staged tile on the MATRIX pipe (LEAN kernels, bf16).
 // The tile sits in LDS as [64 rows][64 channels] bf16 with pitch P.  A transposed read (ds_read_b64_tr_b16) hands lane (g, j) the
 // eight rows 8g .. 8g+7 (of a 32-row K group) of channel c0 + j -- which is both the A and the B operand of an MFMA that
@@ -593,7 +558,7 @@ __device__ __forceinline__ void nt_epilogue_store(const char* mine, int P, char*
     constexpr int EPV = 16 / (int)sizeof(T);          // elements per 16-byte vector
     constexpr int LPR = 64 / EPV;                     // lanes per 64-channel row
     constexpr int RPI = 64 / LPR;                     // rows per wave instruction
-    const int lane = lane_id();
+    const int lane = lane_id(), wave = wave_id();
     const int chunk = lane % LPR, rsub = lane / LPR;
     const int n = n0 + chunk * EPV;
     float s1[EPV], s2[EPV];
@@ -631,13 +596,9 @@ __device__ __forceinline__ void nt_epilogue_store(const char* mine, int P, char*
             }
         }
     } else {
-        float bb[EPV], asc[EPV], ash[EPV];
+        float bb[EPV];
 #pragma unroll
-        for (int e = 0; e < EPV; ++e) {
-            bb[e] = (br.bias && n + e < Nout) ? br.bias[n + e] : 0.f;
-            asc[e] = (br.aff_scale && n + e < Nout) ? br.aff_scale[n + e] : 1.f;
-            ash[e] = (br.aff_scale && n + e < Nout) ? br.aff_shift[n + e] : 0.f;
-        }
+        for (int e = 0; e < EPV; ++e) bb[e] = (br.bias && n + e < Nout) ? br.bias[n + e] : 0.f;
         T* ao = reinterpret_cast<T*>(br.act);
 #pragma unroll
         for (int it = 0; it < WROWS / RPI; ++it) {
@@ -645,16 +606,7 @@ __device__ __forceinline__ void nt_epilogue_store(const char* mine, int P, char*
             const int m = m0 + row;
             Vec16<T> v = *reinterpret_cast<const Vec16<T>*>(mine + row * P + chunk * 16);
             if (m < M && n < Nout) {
-                if (br.aff_scale) {
-                    Vec16<T> rr;
-                    if (has_res) rr = ops.res_row(it);
-#pragma unroll
-                    for (int e = 0; e < EPV; ++e) {
-                        float o = v.get(e) * asc[e] + ash[e];
-                        if (has_res) o += rr.get(e);
-                        v.set(e, br.aff_relu ? fmaxf(o, 0.f) : o);
-                    }
-                } else if (has_res) {
+                if (has_res) {
                     const Vec16<T> rr = ops.res_row(it);
 #pragma unroll
                     for (int e = 0; e < EPV; ++e) v.set(e, v.get(e) + rr.get(e));
@@ -691,7 +643,35 @@ __device__ __forceinline__ void nt_epilogue_store(const char* mine, int P, char*
             for (int e = 0; e < EPV; ++e) { const float x = v.get(e); s1[e] += x; s2[e] += x * x; }
         }
     }
-    if (stats) epi_stats_tail<T, WM, WN, THREADS, BN>(s1, s2, smem, Nout, stats, mtile, ntile);
+    if (stats) {
+        // rows beyond M were gathered as zeros -> contribute 0.  Reduce over the lanes that share `chunk`.
+#pragma unroll
+        for (int e = 0; e < EPV; ++e) {
+            if constexpr (LPR <= 8) { s1[e] = lane_sum_bit3(s1[e]); s2[e] = lane_sum_bit3(s2[e]); }
+            if constexpr (LPR <= 16) { s1[e] = lane_sum_bit4(s1[e]); s2[e] = lane_sum_bit4(s2[e]); }
+            s1[e] = lane_sum_bit5(s1[e]); s2[e] = lane_sum_bit5(s2[e]);
+        }
+        static_assert(LPR == 8 || LPR == 16, "lanes per 64-channel row");
+        __syncthreads();                                // staging area is free again
+        float* red = reinterpret_cast<float*>(smem);   // [wave][2][64]
+        if (lane < LPR) {
+#pragma unroll
+            for (int e = 0; e < EPV; ++e) {
+                red[(wave * 2 + 0) * 64 + chunk * EPV + e] = s1[e];
+                red[(wave * 2 + 1) * 64 + chunk * EPV + e] = s2[e];
+            }
+        }
+        __syncthreads();
+        // one thread per (wn, stat, channel): sum over the WM waves that share wn
+        for (int t = threadIdx.x; t < WN * 2 * 64; t += THREADS) {
+            const int c = t & 63, st = (t >> 6) & 1, w_n = t >> 7;
+            float a = 0.f;
+#pragma unroll
+            for (int w_m = 0; w_m < WM; ++w_m) a += red[((w_m * WN + w_n) * 2 + st) * 64 + c];
+            const int nn = ntile * BN + w_n * 64 + c;
+            if (nn < Nout) stats[((size_t)mtile * 2 + st) * Nout + nn] = a;
+        }
+    }
 }
 
 }  // namespace frhip

@@ -9,6 +9,7 @@ namespace frhip {
 bool halo_applicable(int dtype, int h, int w, int c, int k, int r, int s, int stride, int pad);
 int halo_stat_rows(int dtype, int m, int w, int c, int k, int sign);
 bool halo_xf_applicable(int dtype, int h, int w, int c, int k, int r, int s, int stride, int pad);
+bool halo_lean_applies(int dtype, int n, int h, int w, int c, int k, int sign);
 int halo_run(int dtype, const void* a, const void* b, void* out, const void* res, float* stats, const EpiBnRed& br,
              int n, int h, int w, int c, int k, int sign, hipStream_t stream, const float* xf_scale = nullptr,
              const float* xf_shift = nullptr, void* xf_out = nullptr);
@@ -206,11 +207,16 @@ extern "C" int frhip_conv_fwd_affine(int dtype, const void* x, const void* w, vo
     const int ho = (h + 2 * pad - r) / stride + 1, wo = (wd + 2 * pad - s) / stride + 1;
     int rc = fill_geom(g, dtype, n, h, wd, c, ho, wo, k, r, s, stride, pad, 0, "frhip_conv_fwd_affine");
     if (rc) return rc;
-    EpiBnRed br = NO_BNRED;
-    br.aff_scale = scale; br.aff_shift = shift; br.aff_relu = relu;
-    if (halo_applicable(dtype, h, wd, c, k, r, s, stride, pad))
+    if (halo_applicable(dtype, h, wd, c, k, r, s, stride, pad) && halo_lean_applies(dtype, n, h, wd, c, k, +1)) {
+        EpiBnRed br = NO_BNRED;
+        br.aff_scale = scale; br.aff_shift = shift; br.aff_relu = relu;
         return halo_run(dtype, x, w, y, residual, nullptr, br, n, h, wd, c, k, +1, stream);
-    return nt_dispatch(dtype, g, x, w, y, residual, nullptr, br, 1, false, stream);
+    }
+    // not a launch of whole tiles on a lean kernel (strided / 1x1 convolutions, small batches, fp32 validation mode): the unfused pair,
+    // the BatchNorm-apply pass in place on the convolution's output -- same values
+    rc = frhip_conv_fwd(dtype, x, w, y, nullptr, n, h, wd, c, k, r, s, stride, pad, stream);
+    if (rc) return rc;
+    return frhip_bn_apply(dtype, y, scale, shift, residual, nullptr, nullptr, relu, y, n * ho * wo, k, stream);
 }
 
 extern "C" int frhip_conv_bnrelu_fusable(int dtype, int h, int wd, int c, int k, int r, int s, int stride, int pad) {

@@ -74,3 +74,12 @@ for sub in ("fetch", "write"):
 subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "pmc_traffic_report.py"), os.path.join(ROOT, "gpurun_out", "pmc"), TAG],
                       stdout=subprocess.DEVNULL)
 print(d["value"], d["ms_per_step"], d["roofline"]["frac"], d["roofline"]["avg_launch_us"], d["cpu_baseline"]["value"])
+
+# in-kernel clock, ablation and inference throughput (tools/clock_probe.py, tools/ablate.py, tools/bench_eval.py)
+for src, dst, hdr in (("clock.txt", "_inkernel_clock.txt", "# tools/clock_probe.py run: s_memtime / s_memrealtime stamps around the main loop of every workgroup (diagnostic build)\n"),
+                      ("ablate.txt", "_halo_ablation.txt", "# tools/ablate.py run: timing-only variants of the 4-wave halo kernel (results of the ablated variants are wrong by design), forward, no statistics\n"),
+                      ("eval.txt", "_eval_throughput.txt", "# tools/bench_eval.py ResNet50 512: encoder in eval mode, BatchNorm folded into the conv epilogues (1) against separate passes (0)\n")):
+    f = os.path.join(F, src)
+    if os.path.exists(f):
+        body = "".join(l for l in open(f) if "amdgpu.ids" not in l)
+        open(os.path.join(P, TAG + dst), "w").write(hdr + body)

@@ -36,4 +36,9 @@ done
 FRHIP_T9_NARROW=0 FRHIP_T9_LDS_PAD=0 bash tools/pmc_run.sh $OUT/pmc_wgrad8 wgrad 14 256 256 > $OUT/pmc_wgrad8.log 2>&1 || true
 python tools/pmc_show.py $OUT/pmc_wgrad8 > $OUT/pmc_wgrad8.txt 2>/dev/null || true
 rm -rf $OUT/pmc_*/g*      # raw counter CSVs: summarised in pmc_*.txt
+# in-kernel clock of the halo kernels (diagnostic build: `python tools/clock_probe.py build` before the snapshot) and the timing-only
+# ablation of the 4-wave halo kernel (`ABL_ONLY=... python tools/ablate.py build`)
+CLOCK_SECS=1.5 python tools/clock_probe.py run > $OUT/clock.txt 2>&1 || true
+ABL_ONLY=full,nobar,nomfma,nodma,noepi,nolds,mfma_only,lds_only python tools/ablate.py run > $OUT/ablate.txt 2>&1 || true
+python tools/bench_eval.py ResNet50 512 > $OUT/eval.txt 2>&1 || true
 ls $OUT | head -40
