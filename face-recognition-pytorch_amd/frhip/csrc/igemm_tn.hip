@@ -525,7 +525,9 @@ void tn_taps9_kernel(TnGeom g, const void* __restrict__ p_ptr, const void* __res
 #pragma unroll
         for (int pre = 0; pre < NST - 1; ++pre)
             if (pre < nks) stage(pre);
-        if (NST == 3 && nks > 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(Cfg::DMA_PER_STAGE) : "memory");
+        // stages 0 .. NST-2 are in flight; stage 0 must have landed: all but the min(nks, NST-1) - 1 newest
+        if (NST >= 4 && nks > 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * Cfg::DMA_PER_STAGE) : "memory");
+        else if (NST >= 3 && nks > 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(Cfg::DMA_PER_STAGE) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         xform_stage(0, ks_begin);
         __syncthreads();
@@ -535,7 +537,9 @@ void tn_taps9_kernel(TnGeom g, const void* __restrict__ p_ptr, const void* __res
             if (it + NST - 1 < nks && !(FRHIP_ABL & 8)) stage((BUF + NST - 1) % NST);
             compute(buf_c);
             if (it + 1 < nks) {
-                if (NST == 3 && it + 2 < nks) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(Cfg::DMA_PER_STAGE) : "memory");
+                // the next stage (it + 1) must have landed; younger stages issued so far: it + 2 .. min(it + NST - 1, nks - 1)
+                if (NST >= 4 && it + 3 < nks) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * Cfg::DMA_PER_STAGE) : "memory");
+                else if (NST >= 3 && it + 2 < nks) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(Cfg::DMA_PER_STAGE) : "memory");
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 xform_stage((BUF + 1) % NST, ks_begin + it + 1);
                 if constexpr (!(FRHIP_ABL & 1)) __builtin_amdgcn_s_barrier();
@@ -544,7 +548,8 @@ void tn_taps9_kernel(TnGeom g, const void* __restrict__ p_ptr, const void* __res
         for (int it = 0; it < nks; it += NST) {
             step(std::integral_constant<int, 0>{}, it);
             if (it + 1 < nks) step(std::integral_constant<int, 1>{}, it + 1);
-            if constexpr (NST == 3) { if (it + 2 < nks) step(std::integral_constant<int, 2>{}, it + 2); }
+            if constexpr (NST >= 3) { if (it + 2 < nks) step(std::integral_constant<int, 2>{}, it + 2); }
+            if constexpr (NST >= 4) { if (it + 3 < nks) step(std::integral_constant<int, 3>{}, it + 3); }
         }
     }
     // ---- epilogue: accumulators straight from registers.  D layout: lane holds rows co = a*16 + 4*(lane>>4) + e, column
@@ -618,6 +623,7 @@ static int g_tn_taps9 = 1;
 // per CU); the gain from having a side stream at all grows from 0.9 to 1.7 ms.  FRHIP_T9_NARROW=0 / FRHIP_T9_LDS_PAD=0 restore
 // the stand-alone-fastest choice (kernel micro-benchmarks use it).
 static int g_t9_narrow = getenv("FRHIP_T9_NARROW") ? atoi(getenv("FRHIP_T9_NARROW")) : 1;
+static int g_t9_stages4 = getenv("FRHIP_T9_STAGES4") ? atoi(getenv("FRHIP_T9_STAGES4")) : 1;     // A/B switch of the four-stage variant
 static int g_t9_lds_pad = getenv("FRHIP_T9_LDS_PAD") ? atoi(getenv("FRHIP_T9_LDS_PAD")) : 83968;
 template <int WCO, int WCI, int COF, int CIF, bool XF = false, int NST = 2, int QROWS = T9_QROWS>
 static int tn_taps9_launch(const TnGeom& g, const void* p, const void* q, float* out, int splits, hipStream_t stream) {
@@ -830,10 +836,13 @@ static int tn_run(int dtype, const void* p, const void* q, float* out, int n, in
         splits = (g.ksteps + g.ksteps_per_split - 1) / g.ksteps_per_split;
         float* dst = (kc % 4 == 0) ? tn_pick_dst(g, out, splits, out_elems, ws, ws_bytes) : out;      // slab layout packs co in fours
         const bool deep = !wide && 64 + 2 * w + 2 <= 128;      // three stages of a 128-row window
+        // W <= 14: a 96-row window, 20-KB stages -- FOUR fit the co-resident tile's 82-KB request, so an operand load has three K steps to land
+        const bool deep4 = deep && g_t9_stages4 && 64 + 2 * w + 2 <= 96 && !xf_scale;
         if (xf_scale) rc = wide ? tn_taps9_launch<2, 4, 4, 1, true>(g, p, q, dst, splits, stream)
                          : deep ? tn_taps9_launch<1, 4, 4, 1, true, 3, 128>(g, p, q, dst, splits, stream)
                                 : tn_taps9_launch<1, 4, 4, 1, true>(g, p, q, dst, splits, stream);
         else rc = wide ? tn_taps9_launch<2, 4, 4, 1>(g, p, q, dst, splits, stream)
+                : deep4 ? tn_taps9_launch<1, 4, 4, 1, false, 4, 96>(g, p, q, dst, splits, stream)
                 : deep ? tn_taps9_launch<1, 4, 4, 1, false, 3, 128>(g, p, q, dst, splits, stream)
                        : tn_taps9_launch<1, 4, 4, 1>(g, p, q, dst, splits, stream);
         return rc ? rc : t9_finish(g, out, splits, out_elems, ws, stream);
