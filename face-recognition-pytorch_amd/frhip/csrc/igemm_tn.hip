@@ -47,6 +47,10 @@ struct TnGeom {
     // gradient wants their output; relu(q * xf_scale[ci] + xf_shift[ci]) is formed in LDS after every window stage has landed
     const float* xf_scale;
     const float* xf_shift;
+    // nine-tap kernel, TAB instantiations: padding predicates of the four pixel rows a lane addresses, as 64-bit LANE masks per K step,
+    // [mask_period][4 rows][up, dn, lf, rt] (t9_mask_table below); K step ks uses row ks % mask_period
+    const unsigned long long* mask_tab;
+    int mask_period;
 };
 
 constexpr int TN_THREADS = 256;
@@ -304,7 +308,9 @@ struct T9Cfg {
     static_assert((NST - 1) * STAGE < 65536 && (QROWS / 8) % NW == 0, "stage base must fit the 16-bit DS offset field");
 };
 
-template <int WCO, int WCI, int COF, int CIF, bool XF = false, int NST = 2, int QROWS = T9_QROWS>
+// TAB: the padding predicates come from a table of lane masks (scalar loads, s_and_b64, v_cndmask on the SGPR pair) instead of per-lane
+// position tracking and compares: 22 v_cmp + 20 position updates per K step (72 MFMAs) leave the vector instruction stream.
+template <int WCO, int WCI, int COF, int CIF, bool XF = false, int NST = 2, int QROWS = T9_QROWS, bool TAB = false>
 __global__ __launch_bounds__(64 * WCO * WCI, (WCO * WCI > 4 ? 1 : 2))
 void tn_taps9_kernel(TnGeom g, const void* __restrict__ p_ptr, const void* __restrict__ q_ptr, float* __restrict__ out,
                      int co_tiles, int ci_tiles) {
@@ -425,6 +431,17 @@ void tn_taps9_kernel(TnGeom g, const void* __restrict__ p_ptr, const void* __res
             qa[t][i] = lds0 + (uint32_t)(Cfg::P_BYTES + qrow * 128 + ((cq ^ tn_swz<128>(qrow)) << 4) + 8 * (fp & 1));
         }
     }
+    int tstep = 0;
+    unsigned long long mk[16];
+    // the table is read-only for the lifetime of the process: constant address space -> the loads are scalar (s_load_dwordx16), the
+    // masks live in SGPR pairs and feed s_and_b64 / v_cndmask directly
+    typedef const __attribute__((address_space(4))) unsigned long long* mask_cp;
+    const mask_cp mask_base = (mask_cp)(uintptr_t)g.mask_tab;
+    if constexpr (TAB) {
+        tstep = __builtin_amdgcn_readfirstlane(ks_begin % g.mask_period);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) mk[k] = mask_base[tstep * 16 + k];
+    }
     typedef __attribute__((ext_vector_type(8))) short i16x8_t;
     // lo_a / hi_a: LDS byte addresses in stage 0; OFF (compile time) selects the stage through the DS immediate
     auto tr8 = [&](auto off_c, uint32_t lo_a, uint32_t hi_a) {
@@ -449,8 +466,16 @@ void tn_taps9_kernel(TnGeom g, const void* __restrict__ p_ptr, const void* __res
         }
         // rows past M need no mask: their dy rows were zero-filled and every window row read is finite data or zero
         bool up[4], dn[4], lf[4], rt[4];
+        if constexpr (TAB) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { up[i] = pho[i] > 0; dn[i] = pho[i] < g.H - 1; lf[i] = pwo[i] > 0; rt[i] = pwo[i] < g.W - 1; }
+            for (int i = 0; i < 4; ++i) {
+                up[i] = __builtin_amdgcn_inverse_ballot_w64(mk[4 * i + 0]); dn[i] = __builtin_amdgcn_inverse_ballot_w64(mk[4 * i + 1]);
+                lf[i] = __builtin_amdgcn_inverse_ballot_w64(mk[4 * i + 2]); rt[i] = __builtin_amdgcn_inverse_ballot_w64(mk[4 * i + 3]);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { up[i] = pho[i] > 0; dn[i] = pho[i] < g.H - 1; lf[i] = pwo[i] > 0; rt[i] = pwo[i] < g.W - 1; }
+        }
         // software pipeline over the 18 (kk, tap) groups: the transposed reads of group n+1 (and the dy fragments of
         // the second K half) are issued before the MFMAs of group n, so LDS latency hides behind the matrix pipe
         bf16x8_t pf[2][COF];
@@ -507,12 +532,19 @@ void tn_taps9_kernel(TnGeom g, const void* __restrict__ p_ptr, const void* __res
             __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
 #endif
         }
+        if constexpr (TAB) {
+            // the next K step's masks: scalar loads, issued behind this step's last fragment reads and consumed after the barrier
+            tstep = tstep + 1 == g.mask_period ? 0 : tstep + 1;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            int wo = pwo[i] + g.adv_wo, ho = pho[i] + g.adv_ho;
-            if (wo >= g.Wo) { wo -= g.Wo; ++ho; }
-            if (ho >= g.Ho) ho -= g.Ho;
-            pwo[i] = wo; pho[i] = ho;
+            for (int k = 0; k < 16; ++k) mk[k] = mask_base[tstep * 16 + k];
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                int wo = pwo[i] + g.adv_wo, ho = pho[i] + g.adv_ho;
+                if (wo >= g.Wo) { wo -= g.Wo; ++ho; }
+                if (ho >= g.Ho) ho -= g.Ho;
+                pwo[i] = wo; pho[i] = ho;
+            }
         }
     };
 
@@ -625,11 +657,54 @@ static int g_tn_taps9 = 1;
 static int g_t9_narrow = getenv("FRHIP_T9_NARROW") ? atoi(getenv("FRHIP_T9_NARROW")) : 1;
 static int g_t9_stages4 = getenv("FRHIP_T9_STAGES4") ? atoi(getenv("FRHIP_T9_STAGES4")) : 1;     // A/B switch of the four-stage variant
 static int g_t9_lds_pad = getenv("FRHIP_T9_LDS_PAD") ? atoi(getenv("FRHIP_T9_LDS_PAD")) : 83968;
-template <int WCO, int WCI, int COF, int CIF, bool XF = false, int NST = 2, int QROWS = T9_QROWS>
+// ---- lane-mask table of the TAB instantiations.  Lane l addresses the pixel rows prow_i(l) = (i >> 1) * 32 + 8 (l >> 4) + ((l & 15) >> 2)
+// + 4 (i & 1) of a K step; K step t covers pixels 64 t .., and a pixel's padding predicates depend on its position inside its image
+// only, so the masks repeat with period H W / gcd(H W, 64) K steps (49 for 7, 14, 28 and 56-wide square maps).  One table per geometry,
+// in module memory, filled on first use (blocking copy: never inside a stream capture -- a warm-up step comes first).
+constexpr int T9_TAB_GEOMS = 8, T9_TAB_MAXP = 64;
+__device__ unsigned long long g_t9_masks[T9_TAB_GEOMS][T9_TAB_MAXP * 16];
+static int g_t9_tab = getenv("FRHIP_T9_MASK_TABLE") ? atoi(getenv("FRHIP_T9_MASK_TABLE")) : 1;
+static bool t9_mask_table(TnGeom& g) {
+    static struct { int h, w, period; const unsigned long long* dev; } cache[T9_TAB_GEOMS];
+    static int used = 0;
+    g.mask_tab = nullptr; g.mask_period = 0;
+    if (!g_t9_tab) return false;
+    for (int i = 0; i < used; ++i)
+        if (cache[i].h == g.H && cache[i].w == g.W) { g.mask_tab = cache[i].dev; g.mask_period = cache[i].period; return true; }
+    const int hw = g.H * g.W;
+    int a = hw, b = 64;
+    while (b) { const int t = a % b; a = b; b = t; }
+    const int period = hw / a;
+    if (period > T9_TAB_MAXP || used == T9_TAB_GEOMS) return false;
+    static unsigned long long host[T9_TAB_MAXP * 16];
+    for (int t = 0; t < period; ++t)
+        for (int i = 0; i < 4; ++i) {
+            unsigned long long m[4] = {0, 0, 0, 0};
+            for (int l = 0; l < 64; ++l) {
+                const int prow = (i >> 1) * 32 + 8 * (l >> 4) + ((l & 15) >> 2) + 4 * (i & 1);
+                const int rem = (t * 64 + prow) % hw, y = rem / g.W, x = rem % g.W;
+                if (y > 0) m[0] |= 1ULL << l;
+                if (y < g.H - 1) m[1] |= 1ULL << l;
+                if (x > 0) m[2] |= 1ULL << l;
+                if (x < g.W - 1) m[3] |= 1ULL << l;
+            }
+            for (int d = 0; d < 4; ++d) host[(t * 4 + i) * 4 + d] = m[d];
+        }
+    void* sym = nullptr;
+    if (hipGetSymbolAddress(&sym, HIP_SYMBOL(g_t9_masks)) != hipSuccess) return false;
+    unsigned long long* dev = reinterpret_cast<unsigned long long*>(sym) + (size_t)used * T9_TAB_MAXP * 16;
+    if (hipMemcpy(dev, host, sizeof(unsigned long long) * period * 16, hipMemcpyHostToDevice) != hipSuccess) { (void)hipGetLastError(); return false; }
+    cache[used].h = g.H; cache[used].w = g.W; cache[used].period = period; cache[used].dev = dev;
+    ++used;
+    g.mask_tab = dev; g.mask_period = period;
+    return true;
+}
+
+template <int WCO, int WCI, int COF, int CIF, bool XF = false, int NST = 2, int QROWS = T9_QROWS, bool TAB = false>
 static int tn_taps9_launch(const TnGeom& g, const void* p, const void* q, float* out, int splits, hipStream_t stream) {
     typedef T9Cfg<WCO, WCI, COF, CIF, NST, QROWS> Cfg;
     const int co_tiles = (g.Kc + Cfg::CO_T - 1) / Cfg::CO_T, ci_tiles = (g.C + 63) / 64;
-    auto kern = tn_taps9_kernel<WCO, WCI, COF, CIF, XF, NST, QROWS>;
+    auto kern = tn_taps9_kernel<WCO, WCI, COF, CIF, XF, NST, QROWS, TAB>;
     static bool attr_done = false;
     if (!attr_done) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -809,6 +884,7 @@ static int tn_run(int dtype, const void* p, const void* q, float* out, int n, in
     g.ksteps = (g.M + TN_KP - 1) / TN_KP;
     g.slab_stride = 0;
     g.xf_scale = xf_scale; g.xf_shift = xf_shift;
+    g.mask_tab = nullptr; g.mask_period = 0;
     if (xf_scale && !(t9_applicable(dtype, w, c, r, s, stride, pad, M, ldp) && (c % 64) == 0)) {
         set_error("%s: operand transform needs the nine-tap kernel (bf16 3x3 stride 1, c %% 64 == 0)", who);
         return FRHIP_EINVAL;
@@ -841,6 +917,10 @@ static int tn_run(int dtype, const void* p, const void* q, float* out, int n, in
         if (xf_scale) rc = wide ? tn_taps9_launch<2, 4, 4, 1, true>(g, p, q, dst, splits, stream)
                          : deep ? tn_taps9_launch<1, 4, 4, 1, true, 3, 128>(g, p, q, dst, splits, stream)
                                 : tn_taps9_launch<1, 4, 4, 1, true>(g, p, q, dst, splits, stream);
+        else if (!wide && g.Ho == g.H && g.Wo == g.W && t9_mask_table(g))
+            rc = deep4 ? tn_taps9_launch<1, 4, 4, 1, false, 4, 96, true>(g, p, q, dst, splits, stream)
+               : deep ? tn_taps9_launch<1, 4, 4, 1, false, 3, 128, true>(g, p, q, dst, splits, stream)
+                      : tn_taps9_launch<1, 4, 4, 1, false, 2, T9_QROWS, true>(g, p, q, dst, splits, stream);
         else rc = wide ? tn_taps9_launch<2, 4, 4, 1>(g, p, q, dst, splits, stream)
                 : deep4 ? tn_taps9_launch<1, 4, 4, 1, false, 4, 96>(g, p, q, dst, splits, stream)
                 : deep ? tn_taps9_launch<1, 4, 4, 1, false, 3, 128>(g, p, q, dst, splits, stream)
