@@ -22,7 +22,12 @@ _STEM_FUSED_REDUCE = os.environ.get("FRHIP_STEM_FUSED_REDUCE", "1") == "1"     #
 # 0: a1 = relu(bn1(y1)) is a pass of its own.  1: folded into conv2's forward AND weight-gradient kernels (a1 never exists).
 # 2: folded into the forward kernel only; the backward pass re-forms a1 with a BatchNorm-apply pass on the SIDE stream right in front
 #    of conv2's weight gradient, where it hides beside the main stream's matrix work (the forward pass has nothing to hide it under)
-_FUSE_BN1 = int(os.environ.get("FRHIP_FUSE_BN1", "0"))
+# 3 (default since the lean store epilogue, round 3): conv2's forward kernel forms a1 = relu(bn1(y1)) in LDS from y1 and writes it out on the
+# way -- no BatchNorm-apply launch for bn1 in the forward pass, bit-identical tensors (-0.23 ms per step, three alternating pairs of
+# 40-step runs on one box: 24.58 / 24.49 / 24.45 -> 24.28 / 24.31 / 24.21).  0: separate pass.  1 / 2: a1 never written (slower).
+# FRHIP_FUSE_BN1_CH: comma list of channel widths mode 3 applies to (default: all)
+_FUSE_BN1 = int(os.environ.get("FRHIP_FUSE_BN1", "3"))
+_FUSE_BN1_CH = [int(v) for v in os.environ.get("FRHIP_FUSE_BN1_CH", "").split(",") if v]
 # inference: eval-mode BatchNorms folded into the store epilogues of the convolutions (0: separate BatchNorm-apply passes)
 _EVAL_FOLD = os.environ.get("FRHIP_EVAL_FOLD", "1") == "1"
 # hand a weight gradient to the side stream BEFORE the data-gradient of the same dy is enqueued (the side stream waits for what
@@ -519,7 +524,7 @@ def basic_block_forward(blk, xin, dt, training, save, wprep=None, q8=None):
     if f1:
         a1, a18 = ops.bn_apply_q8(y1, st1, relu=True)
         y2, p2 = ops.conv_fwd_fp8(a18, *q8.packs[blk.conv2], blk.stride, 1, want_stats=training)
-    elif _FUSE_BN1 == 3 and ops.conv_bnrelu_fusable(y1, w2, blk.stride, 1):
+    elif _FUSE_BN1 == 3 and (not _FUSE_BN1_CH or y1.shape[3] in _FUSE_BN1_CH) and ops.conv_bnrelu_fusable(y1, w2, blk.stride, 1):
         # conv2 forms a1 = relu(bn1(y1)) in LDS from y1 and writes it out on the way (the backward pass reads it): no BatchNorm-apply
         # launch, no second read of y1, the backward pass unchanged
         a1 = torch.empty_like(y1) if save else None
