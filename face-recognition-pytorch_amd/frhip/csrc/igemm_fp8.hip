@@ -42,9 +42,23 @@ __global__ __launch_bounds__(256) void quant_w8_kernel(const float* __restrict__
     }
 }
 
+// Debug counter of saturated activations: pack4_fp8 clamps at +-448 without a trace, and the activation scale is a static
+// 1.0.  frhip_fp8_saturation(1) arms it: the activation quantisers then count the elements whose magnitude exceeds e4m3's range before
+// the clamp (one atomic per thread that saw any); production runs pass a null pointer and pay nothing.
+__device__ unsigned int g_fp8_sat_count;
+static unsigned int* g_fp8_sat_ptr = nullptr;
+template <int N> __device__ __forceinline__ void fp8_count_sat(unsigned int* sat, const float (&f)[N]) {
+    if (!sat) return;
+    int n = 0;
+#pragma unroll
+    for (int e = 0; e < N; ++e) n += fabsf(f[e]) > FP8_MAX ? 1 : 0;
+    if (n) atomicAdd(sat, (unsigned int)n);
+}
+
 // x8 = fp8(x * inv_scale), 16 elements per thread
 template <typename T>
-__global__ __launch_bounds__(256) void quant_act8_kernel(const T* __restrict__ x, uint8_t* __restrict__ x8, size_t n16, float inv_scale) {
+__global__ __launch_bounds__(256) void quant_act8_kernel(const T* __restrict__ x, uint8_t* __restrict__ x8, size_t n16, float inv_scale,
+                                                         unsigned int* __restrict__ sat) {
     constexpr int EPV = 16 / (int)sizeof(T), NV = 16 / EPV;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) {
         float f[16];
@@ -54,6 +68,7 @@ __global__ __launch_bounds__(256) void quant_act8_kernel(const T* __restrict__ x
 #pragma unroll
             for (int e = 0; e < EPV; ++e) f[v * EPV + e] = a.get(e) * inv_scale;
         }
+        fp8_count_sat(sat, f);
         u32x4_t o;
 #pragma unroll
         for (int q = 0; q < 4; ++q) o[q] = pack4_fp8(f[4 * q], f[4 * q + 1], f[4 * q + 2], f[4 * q + 3]);
@@ -67,7 +82,7 @@ __global__ __launch_bounds__(256) void bn_apply_q8_kernel(const T* __restrict__ 
                                                           const float* __restrict__ shift, const T* __restrict__ res,
                                                           const float* __restrict__ rscale, const float* __restrict__ rshift,
                                                           int relu, T* __restrict__ out, uint8_t* __restrict__ out8, float inv_q,
-                                                          int rows, int C) {
+                                                          int rows, int C, unsigned int* __restrict__ sat) {
     constexpr int EPV = 16 / (int)sizeof(T);
     const int vpr = C / EPV;
     const int cg = threadIdx.x % vpr, rl = threadIdx.x / vpr, rlanes = 256 / vpr;
@@ -92,6 +107,7 @@ __global__ __launch_bounds__(256) void bn_apply_q8_kernel(const T* __restrict__ 
             f[e] = a.get(e) * inv_q;                       // quantise the value as STORED in T
         }
         *reinterpret_cast<Vec16<T>*>(out + idx) = a;
+        fp8_count_sat(sat, f);
         uint32_t* o8 = reinterpret_cast<uint32_t*>(out8 + idx);
 #pragma unroll
         for (int q = 0; q < EPV / 4; ++q) o8[q] = pack4_fp8(f[4 * q], f[4 * q + 1], f[4 * q + 2], f[4 * q + 3]);
@@ -263,8 +279,8 @@ extern "C" int frhip_quant_fp8(int dtype, const void* x, void* x8, size_t n, flo
     if (n % 16) { set_error("frhip_quant_fp8: n must be a multiple of 16"); return FRHIP_EINVAL; }
     const size_t n16 = n / 16;
     const unsigned grid = (unsigned)((n16 + 255) / 256 > 65536 ? 65536 : (n16 + 255) / 256);
-    if (dtype == FRHIP_DT_BF16) hipLaunchKernelGGL(quant_act8_kernel<bf16_t>, dim3(grid), dim3(256), 0, stream, (const bf16_t*)x, (uint8_t*)x8, n16, inv_scale);
-    else if (dtype == FRHIP_DT_F32) hipLaunchKernelGGL(quant_act8_kernel<float>, dim3(grid), dim3(256), 0, stream, (const float*)x, (uint8_t*)x8, n16, inv_scale);
+    if (dtype == FRHIP_DT_BF16) hipLaunchKernelGGL(quant_act8_kernel<bf16_t>, dim3(grid), dim3(256), 0, stream, (const bf16_t*)x, (uint8_t*)x8, n16, inv_scale, g_fp8_sat_ptr);
+    else if (dtype == FRHIP_DT_F32) hipLaunchKernelGGL(quant_act8_kernel<float>, dim3(grid), dim3(256), 0, stream, (const float*)x, (uint8_t*)x8, n16, inv_scale, g_fp8_sat_ptr);
     else { set_error("frhip_quant_fp8: bad dtype %d", dtype); return FRHIP_EINVAL; }
     return check_launch("frhip_quant_fp8");
 }
@@ -281,8 +297,23 @@ extern "C" int frhip_bn_apply_q8(int dtype, const void* y, const float* scale, c
     int grid = (rows + rlanes * 16 - 1) / (rlanes * 16);
     grid = grid < 1 ? 1 : (grid > 16384 ? 16384 : grid);
     hipLaunchKernelGGL(bn_apply_q8_kernel<bf16_t>, dim3(grid), dim3(256), 0, stream, (const bf16_t*)y, scale, shift, (const bf16_t*)res,
-                       res_scale, res_shift, relu, (bf16_t*)out, (uint8_t*)out8, inv_q, rows, c);
+                       res_scale, res_shift, relu, (bf16_t*)out, (uint8_t*)out8, inv_q, rows, c, g_fp8_sat_ptr);
     return check_launch("frhip_bn_apply_q8");
+}
+
+extern "C" int frhip_fp8_saturation(int op) {
+    // op 1: zero the counter and arm it; op 0: disarm; op 2: read it (device-synchronising copy).  Returns the count (op 2, capped at INT_MAX), 0, or < 0
+    void* sym = nullptr;
+    if (hipGetSymbolAddress(&sym, HIP_SYMBOL(frhip::g_fp8_sat_count)) != hipSuccess) { set_error("frhip_fp8_saturation: no counter symbol"); return FRHIP_ELAUNCH; }
+    unsigned int v = 0;
+    if (op == 1) {
+        if (hipMemcpy(sym, &v, sizeof(v), hipMemcpyHostToDevice) != hipSuccess) return FRHIP_ELAUNCH;
+        frhip::g_fp8_sat_ptr = reinterpret_cast<unsigned int*>(sym);
+        return 0;
+    }
+    if (op == 0) { frhip::g_fp8_sat_ptr = nullptr; return 0; }
+    if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(&v, sym, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return FRHIP_ELAUNCH;
+    return v > 0x7fffffffu ? 0x7fffffff : (int)v;
 }
 
 extern "C" int frhip_conv_fwd_fp8(const void* x8, const void* w8, const float* wscale, float act_scale, void* y,

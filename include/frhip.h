@@ -264,6 +264,10 @@ int frhip_conv_wgrad_bnrelu(int dtype, const void* dy, const void* x, const floa
  * e4m3 on v_mfma_scale_f32_16x16x128_f8f6f4; bf16 output = fp32 accumulator x act_scale x w_scale[k] ---- */
 /* w [k][rowlen] fp32 (a conv weight in its physical [K][R][S][C] order) -> w8 fp8 + scale[k] = amax(row) / 448 */
 int frhip_quant_fp8_weights(const float* w, void* w8, float* scale, int k, int rowlen, frhip_stream_t stream);
+/* debug counter of SATURATED activations in the fp8 quantisers (frhip_quant_fp8, frhip_bn_apply_q8 clamp at +-448 silently; the
+ * activation scale is static): op 1 zeroes and arms it, op 0 disarms, op 2 returns the number of elements that exceeded e4m3's range
+ * since it was armed (synchronises the device; capped at INT_MAX).  Process-global test hook, outside the threading contract */
+int frhip_fp8_saturation(int op);
 /* x8 = fp8(x * inv_scale), n % 16 == 0 */
 int frhip_quant_fp8(int dtype, const void* x, void* x8, size_t n, float inv_scale, frhip_stream_t stream);
 /* frhip_bn_apply that also writes the fp8 copy out8 = fp8(out * inv_q) the next fp8 GEMM reads (bf16 tensors) */

@@ -119,18 +119,43 @@ def _alternet(fp8):
     return A.AlterNet50(conf).cuda()
 
 
+def test_fp8_saturation_counter_counts_clamped_activations():
+    """frhip_fp8_saturation: the activation quantisers clamp at +-448 silently; armed, they count what they clamp."""
+    from frhip import ops
+    from frhip._abi import lib
+    x = torch.zeros(4096, dtype=torch.bfloat16, device="cuda")
+    x[5], x[77], x[4000] = 500.0, -1000.0, 448.0            # two beyond the range, one exactly on it
+    assert lib().frhip_fp8_saturation(1) == 0
+    try:
+        ops.quant_fp8(x)
+        assert lib().frhip_fp8_saturation(2) == 2
+    finally:
+        lib().frhip_fp8_saturation(0)
+    ops.quant_fp8(x)                                        # disarmed: nothing counted, nothing read
+    assert lib().frhip_fp8_saturation(2) == 2
+
+
 def test_alternet50_fp8_eval_vs_bf16_and_reference(golden, pg):
     from oracle import alternet_ref
     g = golden("alternet50_b2_eval")
     spec = alternet_ref.alter_spec("AlterNet50")
     sd = alternet_ref.fill_special(recipe.fill_state(spec, 7300), spec)       # the state the reference fixture was generated with
     outs = {}
+    from frhip._abi import lib
     for fp8 in (False, True):
         net = _alternet(fp8)
         net.load_state_dict(sd, strict=True)
         net = net.cuda().eval()
-        with torch.no_grad():
-            outs[fp8] = net(recipe.images(7301, 2, 192, 192).cuda()).float().cpu()
+        if fp8:
+            assert lib().frhip_fp8_saturation(1) == 0        # arm the debug counter of clamped activations (ADVICE r02)
+        try:
+            with torch.no_grad():
+                outs[fp8] = net(recipe.images(7301, 2, 192, 192).cuda()).float().cpu()
+            if fp8:
+                # static activation scale 1.0: no activation of the whole network may reach e4m3's +-448 (the clamp is silent)
+                assert lib().frhip_fp8_saturation(2) == 0
+        finally:
+            lib().frhip_fp8_saturation(0)
     ref = torch.from_numpy(g["out"])
     for name, a, b in (("fp8 vs bf16", outs[True], outs[False]), ("fp8 vs reference", outs[True], ref)):
         cos = torch.nn.functional.cosine_similarity(a, b, dim=1)
