@@ -102,28 +102,66 @@ def _id(t):
     return t
 
 
-def basic_block(sd, p, x, stride, has_ds, training, q=_id):
-    y = q(F.conv2d(x, q(sd[p + ".conv1.weight"]), None, 1, 1))
+FP8_MAX = 448.0
+
+
+def fp8_e4m3(t):
+    """value of t after a round trip through OCP e4m3 (clamped at +-448 like the kernels' packer)"""
+    return t.clamp(-FP8_MAX, FP8_MAX).to(torch.float8_e4m3fn).float()
+
+
+class _Fp8FwdConv(torch.autograd.Function):
+    """Emulation of the fp8 WEIGHT path of the build (cfg 5) -- test infrastructure, plain PyTorch CPU ops: the forward
+    convolution multiplies e4m3 operands (activations under the static scale 1.0, weights under one scale per output channel =
+    amax / 448), the backward pass is the unquantised one (the build's backward kernels read the bf16 tensors)."""
+
+    @staticmethod
+    def forward(ctx, x, w, stride, pad):
+        ctx.save_for_backward(x, w)
+        ctx.sp = (stride, pad)
+        sc = w.abs().amax(dim=(1, 2, 3), keepdim=True) / FP8_MAX
+        sc = torch.where(sc > 0, sc, torch.ones_like(sc))
+        return F.conv2d(fp8_e4m3(x), fp8_e4m3(w / sc) * sc, None, stride, pad)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        stride, pad = ctx.sp
+        gx = torch.nn.grad.conv2d_input(x.shape, w, g, stride=stride, padding=pad)
+        gw = torch.nn.grad.conv2d_weight(x, w.shape, g, stride=stride, padding=pad)
+        return gx, gw, None, None
+
+
+def _conv(x, w, stride, pad, fp8):
+    """fp8: the build's eligibility rule (input width a multiple of 128: one K step of the fp8 kernels)"""
+    if fp8 and x.shape[1] % 128 == 0:
+        return _Fp8FwdConv.apply(x, w, stride, pad)
+    return F.conv2d(x, w, None, stride, pad)
+
+
+def basic_block(sd, p, x, stride, has_ds, training, q=_id, fp8=False):
+    y = q(_conv(x, q(sd[p + ".conv1.weight"]), 1, 1, fp8))
     y = q(F.relu(_bn(sd, p + ".bn1", y, training)))
-    y = q(F.conv2d(y, q(sd[p + ".conv2.weight"]), None, stride, 1))
+    y = q(_conv(y, q(sd[p + ".conv2.weight"]), stride, 1, fp8))
     y = _bn(sd, p + ".bn2", y, training)
     if has_ds:
-        r = q(F.conv2d(x, q(sd[p + ".downsample.0.weight"]), None, stride, 0))
+        r = q(_conv(x, q(sd[p + ".downsample.0.weight"]), stride, 0, fp8))
         r = _bn(sd, p + ".downsample.1", r, training)
     else:
         r = x
     return q(y + r)
 
 
-def resnet_forward(sd, x, blocks, training, emd_size=512, q=_id):
+def resnet_forward(sd, x, blocks, training, emd_size=512, q=_id, fp8=False):
     """x float32 [B,3,H,W] -> [B, emd_size]; running stats in `sd` updated in place when training.
     q: storage cast applied where a mixed-precision implementation keeps a tensor (conv outputs, activation outputs, block
-    outputs, weights as GEMM operands); identity = the reference's fp32 arithmetic."""
+    outputs, weights as GEMM operands); identity = the reference's fp32 arithmetic.
+    fp8: emulate the build's fp8 forward weight path in the body convolutions with >= 128 input channels (_Fp8FwdConv)."""
     y = F.conv2d(q(x), q(sd["conv1.weight"]), None, 1, 1)
     y = F.relu(_bn(sd, "bn1", y, training))
     y = q(F.max_pool2d(y, 3, 2, 1))
     for si, bi, cin, cout, s, ds in stage_plan(blocks, emd_size):
-        y = basic_block(sd, "layer%d.%d" % (si, bi), y, s, ds, training, q)
+        y = basic_block(sd, "layer%d.%d" % (si, bi), y, s, ds, training, q, fp8)
     y = q(_bn(sd, "bn2", y, training))
     y = y.reshape(y.shape[0], -1)
     y = F.linear(y, q(sd["fc.weight"]), sd["fc.bias"])
