@@ -38,6 +38,49 @@ __global__ __launch_bounds__(256) void l2norm_rows_kernel(const float* __restric
     }
 }
 
+// D == 512 (the embedding width of every configuration): a lane owns eight consecutive elements of its row -- 16-byte loads and stores,
+// the row read ONCE and kept in registers, the row sum by DPP / permlane (no LDS permutes).  The generic kernels above / below issue
+// 4- and 2-byte accesses and read the row twice (156 us for the 122 000 x 512 classifier in the backward pass).
+__device__ __forceinline__ float wave_sum(float x) { return lane_sum_bit5(lane_sum_bit4(lane_sum_row16(x))); }
+
+__global__ __launch_bounds__(256) void l2norm_rows512_kernel(const float* __restrict__ x, bf16_t* __restrict__ xhat,
+                                                             float* __restrict__ norms, int rows, float eps) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const float* xr = x + (size_t)row * 512 + lane * 8;
+    const f32x4_t a = *reinterpret_cast<const f32x4_t*>(xr), b = *reinterpret_cast<const f32x4_t*>(xr + 4);
+    float ss = a[0] * a[0] + a[1] * a[1] + a[2] * a[2] + a[3] * a[3] + b[0] * b[0] + b[1] * b[1] + b[2] * b[2] + b[3] * b[3];
+    ss = wave_sum(ss);
+    const float nrm = fmaxf(sqrtf(ss), eps), inv = 1.f / nrm;
+    if (lane == 0) norms[row] = nrm;
+    bf16x8_t o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { o[e] = (bf16_t)(a[e] * inv); o[4 + e] = (bf16_t)(b[e] * inv); }
+    *reinterpret_cast<bf16x8_t*>(xhat + (size_t)row * 512 + lane * 8) = o;
+}
+
+__global__ __launch_bounds__(256) void l2norm_bwd512_kernel(const float* __restrict__ dxhat, const bf16_t* __restrict__ xhat,
+                                                            const float* __restrict__ norms, float* __restrict__ dx, int rows,
+                                                            float out_scale) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const size_t off = (size_t)row * 512 + lane * 8;
+    const f32x4_t a = *reinterpret_cast<const f32x4_t*>(dxhat + off), b = *reinterpret_cast<const f32x4_t*>(dxhat + off + 4);
+    const bf16x8_t h = *reinterpret_cast<const bf16x8_t*>(xhat + off);
+    float hv[8], dot = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) hv[e] = (float)h[e];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) dot += a[e] * hv[e] + b[e] * hv[4 + e];
+    dot = wave_sum(dot);
+    const float inv = out_scale / norms[row];
+    f32x4_t oa, ob;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { oa[e] = (a[e] - hv[e] * dot) * inv; ob[e] = (b[e] - hv[4 + e] * dot) * inv; }
+    *reinterpret_cast<f32x4_t*>(dx + off) = oa;
+    *reinterpret_cast<f32x4_t*>(dx + off + 4) = ob;
+}
+
 // dx = (dxhat - xhat * <dxhat, xhat>) / norm     (all fp32 except xhat which is T)
 template <typename T>
 __global__ __launch_bounds__(256) void l2norm_bwd_kernel(const float* __restrict__ dxhat, const T* __restrict__ xhat,
@@ -301,7 +344,8 @@ using namespace frhip;
 extern "C" int frhip_l2norm_rows(int dtype, const float* x, void* xhat, float* norms, int rows, int d, float eps,
                                  hipStream_t stream) {
     if (d % 4) { set_error("frhip_l2norm_rows: d must be a multiple of 4"); return FRHIP_EINVAL; }
-    if (dtype == FRHIP_DT_BF16) hipLaunchKernelGGL(l2norm_rows_kernel<bf16_t>, dim3((rows + 3) / 4), dim3(256), 0, stream, x, (bf16_t*)xhat, norms, rows, d, eps);
+    if (dtype == FRHIP_DT_BF16 && d == 512) hipLaunchKernelGGL(l2norm_rows512_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, x, (bf16_t*)xhat, norms, rows, eps);
+    else if (dtype == FRHIP_DT_BF16) hipLaunchKernelGGL(l2norm_rows_kernel<bf16_t>, dim3((rows + 3) / 4), dim3(256), 0, stream, x, (bf16_t*)xhat, norms, rows, d, eps);
     else if (dtype == FRHIP_DT_F32) hipLaunchKernelGGL(l2norm_rows_kernel<float>, dim3((rows + 3) / 4), dim3(256), 0, stream, x, (float*)xhat, norms, rows, d, eps);
     else { set_error("frhip_l2norm_rows: bad dtype %d", dtype); return FRHIP_EINVAL; }
     return check_launch("frhip_l2norm_rows");
@@ -309,7 +353,8 @@ extern "C" int frhip_l2norm_rows(int dtype, const float* x, void* xhat, float* n
 
 extern "C" int frhip_l2norm_bwd(int dtype, const float* dxhat, const void* xhat, const float* norms, float* dx,
                                 int rows, int d, float out_scale, hipStream_t stream) {
-    if (dtype == FRHIP_DT_BF16) hipLaunchKernelGGL(l2norm_bwd_kernel<bf16_t>, dim3((rows + 3) / 4), dim3(256), 0, stream, dxhat, (const bf16_t*)xhat, norms, dx, rows, d, out_scale);
+    if (dtype == FRHIP_DT_BF16 && d == 512) hipLaunchKernelGGL(l2norm_bwd512_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, dxhat, (const bf16_t*)xhat, norms, dx, rows, out_scale);
+    else if (dtype == FRHIP_DT_BF16) hipLaunchKernelGGL(l2norm_bwd_kernel<bf16_t>, dim3((rows + 3) / 4), dim3(256), 0, stream, dxhat, (const bf16_t*)xhat, norms, dx, rows, d, out_scale);
     else if (dtype == FRHIP_DT_F32) hipLaunchKernelGGL(l2norm_bwd_kernel<float>, dim3((rows + 3) / 4), dim3(256), 0, stream, dxhat, (const float*)xhat, norms, dx, rows, d, out_scale);
     else { set_error("frhip_l2norm_bwd: bad dtype %d", dtype); return FRHIP_EINVAL; }
     return check_launch("frhip_l2norm_bwd");

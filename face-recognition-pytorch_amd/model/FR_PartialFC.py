@@ -17,6 +17,8 @@ import torch
 from torch import nn
 from torch.nn.parallel import DistributedDataParallel as DDP
 
+import nets._backbone as _bb
+
 
 class _NormalizeFn(torch.autograd.Function):
     """F.normalize(x) rows (model/FR_PartialFC.py:171) on the HIP kernels."""
@@ -105,6 +107,10 @@ class Model(nn.Module):
             # group may be updated as soon as its gradient exists, beside the backbone's backward pass
             self.loss.arm_early_update(self.opt)
         loss.backward()
+        # an early head update the backbone's backward pass did not get to launch (the hook fired behind it): launch it now, so that
+        # nothing parked survives into the next step
+        while _bb.DEFERRED_SIDE:
+            _bb.DEFERRED_SIDE.pop(0)()
         if hasattr(self.opt, "last_grad_norm"):          # frhip.optim.SGD: the clip rides inside the fused update
             self.opt.step(clip=(self.encoder.parameters(), 5))
         else:

@@ -536,8 +536,15 @@ class _PartialFCBase(torch.nn.Module):
                 return
             if opt.param_groups[-1]["params"][0] is not param or torch.cuda.is_current_stream_capturing():
                 return
-            from ._backbone import side_stream
-            opt.step_group_early(len(opt.param_groups) - 1, side_stream(param.device))
+            from . import _backbone as bb
+
+            def launch():
+                opt.step_group_early(len(opt.param_groups) - 1, bb.side_stream(param.device))
+            if bb.DEFER_EARLY_BLOCKS >= 0:
+                del bb.DEFERRED_SIDE[:]            # at most one parked update (a stale one belongs to a backward pass that never ran)
+                bb.DEFERRED_SIDE.append(launch)    # the backbone's backward pass launches it a few blocks in (or its join() does)
+            else:
+                launch()
 
         p._frhip_early_hook = p.register_post_accumulate_grad_hook(hook)
 

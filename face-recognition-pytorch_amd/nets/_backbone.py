@@ -215,6 +215,14 @@ def side_stream(device):
     return _SIDE_STREAMS[key]
 
 
+# Side-stream work that does not belong to the backbone but should run UNDER its backward pass, at a point the backbone chooses: the
+# PartialFC head parks its early parameter update here (1.25 GB of HBM traffic at 122 000 classes).  Launched right away it collides with
+# the backbone's tail -- a chain of a dozen small, latency-bound kernels (bn3 / fc / bn2 backward) whose every load then queues behind a
+# saturated memory system; a few blocks later the main stream runs MFMA-bound 512-channel convolutions that do not mind.
+DEFERRED_SIDE = []
+DEFER_EARLY_BLOCKS = int(os.environ.get("FRHIP_EARLY_HEAD_DEFER", "2"))      # blocks of the backward pass to let go by (-1: launch at once)
+
+
 class BackwardCtx:
     """Gradient arena + the side stream on which weight gradients run + (data parallel) the gradient all-reduce.
 
@@ -294,7 +302,13 @@ class BackwardCtx:
             self._reduce(lo, self.reduced_from)
             self.reduced_from = lo
 
+    def run_deferred(self):
+        """launch the side-stream work other modules parked for the backward pass (DEFERRED_SIDE: the head's early parameter update)"""
+        while DEFERRED_SIDE:
+            DEFERRED_SIDE.pop(0)()
+
     def join(self):
+        self.run_deferred()
         for fn in self.before_join:
             fn()
         self.before_join = []

@@ -18,7 +18,7 @@ There is no CPU / eager fallback: without libfrhip.so or without a GPU tensor, f
 import torch
 import torch.nn as nn
 
-from ._backbone import (BackwardCtx, BasicBlock, Fp8Ctx, Saved, _BN, _Conv, _Linear, basic_block_backward,
+from ._backbone import (BackwardCtx, BasicBlock, DEFER_EARLY_BLOCKS, Fp8Ctx, Saved, _BN, _Conv, _Linear, basic_block_backward,
                         basic_block_forward, compute_dtype, encoder_call, prepare_conv_weights, stem_backward,
                         stem_forward, stem_reduction_operands,
                         tail_backward, tail_forward, use_fp8)
@@ -98,6 +98,8 @@ class ResNet(nn.Module):
             res = basic_block_backward(blocks[i], sv.blocks[i], dout, self.dtype, bc, part2=part, next_bn=nxt)
             dout, part = res if nxt is not None else (res, None)
             bc.reduce_down_to(blocks[i].conv1.weight)      # data parallel: block i and everything behind it is final
+            if len(blocks) - 1 - i == DEFER_EARLY_BLOCKS:
+                bc.run_deferred()                          # the head's early parameter update: beside MFMA-bound blocks, not beside the tail
         stem_backward(self, sv, dout, bc, part)
         return bc.join()
 
