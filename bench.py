@@ -185,7 +185,7 @@ def csrc_digest():
     h = hashlib.sha1()
     d = os.path.join(PKG, "frhip", "csrc")
     for f in sorted(os.listdir(d)):
-        if f.startswith("igemm_"):
+        if f.startswith(("igemm_halo", "igemm_nt", "common")):       # the forward / data-gradient conv kernels and what they include
             h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:16]
 

@@ -664,7 +664,7 @@ static int g_t9_lds_pad = getenv("FRHIP_T9_LDS_PAD") ? atoi(getenv("FRHIP_T9_LDS
 constexpr int T9_TAB_GEOMS = 8, T9_TAB_MAXP = 64;
 __device__ unsigned long long g_t9_masks[T9_TAB_GEOMS][T9_TAB_MAXP * 16];
 static int g_t9_tab = getenv("FRHIP_T9_MASK_TABLE") ? atoi(getenv("FRHIP_T9_MASK_TABLE")) : 1;
-static bool t9_mask_table(TnGeom& g) {
+static bool t9_mask_table(TnGeom& g, hipStream_t stream) {
     static struct { int h, w, period; const unsigned long long* dev; } cache[T9_TAB_GEOMS];
     static int used = 0;
     g.mask_tab = nullptr; g.mask_period = 0;
@@ -676,6 +676,11 @@ static bool t9_mask_table(TnGeom& g) {
     while (b) { const int t = a % b; a = b; b = t; }
     const int period = hw / a;
     if (period > T9_TAB_MAXP || used == T9_TAB_GEOMS) return false;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) {     // no blocking copy inside a capture:
+        (void)hipGetLastError();                                                                  // this launch takes the VALU predicates
+        return false;
+    }
     static unsigned long long host[T9_TAB_MAXP * 16];
     for (int t = 0; t < period; ++t)
         for (int i = 0; i < 4; ++i) {
@@ -917,7 +922,7 @@ static int tn_run(int dtype, const void* p, const void* q, float* out, int n, in
         if (xf_scale) rc = wide ? tn_taps9_launch<2, 4, 4, 1, true>(g, p, q, dst, splits, stream)
                          : deep ? tn_taps9_launch<1, 4, 4, 1, true, 3, 128>(g, p, q, dst, splits, stream)
                                 : tn_taps9_launch<1, 4, 4, 1, true>(g, p, q, dst, splits, stream);
-        else if (!wide && g.Ho == g.H && g.Wo == g.W && t9_mask_table(g))
+        else if (!wide && g.Ho == g.H && g.Wo == g.W && t9_mask_table(g, stream))
             rc = deep4 ? tn_taps9_launch<1, 4, 4, 1, false, 4, 96, true>(g, p, q, dst, splits, stream)
                : deep ? tn_taps9_launch<1, 4, 4, 1, false, 3, 128, true>(g, p, q, dst, splits, stream)
                       : tn_taps9_launch<1, 4, 4, 1, false, 2, T9_QROWS, true>(g, p, q, dst, splits, stream);
