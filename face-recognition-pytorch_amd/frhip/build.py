@@ -8,7 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 ROOT = os.path.dirname(os.path.dirname(HERE))
 LIB = os.path.join(HERE, "libfrhip.so")
-SOURCES = ["misc.hip", "bn.hip", "stem.hip", "stem_fused.hip", "stem_algebra.hip", "igemm_nt.hip", "igemm_halo.hip", "igemm_tn.hip", "igemm_fp8.hip", "mlp_recompute.hip", "head.hip", "pfc_sample.hip", "margin.hip", "winattn.hip", "winattn_mfma.hip", "cpb.hip", "optim.hip", "augment.hip"]
+SOURCES = ["misc.hip", "bn.hip", "stem.hip", "stem_fused.hip", "stem_algebra.hip", "igemm_nt.hip", "igemm_halo.hip", "igemm_tn.hip", "igemm_fp8.hip", "head.hip", "pfc_sample.hip", "margin.hip", "winattn.hip", "winattn_mfma.hip", "cpb.hip", "optim.hip", "augment.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-munsafe-fp-atomics",
          "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]

@@ -218,33 +218,6 @@ def linear_dgrad_gelu(dy, wt, pre, want_colsum=True):
     return dx, (part[:, 0].sum(0) if want_colsum else None)
 
 
-def mlp_recompute_ok(a, w):
-    """can the fc1 -> GELU -> fc2 pair run without its hidden pre-activation in HBM (linear_fwd_act / linear_dgrad_gelu_rc)?"""
-    return a.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and a.shape[1] % 64 == 0 and w.shape[0] % 8 == 0
-
-
-def linear_fwd_act(a, w, bias):
-    """act = gelu(a [M,K] @ w [N,K]^T + bias): linear_fwd(want_act=True) without its pre-activation output"""
-    m, k = a.shape
-    n = w.shape[0]
-    assert w.shape[1] == k and a.dtype == w.dtype
-    act = torch.empty((m, n), dtype=a.dtype, device=a.device)
-    check(lib().frhip_linear_fwd_act(dt_of(a), _p(a), _p(w), _p(bias), _p(act), m, n, k, _s()), "frhip_linear_fwd_act")
-    return act
-
-
-def linear_dgrad_gelu_rc(dy, wt, x, w1, bias1):
-    """linear_dgrad_gelu with the pre-activation RECOMPUTED from x [M,K], w1 [N,K], bias1 [N] instead of read: (dx, colsum)"""
-    m, k = dy.shape
-    n = wt.shape[0]
-    assert tuple(x.shape) == (m, k) and tuple(w1.shape) == (n, k) and x.dtype == dy.dtype == wt.dtype == w1.dtype
-    dx = torch.empty((m, n), dtype=dy.dtype, device=dy.device)
-    part = torch.empty((lib().frhip_mlp_stat_rows(m), 2, n), dtype=torch.float32, device=dy.device)
-    check(lib().frhip_linear_dgrad_gelu_rc(dt_of(dy), _p(dy), _p(wt), _p(x), _p(w1), _p(bias1), _p(dx), _p(part), m, n, k, _s()),
-          "frhip_linear_dgrad_gelu_rc")
-    return dx, part[:, 0].sum(0)
-
-
 def gemm_tn(p, q, out, kc=None, splits=0, overwrite=False):
     """out[kc][c] fp32 += sum_m p[m][:kc] * q[m][:c]      (overwrite: out = ..., out need not be initialised)"""
     m, ldp = p.shape

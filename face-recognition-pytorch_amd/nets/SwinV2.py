@@ -94,11 +94,6 @@ class SwinTransformerBlock(nn.Module):
 
 
 # ------------------------------------------------------------------------------------------------- block math
-# the MLP without its hidden pre-activation in HBM: fc1 writes gelu(hid) only, fc2's data-gradient recomputes hid from the block input
-# (csrc/mlp_recompute.hip; bit-identical; FRHIP_MLP_RECOMPUTE=0: both tensors kept)
-MLP_RECOMPUTE = os.environ.get("FRHIP_MLP_RECOMPUTE", "1") == "1"
-MLP_RECOMPUTE_MAXC = int(os.environ.get("FRHIP_MLP_RECOMPUTE_MAXC", "128"))    # block widths it is used for (kernel timings: tools/bench_mlp.py)
-
 def _w2d(conv_or_lin, dt):
     w = conv_or_lin.weight.data
     return ops.cast_from_f32(w.reshape(w.shape[0], -1).contiguous(), dt)
@@ -282,11 +277,7 @@ def swin_block_forward(blk, x, dt, training, save, wprep=None):
     st2 = bn_forward_state(blk.norm2, part2, m, training)
     x1 = ops.bn_apply(po, st2, res=x2)
     w1, w1_t = _lin_operands(blk.mlp.fc1, dt, wprep)
-    if MLP_RECOMPUTE and save and c <= MLP_RECOMPUTE_MAXC and ops.mlp_recompute_ok(x1, w1):
-        # the pre-activation is never written: fc2's data-gradient recomputes its tile from x1 (frhip_linear_dgrad_gelu_rc)
-        hid, act = None, ops.linear_fwd_act(x1, w1, blk.mlp.fc1.bias.data)
-    else:
-        hid, act, _ = ops.linear_fwd(x1, w1, blk.mlp.fc1.bias.data, want_act=True)      # bias + GELU, both tensors kept
+    hid, act, _ = ops.linear_fwd(x1, w1, blk.mlp.fc1.bias.data, want_act=True)          # bias + GELU, both tensors kept
     w2, w2_t = _lin_operands(blk.mlp.fc2, dt, wprep)
     mo, _, part3 = ops.linear_fwd(act, w2, blk.mlp.fc2.bias.data, want_stats=training)
     st3 = bn_forward_state(blk.norm3, part3, m, training)
@@ -331,10 +322,7 @@ def swin_block_backward(blk, s, dout, dt, bc, next_bn=None, part3=None):
     # * sum xhat) = 0); the reference gets 1e-8-sized round-off there.  Left at the arena's zero: no reduction pass.
     bc.on_side(lambda: ops.gemm_tn(dmo, s.act, G(blk.mlp.fc2.weight).view(c, 4 * c)), dmo, s.act)
     # [M, 4C]: fc2's data-gradient with gelu'(hid) and fc1.bias's gradient (column sums) fused into its epilogue
-    if s.hid is None:
-        dhid, db1 = ops.linear_dgrad_gelu_rc(dmo, _transposed(s.w2, s.w2_t), s.x1, s.w1, blk.mlp.fc1.bias.data)
-    else:
-        dhid, db1 = ops.linear_dgrad_gelu(dmo, _transposed(s.w2, s.w2_t), s.hid)
+    dhid, db1 = ops.linear_dgrad_gelu(dmo, _transposed(s.w2, s.w2_t), s.hid)
     G(blk.mlp.fc1.bias).add_(db1)
     bc.on_side(lambda: ops.gemm_tn(dhid, s.x1, G(blk.mlp.fc1.weight).view(4 * c, c)), dhid, s.x1)
     # dx1 is the upstream gradient of norm2: its backward reduction over (dx1, po) rides in this data-gradient's epilogue

@@ -121,16 +121,6 @@ int frhip_linear_fwd(int dtype, const void* a, const void* w, const float* bias,
  * the column sums of dx = the gradient of fc1.bias */
 int frhip_linear_dgrad_gelu(int dtype, const void* dy, const void* wt, const void* pre, void* dx, float* stats_partial,
                             int m, int n, int k, frhip_stream_t stream);
-/* The MLP of a Swin / AlterNet block (nets/SwinV2.py:16-32: fc1 -> GELU -> fc2) WITHOUT its hidden pre-activation in HBM (bf16; k % 64 == 0):
- * frhip_linear_fwd_act writes act = gelu(a w^T + bias) only; frhip_linear_dgrad_gelu_rc forms fc2's data-gradient and multiplies it by
- * gelu'(hid) with the hid tile RECOMPUTED from the block input x (hid = x w1^T + bias1: one more K = C GEMM through the same LDS stages)
- * -- act, dx and the column sums are those of frhip_linear_fwd / frhip_linear_dgrad_gelu bit for bit (same roundings);
- * stats_partial [frhip_mlp_stat_rows(m)][2][n]: row 0 of each tile sums to the column sums of dx = fc1.bias's gradient */
-int frhip_mlp_stat_rows(int m);
-int frhip_linear_fwd_act(int dtype, const void* a, const void* w, const float* bias, void* act_out, int m, int n, int k,
-                         frhip_stream_t stream);
-int frhip_linear_dgrad_gelu_rc(int dtype, const void* dy, const void* wt, const void* x, const void* w1, const float* bias1, void* dx,
-                               float* stats_partial, int m, int n, int k, frhip_stream_t stream);
 /* out[m][n] = sum_k a[m][k]*b[n][k].  atomic_f32 = 0: out has `dtype`, overwritten (splits ignored);
  * atomic_f32 = 1: out is fp32, caller-zeroed, K is split `splits` ways and added atomically.  nn.Linear: nets/resnet.py:244 */
 int frhip_gemm_nt(int dtype, const void* a, const void* b, void* out, int m, int n, int k, int splits,

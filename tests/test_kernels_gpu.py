@@ -341,30 +341,6 @@ def test_linear_dgrad_gelu_fused(dtype, mnk):
     np.testing.assert_allclose(colsum.cpu().numpy(), want, rtol=1e-4, atol=1e-4 * np.abs(dx.float().cpu().numpy()).sum(0).max())
 
 
-@pytest.mark.parametrize("mnk", [(3136, 256, 64), (1000, 512, 128), (392, 1024, 256), (130, 2048, 512)])
-def test_mlp_without_the_hidden_preactivation_is_bit_identical(mnk):
-    """csrc/mlp_recompute.hip (reference nets/SwinV2.py:16-32, fc1 -> GELU -> fc2): frhip_linear_fwd_act = the act output of
-    frhip_linear_fwd; frhip_linear_dgrad_gelu_rc, which recomputes the pre-activation tile from the block input, = frhip_linear_dgrad_gelu
-    on the stored pre-activation -- bit for bit (same roundings), ragged row and column tiles included; the column sums (fc1.bias's
-    gradient) to fp32 summation order."""
-    ops = _ops()
-    m, n, k = mnk                      # tokens, hidden width, block width
-    dt = torch.bfloat16
-    x = rnd(80, (m, k)).to(dt).cuda()
-    w1 = (rnd(81, (n, k)) * 0.1).to(dt).cuda()
-    b1 = (rnd(82, (n,)) * 0.2).cuda()
-    dy = rnd(83, (m, k)).to(dt).cuda()
-    w2t = (rnd(84, (n, k)) * 0.1).to(dt).cuda()          # fc2's weight, transposed: [hidden][block width]
-    assert ops.mlp_recompute_ok(x, w1)
-    hid, act, _ = ops.linear_fwd(x, w1, b1, want_act=True)
-    act2 = ops.linear_fwd_act(x, w1, b1)
-    assert torch.equal(act, act2)
-    dh, db = ops.linear_dgrad_gelu(dy, w2t, hid)
-    dh2, db2 = ops.linear_dgrad_gelu_rc(dy, w2t, x, w1, b1)
-    assert torch.equal(dh, dh2)
-    np.testing.assert_allclose(db2.cpu().numpy(), db.cpu().numpy(), rtol=1e-4, atol=1e-4 * float(db.abs().max()))
-
-
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("shape", [(96, 200, 208, 64), (1000, 128, 128, 512), (70, 24, 24, 32)])
 def test_gemm_tn(dtype, shape):
