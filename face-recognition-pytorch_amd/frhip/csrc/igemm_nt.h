@@ -546,6 +546,96 @@ __device__ __forceinline__ void nt_epilogue_store_fast(const char* mine, int P, 
     }
 }
 
+// Lean store epilogue of the LINEAR layers (nets/SwinV2.py qkv / proj / fc1 / fc2 and their data-gradients on the 256 x 256 tile: K = 256 ...
+// 2048, where the general epilogue's ~2 000 VALU instructions per wave and tile outweigh the 256 ... 2 048 MFMAs): bf16, every tile whole,
+// dense rows.  out = [gelu'(pre) *] (gemm [+ res]) [+ bias], rounded to T where the general epilogue rounds; act = gelu(out); the forward-style
+// statistics { sum out, sum out^2 } (or the column sums of a GELU data-gradient) on the matrix pipe.  Rows by 32-bit buffer offsets; the
+// residual / pre-activation rows of eight row groups are in flight at a time.  Not for the fused BatchNorm-backward partials (br.y without
+// gelu_bwd): those need a second staging area, which the 256 x 256 tile's LDS does not have -- the host keeps the general kernel for them.
+template <int WM, int WN, int WROWS, int THREADS, int BN>
+__device__ __forceinline__ void nt_epilogue_store_lean(const char* mine, int P, char* smem, int M, int Nout, void* __restrict__ out,
+                                                       const void* __restrict__ res, float* __restrict__ stats, const EpiBnRed& br,
+                                                       int mtile, int ntile, int m0, int n0) {
+    typedef bf16_t T;
+    constexpr int EPV = 8, RPI = 8, ITERS = WROWS / RPI, GRP = 8;
+    static_assert(ITERS % GRP == 0, "row groups of eight");
+    const int lane = lane_id();
+    const int chunk = lane & 7, rsub = lane >> 3;
+    const int n = n0 + chunk * EPV;
+    const uint32_t bytes = (uint32_t)M * (uint32_t)Nout * 2u;
+    const uint32_t voff = ((uint32_t)(m0 + rsub) * (uint32_t)Nout + (uint32_t)n) * 2u, vstep = (uint32_t)RPI * (uint32_t)Nout * 2u;
+    const __amdgpu_buffer_rsrc_t ro = make_rsrc(out, bytes);
+    const bool has_res = res != nullptr, has_bias = br.bias != nullptr, gbw = br.gelu_bwd != 0, has_act = br.act != nullptr;
+    const bool rewrite = stats != nullptr && (has_res || has_bias || gbw);     // the sums describe the STORED tile: put it back for the matrix-pipe pass
+    float bb[EPV];
+#pragma unroll
+    for (int e = 0; e < EPV; ++e) bb[e] = has_bias ? br.bias[n + e] : 0.f;
+    char* src = const_cast<char*>(mine) + rsub * P + chunk * 16;
+    for (int g0 = 0; g0 < ITERS; g0 += GRP) {
+        Vec16<T> rv[GRP], yv[GRP];
+        if (has_res) {
+            const __amdgpu_buffer_rsrc_t rr = make_rsrc(res, bytes);
+#pragma unroll
+            for (int j = 0; j < GRP; ++j) rv[j].v = __builtin_bit_cast(bf16x8_t, __builtin_amdgcn_raw_buffer_load_b128(rr, voff, (g0 + j) * vstep, 0));
+        }
+        if (gbw) {
+            const __amdgpu_buffer_rsrc_t ry = make_rsrc(br.y, bytes);
+#pragma unroll
+            for (int j = 0; j < GRP; ++j) yv[j].v = __builtin_bit_cast(bf16x8_t, __builtin_amdgcn_raw_buffer_load_b128(ry, voff, (g0 + j) * vstep, 0));
+        }
+#pragma unroll
+        for (int j = 0; j < GRP; ++j) {
+            const int it = g0 + j;
+            Vec16<T> v = *reinterpret_cast<const Vec16<T>*>(src + it * RPI * P);
+            if (has_res) {
+#pragma unroll
+                for (int e = 0; e < EPV; ++e) v.set(e, v.get(e) + rv[j].get(e));
+            }
+            if (has_bias) {
+#pragma unroll
+                for (int e = 0; e < EPV; ++e) v.set(e, v.get(e) + bb[e]);
+            }
+            if (gbw) {
+#pragma unroll
+                for (int e = 0; e < EPV; ++e) {
+                    const float hh = yv[j].get(e);
+                    float cdf, pdf;
+                    gelu_parts(hh, cdf, pdf);
+                    v.set(e, v.get(e) * (cdf + hh * pdf));
+                }
+            }
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v.v), ro, voff, it * vstep, EPI_NT_STORE ? 2 : 0);
+            if (has_act) {
+                Vec16<T> ga;
+#pragma unroll
+                for (int e = 0; e < EPV; ++e) {
+                    const float hr = v.get(e);
+                    float cdf, pdf;
+                    gelu_parts(hr, cdf, pdf);
+                    ga.set(e, hr * cdf);
+                }
+                const __amdgpu_buffer_rsrc_t ra = make_rsrc(br.act, bytes);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, ga.v), ra, voff, it * vstep, 0);
+            }
+            if (rewrite) *reinterpret_cast<Vec16<T>*>(src + it * RPI * P) = v;
+        }
+    }
+    if (stats) {
+        f32x4_t S[4], G[4];
+        epi_mfma_sums<WROWS>(mine, mine, P, S, G);
+        float a1[4], a2[4];
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) { a1[cb] = S[cb][0]; a2[cb] = epi_diag(G[cb], lane); }
+        epi_stats_tail_mfma<WM, WN, THREADS, BN>(a1, a2, smem, Nout, stats, mtile, ntile);
+    }
+}
+
+// host side: may a launch on the 256 x 256 tile use the lean linear epilogue?
+inline bool nt_lean_ok(bool bf16, long long M, int Nout, const EpiBnRed& br, const float* stats) {
+    return bf16 && M % 256 == 0 && Nout % 256 == 0 && br.map.wc == 0 && br.res_w == 0 && !br.aff_scale && !(stats && br.y && !br.gelu_bwd) &&
+           M * Nout * 2 < 0x7fffffffLL;
+}
+
 // Shared store epilogue: the wave's (WROWS x 64) tile sits in its LDS staging area `mine` as T (row = pixel).
 // Rows are written back as whole 128/256-byte lines (+ optional residual); the same read-back accumulates the
 // per-channel sum / sum of squares of the STORED values -> BN batch-statistic partials [mtile][2][Nout]

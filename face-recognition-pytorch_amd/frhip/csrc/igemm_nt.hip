@@ -14,7 +14,8 @@ int halo_run(int dtype, const void* a, const void* b, void* out, const void* res
              int n, int h, int w, int c, int k, int sign, hipStream_t stream, const float* xf_scale = nullptr,
              const float* xf_shift = nullptr, void* xf_out = nullptr);
 
-enum { EPI_STORE = 0, EPI_ATOMIC = 1, EPI_SLAB = 2 };    // SLAB: K split y stores its fp32 partial tile to slab y of `out`
+enum { EPI_STORE = 0, EPI_ATOMIC = 1, EPI_SLAB = 2, EPI_LEAN = 3 };    // SLAB: K split y stores its fp32 partial tile to slab y of `out`; LEAN: nt_epilogue_store_lean
+extern int g_epi_lean;      // igemm_halo.hip: frhip_set_epi_lean / FRHIP_EPI_LEAN
 
 template <typename T, int WM, int WN, int MT, int EPI>
 __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void nt_kernel(NtGeom g, const void* __restrict__ a,
@@ -36,7 +37,11 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void nt_kernel(NtGeom 
     const int wm = wave / WN, wn = wave % WN;
     const int m0 = mtile * Tile::BM + wm * WROWS, n0 = ntile * Tile::BN + wn * 64;
 
-    if constexpr (EPI == EPI_STORE) {
+    if constexpr (EPI == EPI_LEAN) {
+        const char* mine = ml.template stage_out<T>(smem);
+        nt_epilogue_store_lean<WM, WN, WROWS, THREADS, Tile::BN>(mine, Tile::template stage_pitch<T>(), smem, g.M, g.Nout, out, res, stats, br,
+                                                                 mtile, ntile, m0, n0);
+    } else if constexpr (EPI == EPI_STORE) {
         EpiOperands<T, WROWS> eo;
         eo.fetch(res, (stats || br.gelu_bwd) ? br.y : nullptr, g.M, g.Nout, m0, n0, br.res_h, br.res_w, &br.map);
         const char* mine = ml.template stage_out<T>(smem);
@@ -64,7 +69,7 @@ static int nt_launch_cfg(const NtGeom& g, const void* a, const void* b, void* ou
                          float* stats, const EpiBnRed& br, int splits, hipStream_t stream) {
     typedef NtTile<T, WM, WN, MT> Tile;
     const int mtiles = (g.M + Tile::BM - 1) / Tile::BM, ntiles = (g.Nout + Tile::BN - 1) / Tile::BN;
-    const int lds = (EPI == EPI_STORE) ? Tile::template lds_bytes<T>() : Tile::template lds_bytes<float>();     // ATOMIC / SLAB stage fp32
+    const int lds = (EPI == EPI_STORE || EPI == EPI_LEAN) ? Tile::template lds_bytes<T>() : Tile::template lds_bytes<float>();     // ATOMIC / SLAB stage fp32
     auto kern = nt_kernel<T, WM, WN, MT, EPI>;
     static bool attr_done = false;
     if (!attr_done) {
@@ -105,7 +110,9 @@ static int nt_dispatch(int dtype, const NtGeom& g, const void* a, const void* b,
         switch (tile) {
             case 2: NT_GO(bf16_t, 4, 1, 4);
             case 3: NT_GO(bf16_t, 4, 2, 4);
-            case 4: if (!atomic) return nt_launch_cfg<bf16_t, 2, 4, 8, EPI_STORE>(g, a, b, out, res, stats, br, splits, stream);
+            case 4: if (!atomic && splits == 1 && g_epi_lean && nt_lean_ok(true, g.M, g.Nout, br, stats))
+                        return nt_launch_cfg<bf16_t, 2, 4, 8, EPI_LEAN>(g, a, b, out, res, stats, br, splits, stream);
+                    if (!atomic) return nt_launch_cfg<bf16_t, 2, 4, 8, EPI_STORE>(g, a, b, out, res, stats, br, splits, stream);
                     NT_GO(bf16_t, 4, 2, 4);
             default: NT_GO(bf16_t, 2, 2, 4);
         }

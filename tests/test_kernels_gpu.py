@@ -322,6 +322,36 @@ def test_linear_fwd_fused_bias_gelu_stats(dtype, mnk):
     np.testing.assert_allclose(plain.float().cpu().numpy(), (a @ w.t()).numpy(), **t)
 
 
+@pytest.mark.parametrize("mnk", [(1024, 256, 256), (2560, 768, 256), (512, 2048, 512), (768, 512, 2048)])
+def test_linear_lean_epilogue_is_bit_identical_to_the_general_one(mnk):
+    """Linears made of whole 256 x 256 tiles (every Swin34 / AlterNet linear at B = 512) run the lean store epilogue (nt_epilogue_store_lean;
+    frhip_set_epi_lean): out, the GELU output and the GELU data-gradient must be the bits of the general epilogue, the per-tile sums
+    (BatchNorm partials, bias-gradient column sums: matrix pipe against VALU) agree to fp32 summation order."""
+    ops = _ops()
+    from frhip._abi import lib
+    m, n, k = mnk
+    dt = torch.bfloat16
+    a = rnd(90, (m, k)).to(dt).cuda()
+    w = (rnd(91, (n, k)) * 0.2).to(dt).cuda()
+    bias = rnd(92, (n,)).cuda()
+    pre = (rnd(93, (m, n)) * 1.5).to(dt).cuda()
+    res = {}
+    for lean in (0, 1):
+        old = lib().frhip_set_epi_lean(lean)
+        try:
+            out, act, part = ops.linear_fwd(a, w, bias, want_act=True, want_stats=True)
+            plain, _, _ = ops.linear_fwd(a, w)
+            dx, colsum = ops.linear_dgrad_gelu(a, w, pre)
+            res[lean] = (out, act, part.sum(0), plain, ops.gemm_nt(a, w), dx, colsum)
+        finally:
+            lib().frhip_set_epi_lean(old)
+    g, l = res[0], res[1]
+    for i in (0, 1, 3, 4, 5):
+        assert torch.equal(g[i], l[i]), i
+    np.testing.assert_allclose(l[2].cpu().numpy(), g[2].cpu().numpy(), rtol=1e-5, atol=1e-5 * float(g[2].abs().max()))
+    np.testing.assert_allclose(l[6].cpu().numpy(), g[6].cpu().numpy(), rtol=1e-5, atol=1e-5 * float(g[6].abs().max()))
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("mnk", [(600, 256, 64), (5000, 512, 128), (300, 72, 64)])
 def test_linear_dgrad_gelu_fused(dtype, mnk):
