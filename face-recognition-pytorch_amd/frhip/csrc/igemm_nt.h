@@ -234,6 +234,27 @@ struct NtMainloop {
         compute(cur);
     }
 
+    // rows [64 h, 64 h + 64) of this wave's tile (MT == 8) to rows 0 .. 63 of its staging area, as bf16: the upper 64 rows of the area stay free
+    // for a second operand tile (lean BatchNorm-backward partials on the 256 x 256 tile)
+    __device__ __forceinline__ char* stage_half(char* smem, int h) {
+        constexpr int P = Tile::template stage_pitch<bf16_t>();
+        const int lane = lane_id();
+        const int fi = lane & 15, fg = lane >> 4;
+        char* mine = smem + wave_id() * Tile::WROWS * P;
+        __syncthreads();
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                bf16x4_t v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = (bf16_t)(h ? acc[nt][(MT > 4 ? 4 : 0) + mt][e] : acc[nt][mt][e]);
+                *reinterpret_cast<bf16x4_t*>(mine + (mt * 16 + fi) * P + (nt * 16 + 4 * fg) * 2) = v;
+            }
+        __syncthreads();
+        return mine;
+    }
+
     // Write this wave's (MT*16)x64 tile to its private LDS staging area as TS (row = pixel, 64 channels).
     template <typename TS>
     __device__ __forceinline__ char* stage_out(char* smem) {
@@ -446,10 +467,13 @@ __device__ __forceinline__ void epi_stats_tail_mfma(const float (&a1)[4], const 
 // row map.  Same values, same summation order as the general path below (results and partial sums are bit-identical); what is gone
 // is the per-row 64-bit index arithmetic, the per-row bounds checks and the layout cases: one buffer descriptor, one lane offset, a
 // scalar row step.
+// yoff: byte offset (from `mine`) of the wave's second staging area for the saved BatchNorm-input rows; acc (optional, [2][4]): the wave's
+// sums are ADDED there instead of going to the workgroup's partial row -- the caller runs epi_stats_tail_mfma itself (a tile staged in halves)
 template <typename T, int WM, int WN, int WROWS, int THREADS, int BN>
 __device__ __forceinline__ void nt_epilogue_store_fast(const char* mine, int P, char* smem, int M, int Nout, void* __restrict__ out,
                                                        bool has_res, float* __restrict__ stats, const EpiBnRed& br,
-                                                       const EpiOperands<T, WROWS>& ops, int mtile, int ntile) {
+                                                       const EpiOperands<T, WROWS>& ops, int mtile, int ntile,
+                                                       int yoff = WM * WN * WROWS * (64 * (int)sizeof(T) + 16), float (*acc)[4] = nullptr) {
     constexpr int EPV = 16 / (int)sizeof(T), LPR = 64 / EPV, RPI = 64 / LPR, ITERS = WROWS / RPI;
     const int lane = lane_id();
     const int chunk = lane % LPR, rsub = lane / LPR;
@@ -465,7 +489,7 @@ __device__ __forceinline__ void nt_epilogue_store_fast(const char* mine, int P, 
         // ones x D and the diagonal of D^T Y.  What is left on the VALU is the mask (5 instructions per element; none without ReLU).
         const bool masked = br.mscale != nullptr;
         const int n = ops.n;
-        char* ydst = const_cast<char*>(src) + WM * WN * WROWS * P;
+        char* ydst = const_cast<char*>(src) + yoff;
         float ms[EPV], mb[EPV];
 #pragma unroll
         for (int e = 0; e < EPV; ++e) { ms[e] = masked ? br.mscale[n + e] : 0.f; mb[e] = masked ? br.mshift[n + e] : 1.f; }
@@ -495,7 +519,7 @@ __device__ __forceinline__ void nt_epilogue_store_fast(const char* mine, int P, 
             *reinterpret_cast<Vec16<T>*>(ydst + it * RPI * P) = yy;
         }
         f32x4_t S[4], G[4];
-        epi_mfma_sums<WROWS>(mine, mine + WM * WN * WROWS * P, P, S, G);
+        epi_mfma_sums<WROWS>(mine, mine + yoff, P, S, G);
         float a1[4], a2[4];
         const int n0 = ntile * BN + (wave_id() % WN) * 64, j = lane & 15;
 #pragma unroll
@@ -504,7 +528,12 @@ __device__ __forceinline__ void nt_epilogue_store_fast(const char* mine, int P, 
             a1[cb] = S[cb][0];
             a2[cb] = br.invstd[c] * (epi_diag(G[cb], lane) - br.mean[c] * a1[cb]);
         }
-        epi_stats_tail_mfma<WM, WN, THREADS, BN>(a1, a2, smem, Nout, stats, mtile, ntile);
+        if (acc) {
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) { acc[0][cb] += a1[cb]; acc[1][cb] += a2[cb]; }
+        } else {
+            epi_stats_tail_mfma<WM, WN, THREADS, BN>(a1, a2, smem, Nout, stats, mtile, ntile);
+        }
         return;
     } else if (br.aff_scale) {
         // eval-mode BatchNorm folded into the store (see EpiBnRed): no statistics
@@ -550,8 +579,10 @@ __device__ __forceinline__ void nt_epilogue_store_fast(const char* mine, int P, 
 // 2048, where the general epilogue's ~2 000 VALU instructions per wave and tile outweigh the 256 ... 2 048 MFMAs): bf16, every tile whole,
 // dense rows.  out = [gelu'(pre) *] (gemm [+ res]) [+ bias], rounded to T where the general epilogue rounds; act = gelu(out); the forward-style
 // statistics { sum out, sum out^2 } (or the column sums of a GELU data-gradient) on the matrix pipe.  Rows by 32-bit buffer offsets; the
-// residual / pre-activation rows of eight row groups are in flight at a time.  Not for the fused BatchNorm-backward partials (br.y without
-// gelu_bwd): those need a second staging area, which the 256 x 256 tile's LDS does not have -- the host keeps the general kernel for them.
+// residual / pre-activation rows of eight row groups are in flight at a time.  The fused BatchNorm-backward partials (br.y without gelu_bwd)
+// need a second staging area for the saved BatchNorm-input rows, which the 256 x 256 tile's LDS does not have beside eight 128-row tiles: the
+// kernel stages such a tile in two 64-row halves (NtMainloop::stage_half) and runs the 64-row lean epilogue on each, with the free upper half
+// of the wave's area as the second tile.
 template <int WM, int WN, int WROWS, int THREADS, int BN>
 __device__ __forceinline__ void nt_epilogue_store_lean(const char* mine, int P, char* smem, int M, int Nout, void* __restrict__ out,
                                                        const void* __restrict__ res, float* __restrict__ stats, const EpiBnRed& br,
@@ -632,8 +663,8 @@ __device__ __forceinline__ void nt_epilogue_store_lean(const char* mine, int P, 
 
 // host side: may a launch on the 256 x 256 tile use the lean linear epilogue?
 inline bool nt_lean_ok(bool bf16, long long M, int Nout, const EpiBnRed& br, const float* stats) {
-    return bf16 && M % 256 == 0 && Nout % 256 == 0 && br.map.wc == 0 && br.res_w == 0 && !br.aff_scale && !(stats && br.y && !br.gelu_bwd) &&
-           M * Nout * 2 < 0x7fffffffLL;
+    return bf16 && M % 256 == 0 && Nout % 256 == 0 && br.map.wc == 0 && br.res_w == 0 && !br.aff_scale &&
+           !(stats && br.y && !br.gelu_bwd && (br.bias || br.act)) && M * Nout * 2 < 0x7fffffffLL;
 }
 
 // Shared store epilogue: the wave's (WROWS x 64) tile sits in its LDS staging area `mine` as T (row = pixel).

@@ -38,9 +38,24 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void nt_kernel(NtGeom 
     const int m0 = mtile * Tile::BM + wm * WROWS, n0 = ntile * Tile::BN + wn * 64;
 
     if constexpr (EPI == EPI_LEAN) {
-        const char* mine = ml.template stage_out<T>(smem);
-        nt_epilogue_store_lean<WM, WN, WROWS, THREADS, Tile::BN>(mine, Tile::template stage_pitch<T>(), smem, g.M, g.Nout, out, res, stats, br,
-                                                                 mtile, ntile, m0, n0);
+        if (stats && br.y && !br.gelu_bwd) {
+            // BatchNorm-backward partials (a data-gradient whose result is the upstream gradient of a BatchNorm): two 64-row halves
+            constexpr int P = Tile::template stage_pitch<T>();
+            float accs[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                EpiOperands<T, 64> eo;
+                eo.fetch_fast(res, br.y, g.M, g.Nout, m0 + 64 * half, n0);
+                const char* mine = ml.stage_half(smem, half);
+                nt_epilogue_store_fast<T, WM, WN, 64, THREADS, Tile::BN>(mine, P, smem, g.M, g.Nout, out, res != nullptr, stats, br, eo, mtile, ntile,
+                                                                         64 * P, accs);
+            }
+            epi_stats_tail_mfma<WM, WN, THREADS, Tile::BN>(accs[0], accs[1], smem, g.Nout, stats, mtile, ntile);
+        } else {
+            const char* mine = ml.template stage_out<T>(smem);
+            nt_epilogue_store_lean<WM, WN, WROWS, THREADS, Tile::BN>(mine, Tile::template stage_pitch<T>(), smem, g.M, g.Nout, out, res, stats, br,
+                                                                     mtile, ntile, m0, n0);
+        }
     } else if constexpr (EPI == EPI_STORE) {
         EpiOperands<T, WROWS> eo;
         eo.fetch(res, (stats || br.gelu_bwd) ? br.y : nullptr, g.M, g.Nout, m0, n0, br.res_h, br.res_w, &br.map);

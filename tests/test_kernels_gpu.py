@@ -352,6 +352,33 @@ def test_linear_lean_epilogue_is_bit_identical_to_the_general_one(mnk):
     np.testing.assert_allclose(l[6].cpu().numpy(), g[6].cpu().numpy(), rtol=1e-5, atol=1e-5 * float(g[6].abs().max()))
 
 
+@pytest.mark.parametrize("mkc", [(1024, 1024, 256), (2560, 256, 256), (512, 2048, 512)])
+def test_linear_dgrad_with_bn_partials_lean_against_general(mkc):
+    """A linear's data-gradient whose result (+ residual) is the upstream gradient of a BatchNorm (nets/SwinV2.py: x + norm(f(x)); the 1 x 1
+    form of frhip_conv_dgrad_bnred) on whole 256 x 256 tiles: the lean kernel stages its tile in two 64-row halves and forms the partials
+    { sum d, sum d xhat } on the matrix pipe -- dx bit-identical to the general epilogue, the sums to fp32 summation order."""
+    ops = _ops()
+    from frhip._abi import lib
+    m, k, c = mkc
+    dt = torch.bfloat16
+    dy = rnd(95, (m, 1, 1, k)).to(dt).cuda()
+    wt = (rnd(96, (c, 1, 1, k)) * 0.1).to(dt).cuda()
+    res = rnd(97, (m, 1, 1, c)).to(dt).cuda()
+    y_bn = (rnd(98, (m, 1, 1, c)) * 0.8 + 0.5).to(dt).cuda()
+    st = ops.bn_finalize(ops.colstats(y_bn.view(m, c)), m, (1 + 0.1 * rnd(99, (c,))).cuda(), (0.1 * rnd(100, (c,))).cuda(), None, None)
+    outs = {}
+    for lean in (0, 1):
+        old = lib().frhip_set_epi_lean(lean)
+        try:
+            outs[lean] = ops.conv_dgrad(dy, wt, (m, 1, 1, c), 1, 1, 1, 0, residual=res, bnred=(y_bn, st, False))
+        finally:
+            lib().frhip_set_epi_lean(old)
+    (dx0, p0), (dx1, p1) = outs[0], outs[1]
+    assert torch.equal(dx0, dx1) and p0.shape == p1.shape
+    a, b = p1.sum(0).cpu().numpy(), p0.sum(0).cpu().numpy()
+    np.testing.assert_allclose(a, b, rtol=2e-4, atol=2e-4 * max(1.0, np.abs(b).max()))
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("mnk", [(600, 256, 64), (5000, 512, 128), (300, 72, 64)])
 def test_linear_dgrad_gelu_fused(dtype, mnk):
