@@ -146,7 +146,7 @@ constexpr int WM_FWD_WAVE = 3 * WM_TILE + 512;
 
 __global__ __launch_bounds__(256, 2) void wm_fwd_kernel(const bf16_t* __restrict__ qkv, const float* __restrict__ bias,
                                                         const float* __restrict__ scale, bf16_t* __restrict__ out, int nwin,
-                                                        WaGeom g, int C, int win_per_block) {
+                                                        WaGeom g, int C, int win_per_block, int heads) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int wave = wave_id(), lane = lane_id();
     char* qh = smem + wave * WM_FWD_WAVE;
@@ -154,14 +154,18 @@ __global__ __launch_bounds__(256, 2) void wm_fwd_kernel(const bf16_t* __restrict
     char* vt = kh + WM_TILE;
     int* spix = reinterpret_cast<int*>(vt + WM_TILE);
     int* sreg = spix + 64;
-    const int h = blockIdx.x, n = g.n, grp = lane >> 4, c = lane & 15;
+    // (head, window chunk) from ONE XCD-remapped grid dimension with the head fastest: a head's slice of a token row is 64 bytes -- half a
+    // cache line -- so the workgroups of adjacent heads of one window chunk should run on the same XCD at the same time (with a (heads,
+    // chunks) grid and eight heads, head h ALWAYS landed on XCD h and every XCD's L2 fetched every line of qkv for half of it)
+    const uint32_t lin = xcd_remap(blockIdx.x, gridDim.x);
+    const int h = (int)(lin % (uint32_t)heads), chunk = (int)(lin / (uint32_t)heads), n = g.n, grp = lane >> 4, c = lane & 15;
     const float sc = scale[h];
     const bool masked = g.shift > 0;
     f32x4_t bs[4][4];
     wm_load_bias(bias + (size_t)h * n * n, n, lane, bs);
     const bool active = lane < n;
     const int tok = active ? lane : 0;
-    const int w_begin = blockIdx.y * win_per_block, w_end = min(nwin, w_begin + win_per_block);
+    const int w_begin = chunk * win_per_block, w_end = min(nwin, w_begin + win_per_block);
     for (int win = w_begin + wave; win < w_end; win += 4) {
         int region;
         const size_t pix = wa_pixel(win, tok, g, &region);
@@ -247,7 +251,7 @@ __global__ __launch_bounds__(256, 1) void wm_bwd_kernel(const bf16_t* __restrict
                                                         const float* __restrict__ bias, const float* __restrict__ scale,
                                                         bf16_t* __restrict__ dqkv, float* __restrict__ dbias,
                                                         float* __restrict__ dscale, float* __restrict__ colsum, int nwin,
-                                                        WaGeom g, int C, int win_per_block) {
+                                                        WaGeom g, int C, int win_per_block, int heads) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int wave = wave_id(), lane = lane_id();
     char* qh = smem + wave * WM_BWD_WAVE;
@@ -259,7 +263,11 @@ __global__ __launch_bounds__(256, 1) void wm_bwd_kernel(const bf16_t* __restrict
     float* sik = siq + 64;
     int* spix = reinterpret_cast<int*>(sik + 64);
     int* sreg = spix + 64;
-    const int h = blockIdx.x, n = g.n, grp = lane >> 4, c = lane & 15;
+    // (head, window chunk) from ONE XCD-remapped grid dimension with the head fastest: a head's slice of a token row is 64 bytes -- half a
+    // cache line -- so the workgroups of adjacent heads of one window chunk should run on the same XCD at the same time (with a (heads,
+    // chunks) grid and eight heads, head h ALWAYS landed on XCD h and every XCD's L2 fetched every line of qkv for half of it)
+    const uint32_t lin = xcd_remap(blockIdx.x, gridDim.x);
+    const int h = (int)(lin % (uint32_t)heads), chunk = (int)(lin / (uint32_t)heads), n = g.n, grp = lane >> 4, c = lane & 15;
     const float sc = scale[h];
     const bool masked = g.shift > 0;
     f32x4_t bs[4][4], db[4][4];
@@ -276,7 +284,7 @@ __global__ __launch_bounds__(256, 1) void wm_bwd_kernel(const bf16_t* __restrict
         for (int te = 0; te < 2; ++te) csum[a][te] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     const bool active = lane < n;
     const int tok = active ? lane : 0;
-    const int w_begin = blockIdx.y * win_per_block, w_end = min(nwin, w_begin + win_per_block);
+    const int w_begin = chunk * win_per_block, w_end = min(nwin, w_begin + win_per_block);
     for (int win = w_begin + wave; win < w_end; win += 4) {
         int region;
         const size_t pix = wa_pixel(win, tok, g, &region);
@@ -470,8 +478,8 @@ int winattn_mfma_fwd(const void* qkv, const float* bias, const float* scale, voi
     }
     int wpb;
     const int chunks = wm_chunks(nwin, heads, 2048, &wpb);
-    hipLaunchKernelGGL(wm_fwd_kernel, dim3(heads, chunks), dim3(256), lds, stream, (const bf16_t*)qkv, bias, scale, (bf16_t*)out,
-                       nwin, g, C, wpb);
+    hipLaunchKernelGGL(wm_fwd_kernel, dim3(heads * chunks), dim3(256), lds, stream, (const bf16_t*)qkv, bias, scale, (bf16_t*)out,
+                       nwin, g, C, wpb, heads);
     return check_launch("frhip_winattn_fwd");
 }
 
@@ -488,8 +496,8 @@ int winattn_mfma_bwd(const void* qkv, const void* dout, const float* bias, const
     }
     int wpb;
     const int chunks = wm_chunks(nwin, heads, 1024, &wpb);
-    hipLaunchKernelGGL(wm_bwd_kernel, dim3(heads, chunks), dim3(256), lds, stream, (const bf16_t*)qkv, (const bf16_t*)dout, bias,
-                       scale, (bf16_t*)dqkv, dbias, dscale, colsum, nwin, g, C, wpb);
+    hipLaunchKernelGGL(wm_bwd_kernel, dim3(heads * chunks), dim3(256), lds, stream, (const bf16_t*)qkv, (const bf16_t*)dout, bias,
+                       scale, (bf16_t*)dqkv, dbias, dscale, colsum, nwin, g, C, wpb, heads);
     return check_launch("frhip_winattn_bwd");
 }
 
