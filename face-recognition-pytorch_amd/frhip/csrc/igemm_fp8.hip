@@ -12,6 +12,7 @@
 #include "frhip.h"
 
 namespace frhip {
+extern int g_epi_lean;      // igemm_halo.hip: frhip_set_epi_lean / FRHIP_EPI_LEAN
 
 constexpr float FP8_MAX = 448.f;
 
@@ -115,7 +116,8 @@ __global__ __launch_bounds__(256) void bn_apply_q8_kernel(const T* __restrict__ 
 }
 
 // ---- fp8 x fp8 -> bf16 implicit GEMM on the shared NT main loop (one K step = one filter tap x 128 channels)
-template <int WM, int WN, int MT>
+// LEAN: whole 256-row / 256-channel tiles and a dense layout (nt_lean_ok): the lean store epilogue of igemm_nt.h
+template <int WM, int WN, int MT, bool LEAN = false>
 __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void nt8_kernel(NtGeom g, const void* __restrict__ a,
                                                                          const void* __restrict__ b, const float* __restrict__ wscale,
                                                                          float ascale, void* __restrict__ out, float* __restrict__ stats,
@@ -142,20 +144,25 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void nt8_kernel(NtGeom
 #pragma unroll
             for (int e = 0; e < 4; ++e) ml.acc[nt][mt][e] *= sc[e];
     }
-    EpiOperands<bf16_t, WROWS> eo;
-    eo.fetch(nullptr, nullptr, g.M, g.Nout, m0, n0, 0, 0, &br.map);
     const char* mine = ml.template stage_out<bf16_t>(smem);
-    nt_epilogue_store<bf16_t, WM, WN, WROWS, Tile::THREADS, Tile::BN>(mine, Tile::template stage_pitch<bf16_t>(), smem, g.M, g.Nout,
-                                                                      out, false, stats, br, eo, mtile, ntile, m0, n0);
+    if constexpr (LEAN) {
+        nt_epilogue_store_lean<WM, WN, WROWS, Tile::THREADS, Tile::BN>(mine, Tile::template stage_pitch<bf16_t>(), smem, g.M, g.Nout, out,
+                                                                       nullptr, stats, br, mtile, ntile, m0, n0);
+    } else {
+        EpiOperands<bf16_t, WROWS> eo;
+        eo.fetch(nullptr, nullptr, g.M, g.Nout, m0, n0, 0, 0, &br.map);
+        nt_epilogue_store<bf16_t, WM, WN, WROWS, Tile::THREADS, Tile::BN>(mine, Tile::template stage_pitch<bf16_t>(), smem, g.M, g.Nout,
+                                                                          out, false, stats, br, eo, mtile, ntile, m0, n0);
+    }
 }
 
-template <int WM, int WN, int MT>
+template <int WM, int WN, int MT, bool LEAN = false>
 static int nt8_launch(const NtGeom& g, const void* a, const void* b, const float* wscale, float ascale, void* out, float* stats,
                       const EpiBnRed& br, hipStream_t stream) {
     typedef NtTile<fp8_t, WM, WN, MT> Tile;
     const int mtiles = (g.M + Tile::BM - 1) / Tile::BM, ntiles = (g.Nout + Tile::BN - 1) / Tile::BN;
     const int lds = Tile::template lds_bytes<bf16_t>();
-    auto kern = nt8_kernel<WM, WN, MT>;
+    auto kern = nt8_kernel<WM, WN, MT, LEAN>;
     static bool attr_done = false;
     if (!attr_done) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
@@ -171,7 +178,7 @@ static int nt8_launch(const NtGeom& g, const void* a, const void* b, const float
 // ---- 3x3 / stride-1 / pad-1 fp8 convolution on the LDS-halo main loop (igemm_halo.h): activation window resident in LDS per
 //      128-channel chunk, weights streamed per tap; non-scaled fp8 MFMA (see Mma<fp8n_t>): half the L2 -> LDS bytes per MAC of the
 //      bf16 kernel, which is what bounds it.
-template <int WM, int WN, int MT, int HBUFS>
+template <int WM, int WN, int MT, int HBUFS, bool LEAN = false>
 __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void halo8_kernel(HaloGeom g, const void* __restrict__ a,
                                                                            const void* __restrict__ b, const float* __restrict__ wscale,
                                                                            float ascale, void* __restrict__ out, float* __restrict__ stats,
@@ -197,10 +204,16 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void halo8_kernel(Halo
             for (int e = 0; e < 4; ++e) ml.acc[nt][mt][e] *= sc[e];
     }
     EpiOperands<bf16_t, Tile::WROWS> eo;
-    eo.fetch(nullptr, nullptr, g.M, g.Nout, m0, n0, 0, 0, &br.map);
     const char* mine = ml.template stage_out<bf16_t>(smem);
-    nt_epilogue_store<bf16_t, WM, WN, Tile::WROWS, Tile::THREADS, Tile::BN>(mine, Tile::template stage_pitch<bf16_t>(), smem, g.M, g.Nout,
-                                                                            out, false, stats, br, eo, mtile, ntile, m0, n0);
+    if constexpr (LEAN) {
+        eo.fetch_fast(nullptr, nullptr, g.M, g.Nout, m0, n0);
+        nt_epilogue_store_fast<bf16_t, WM, WN, Tile::WROWS, Tile::THREADS, Tile::BN>(mine, Tile::template stage_pitch<bf16_t>(), smem, g.M,
+                                                                                     g.Nout, out, false, stats, br, eo, mtile, ntile);
+    } else {
+        eo.fetch(nullptr, nullptr, g.M, g.Nout, m0, n0, 0, 0, &br.map);
+        nt_epilogue_store<bf16_t, WM, WN, Tile::WROWS, Tile::THREADS, Tile::BN>(mine, Tile::template stage_pitch<bf16_t>(), smem, g.M, g.Nout,
+                                                                                out, false, stats, br, eo, mtile, ntile, m0, n0);
+    }
 }
 
 static int g_fp8_halo = 1;      // 3x3 / stride-1 layers on the halo main loop (0: generic NT kernel; test hook frhip_set_fp8_halo)
@@ -221,16 +234,17 @@ static int halo8_run(const void* x8, const void* w8, const float* wscale, float 
     g.d_hw = make_fastdiv((uint32_t)(h * w)); g.d_w = make_fastdiv((uint32_t)w);
     const int mtiles = (g.M + Tile::BM - 1) / Tile::BM, ntiles = (k + Tile::BN - 1) / Tile::BN;
     const int lds = Tile::template lds_bytes<bf16_t>();
-    auto kern = halo8_kernel<4, 1, 4, 1>;
-    static bool attr_done = false;
-    if (!attr_done) {
+    static const EpiBnRed none = {nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, {0, 0, 0, 0, 0, 0}, nullptr, nullptr, 0};
+    const bool lean = g_epi_lean && epi_lean_ok(true, g.M, k, Tile::BM, Tile::BN, none);
+    auto kern = lean ? halo8_kernel<4, 1, 4, 1, true> : halo8_kernel<4, 1, 4, 1, false>;
+    static bool attr_done[2] = {false, false};
+    if (!attr_done[lean]) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
             set_error("igemm_fp8(halo): cannot raise dynamic LDS to %d bytes", lds);
             return FRHIP_ELAUNCH;
         }
-        attr_done = true;
+        attr_done[lean] = true;
     }
-    static const EpiBnRed none = {nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, {0, 0, 0, 0, 0, 0}, nullptr, nullptr, 0};
     hipLaunchKernelGGL(kern, dim3(mtiles * ntiles), dim3(Tile::THREADS), lds, stream, g, x8, w8, wscale, ascale, y, stats, none, mtiles, ntiles);
     return check_launch("igemm_fp8(halo)");
 }
@@ -260,7 +274,10 @@ static const EpiBnRed NO_EPI = {nullptr, nullptr, nullptr, nullptr, nullptr, 0, 
 
 static int fp8_run(const NtGeom& g, const void* x8, const void* w8, const float* wscale, float ascale, void* y, float* stats,
                    const EpiBnRed& br, hipStream_t stream) {
-    if (fp8_wide(g)) return nt8_launch<2, 4, 8>(g, x8, w8, wscale, ascale, y, stats, br, stream);
+    if (fp8_wide(g)) {
+        if (g_epi_lean && nt_lean_ok(true, g.M, g.Nout, br, stats)) return nt8_launch<2, 4, 8, true>(g, x8, w8, wscale, ascale, y, stats, br, stream);
+        return nt8_launch<2, 4, 8>(g, x8, w8, wscale, ascale, y, stats, br, stream);
+    }
     if ((g.Nout % 128) != 0 && g.Nout <= 256) return nt8_launch<4, 1, 4>(g, x8, w8, wscale, ascale, y, stats, br, stream);
     return nt8_launch<2, 2, 4>(g, x8, w8, wscale, ascale, y, stats, br, stream);
 }

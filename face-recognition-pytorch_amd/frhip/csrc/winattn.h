@@ -29,10 +29,13 @@ __device__ __forceinline__ size_t wa_pixel(int win, int tok, const WaGeom& g, in
     return ((size_t)b * g.H + hh) * g.W + ww;
 }
 
+// destinations (fp32 [C] each, any may be null) of the column sums of the q / k / v thirds of dqkv
+struct WaColsum { float* p[3]; };
+
 // bf16 MFMA implementation (winattn_mfma.hip); same operands as frhip_winattn_fwd / _bwd
 int winattn_mfma_fwd(const void* qkv, const float* bias, const float* scale, void* out, int nwin, const WaGeom& g, int C,
                      int heads, hipStream_t stream);
 int winattn_mfma_bwd(const void* qkv, const void* dout, const float* bias, const float* scale, void* dqkv, float* dbias,
-                     float* dscale, float* colsum, int nwin, const WaGeom& g, int C, int heads, hipStream_t stream);
+                     float* dscale, const WaColsum& colsum, int nwin, const WaGeom& g, int C, int heads, hipStream_t stream);
 
 }  // namespace frhip

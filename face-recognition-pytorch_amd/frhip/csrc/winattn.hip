@@ -359,7 +359,7 @@ extern "C" int frhip_winattn_bwd(int dtype, const void* qkv, const void* dout, c
     if (!wa_shape_ok(dtype, b, h, w, c, heads, ws, shift, "frhip_winattn_bwd")) return FRHIP_EINVAL;
     const int nwin = b * (h / ws) * (w / ws);
     WaGeom g; g.H = h; g.W = w; g.ws = ws; g.shift = shift; g.n = ws * ws;
-    if (dtype == FRHIP_DT_BF16 && g_wa_mfma) return winattn_mfma_bwd(qkv, dout, bias, scale, dqkv, dbias, dscale, nullptr, nwin, g, c, heads, stream);
+    if (dtype == FRHIP_DT_BF16 && g_wa_mfma) return winattn_mfma_bwd(qkv, dout, bias, scale, dqkv, dbias, dscale, WaColsum{{nullptr, nullptr, nullptr}}, nwin, g, c, heads, stream);
     int chunks = (1024 + heads - 1) / heads;                 // ~1024 workgroups
     int wpb = (nwin + chunks - 1) / chunks; if (wpb < 4) wpb = 4;
     chunks = (nwin + wpb - 1) / wpb;
@@ -405,5 +405,20 @@ extern "C" int frhip_winattn_bwd_colsum(int dtype, const void* qkv, const void* 
     }
     const int nwin = b * (h / ws) * (w / ws);
     WaGeom g; g.H = h; g.W = w; g.ws = ws; g.shift = shift; g.n = ws * ws;
-    return winattn_mfma_bwd(qkv, dout, bias, scale, dqkv, dbias, dscale, dqkv_colsum, nwin, g, c, heads, stream);
+    const WaColsum cs = {{dqkv_colsum, dqkv_colsum ? dqkv_colsum + c : nullptr, dqkv_colsum ? dqkv_colsum + 2 * c : nullptr}};
+    return winattn_mfma_bwd(qkv, dout, bias, scale, dqkv, dbias, dscale, cs, nwin, g, c, heads, stream);
+}
+
+extern "C" int frhip_winattn_bwd_qvbias(int dtype, const void* qkv, const void* dout, const float* bias, const float* scale,
+                                        void* dqkv, float* dbias, float* dscale, float* dq_bias, float* dv_bias, int b, int h,
+                                        int w, int c, int heads, int ws, int shift, hipStream_t stream) {
+    if (!wa_shape_ok(dtype, b, h, w, c, heads, ws, shift, "frhip_winattn_bwd_qvbias")) return FRHIP_EINVAL;
+    if (dtype != FRHIP_DT_BF16 || !g_wa_mfma) {
+        set_error("frhip_winattn_bwd_qvbias: only the bf16 MFMA kernels produce the column sums (frhip_set_winattn_mfma)");
+        return FRHIP_EINVAL;
+    }
+    const int nwin = b * (h / ws) * (w / ws);
+    WaGeom g; g.H = h; g.W = w; g.ws = ws; g.shift = shift; g.n = ws * ws;
+    const WaColsum cs = {{dq_bias, nullptr, dv_bias}};
+    return winattn_mfma_bwd(qkv, dout, bias, scale, dqkv, dbias, dscale, cs, nwin, g, c, heads, stream);
 }

@@ -250,7 +250,7 @@ __device__ __forceinline__ void wm_store_unnormalised(const f32x4_t (&xt)[2][4],
 __global__ __launch_bounds__(256, 1) void wm_bwd_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
                                                         const float* __restrict__ bias, const float* __restrict__ scale,
                                                         bf16_t* __restrict__ dqkv, float* __restrict__ dbias,
-                                                        float* __restrict__ dscale, float* __restrict__ colsum, int nwin,
+                                                        float* __restrict__ dscale, WaColsum colsum, int nwin,
                                                         WaGeom g, int C, int win_per_block, int heads) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int wave = wave_id(), lane = lane_id();
@@ -432,7 +432,8 @@ __global__ __launch_bounds__(256, 1) void wm_bwd_kernel(const bf16_t* __restrict
     __shared__ float red_s[4];
     if (lane == 0) red_s[wave] = dsc;
     float* red_c = red + 4 * 4096;                                 // [4 waves][3][32]
-    if (colsum) {
+    const bool want_cs = colsum.p[0] || colsum.p[1] || colsum.p[2];
+    if (want_cs) {
 #pragma unroll
         for (int a = 0; a < 3; ++a)
 #pragma unroll
@@ -446,9 +447,10 @@ __global__ __launch_bounds__(256, 1) void wm_bwd_kernel(const bf16_t* __restrict
                 }
     }
     __syncthreads();
-    if (colsum && threadIdx.x < 96) {
+    if (want_cs && threadIdx.x < 96) {
         const int a = threadIdx.x >> 5, e = threadIdx.x & 31;
-        atomicAdd(colsum + a * C + h * WA_D + e, red_c[a * 32 + e] + red_c[96 + a * 32 + e] + red_c[192 + a * 32 + e] + red_c[288 + a * 32 + e]);
+        float* dst = a == 0 ? colsum.p[0] : (a == 1 ? colsum.p[1] : colsum.p[2]);
+        if (dst) atomicAdd(dst + h * WA_D + e, red_c[a * 32 + e] + red_c[96 + a * 32 + e] + red_c[192 + a * 32 + e] + red_c[288 + a * 32 + e]);
     }
     for (int idx = threadIdx.x; idx < n * n; idx += 256) {
         const int i = idx / n, j = idx - i * n, o = i * 64 + j;
@@ -484,7 +486,7 @@ int winattn_mfma_fwd(const void* qkv, const float* bias, const float* scale, voi
 }
 
 int winattn_mfma_bwd(const void* qkv, const void* dout, const float* bias, const float* scale, void* dqkv, float* dbias,
-                     float* dscale, float* colsum, int nwin, const WaGeom& g, int C, int heads, hipStream_t stream) {
+                     float* dscale, const WaColsum& colsum, int nwin, const WaGeom& g, int C, int heads, hipStream_t stream) {
     const int lds = 4 * WM_BWD_WAVE;
     static bool attr_done = false;
     if (!attr_done) {

@@ -203,8 +203,9 @@ def linear_fwd(a, w, bias=None, want_act=False, want_stats=False):
     return out, act, part
 
 
-def linear_dgrad_gelu(dy, wt, pre, want_colsum=True):
-    """dx = (dy [M,K] @ wt [N,K]^T) * gelu'(pre [M,N]); colsum [N] fp32 = sum over rows of dx (the bias gradient)"""
+def linear_dgrad_gelu(dy, wt, pre, want_colsum=True, colsum_into=None):
+    """dx = (dy [M,K] @ wt [N,K]^T) * gelu'(pre [M,N]); colsum [N] fp32 = sum over rows of dx (the bias gradient).
+    colsum_into (fp32 [N]): the column sums are ADDED into it by one launch (frhip_sum_partials) and it is returned"""
     m, k = dy.shape
     n = wt.shape[0]
     assert tuple(pre.shape) == (m, n) and pre.dtype == dy.dtype == wt.dtype
@@ -215,6 +216,9 @@ def linear_dgrad_gelu(dy, wt, pre, want_colsum=True):
         part = torch.empty((rows, 2, n), dtype=torch.float32, device=dy.device)
     check(lib().frhip_linear_dgrad_gelu(dt_of(dy), _p(dy), _p(wt), _p(pre), _p(dx), _p(part), m, n, k, _s()),
           "frhip_linear_dgrad_gelu")
+    if want_colsum and colsum_into is not None:
+        check(lib().frhip_sum_partials(_p(part), part.shape[0], n, 0, _p(colsum_into), _s()), "frhip_sum_partials")
+        return dx, colsum_into
     return dx, (part[:, 0].sum(0) if want_colsum else None)
 
 
@@ -676,9 +680,11 @@ def winattn_fwd(qkv, bias, scale, b, h, w, heads, ws=7, shift=0):
     return out
 
 
-def winattn_bwd(qkv, dout, bias, scale, b, h, w, heads, ws=7, shift=0, want_colsum=False, dbias=None, dscale=None):
+def winattn_bwd(qkv, dout, bias, scale, b, h, w, heads, ws=7, shift=0, want_colsum=False, dbias=None, dscale=None, qv_grads=None):
     """-> dqkv, dbias, dscale [, colsum fp32 [3c] = column sums of dqkv, or None when this dtype / kernel mode cannot fuse them].
-    dbias / dscale given: the kernel ADDS into them (caller-zeroed accumulators) instead of fresh zero tensors."""
+    dbias / dscale given: the kernel ADDS into them (caller-zeroed accumulators) instead of fresh zero tensors.
+    qv_grads = (dq_bias, dv_bias) fp32 [c] with want_colsum: the kernel adds the q / v column sums straight into these gradient
+    accumulators (no [3c] temporary, no add passes) and the fourth result is True."""
     c = qkv.shape[1] // 3
     dqkv = torch.empty_like(qkv)
     dbias = torch.zeros_like(bias) if dbias is None else dbias
@@ -686,6 +692,12 @@ def winattn_bwd(qkv, dout, bias, scale, b, h, w, heads, ws=7, shift=0, want_cols
     if want_colsum:
         if qkv.dtype != torch.bfloat16 or not lib().frhip_set_winattn_mfma(-1):
             return winattn_bwd(qkv, dout, bias, scale, b, h, w, heads, ws, shift, dbias=dbias, dscale=dscale) + (None,)
+        if qv_grads is not None:
+            gq, gv = qv_grads
+            assert gq.dtype == gv.dtype == torch.float32 and gq.numel() == gv.numel() == c and gq.is_contiguous() and gv.is_contiguous()
+            check(lib().frhip_winattn_bwd_qvbias(dt_of(qkv), _p(qkv), _p(dout), _p(bias), _p(scale), _p(dqkv), _p(dbias), _p(dscale),
+                                                 _p(gq), _p(gv), b, h, w, c, heads, ws, shift, _s()), "frhip_winattn_bwd_qvbias")
+            return dqkv, dbias, dscale, True
         colsum = torch.zeros(3 * c, dtype=torch.float32, device=qkv.device)
         check(lib().frhip_winattn_bwd_colsum(dt_of(qkv), _p(qkv), _p(dout), _p(bias), _p(scale), _p(dqkv), _p(dbias), _p(dscale),
                                              _p(colsum), b, h, w, c, heads, ws, shift, _s()), "frhip_winattn_bwd_colsum")

@@ -138,12 +138,14 @@ def attn_block_backward(blk, s, dout, dt, bc):
     bc.on_side(lambda: ops.gemm_tn(dpo, s.ao, G(at.proj.weight)), dpo, s.ao)
     dao = ops.gemm_nt(dpo, _S._transposed(s.wproj, s.wproj_t))
     dqkv, _, _, gsum = ops.winattn_bwd(s.qkv, dao, s.bias, s.scale, b, h, w, at.num_heads, blk.window_size,
-                                       blk.shift_size, want_colsum=True, dbias=s.dbias, dscale=s.dscale)
+                                       blk.shift_size, want_colsum=True, dbias=s.dbias, dscale=s.dscale,
+                                       qv_grads=(G(at.q_bias), G(at.v_bias)))
     if gsum is None:                                 # fp32 validation kernels: column sums by a ones-GEMM
         gsum = torch.zeros(3 * c, dtype=torch.float32, device=dout.device)
         _S._colsum_via_gemm(dqkv, gsum)
-    G(at.q_bias).add_(gsum[:c])
-    G(at.v_bias).add_(gsum[2 * c:])
+    if gsum is not True:                             # bf16 MFMA kernel: already added into the two gradient accumulators
+        G(at.q_bias).add_(gsum[:c])
+        G(at.v_bias).add_(gsum[2 * c:])
     bc.on_side(lambda: ops.gemm_tn(dqkv, s.x2, G(at.qkv.weight)), dqkv, s.x2)
     dx = _S._dgrad_add(dqkv, s.wqkv, d2, s.wqkv_t)
     _S.position_bias_backward(blk, s, bc)

@@ -322,8 +322,7 @@ def swin_block_backward(blk, s, dout, dt, bc, next_bn=None, part3=None):
     # * sum xhat) = 0); the reference gets 1e-8-sized round-off there.  Left at the arena's zero: no reduction pass.
     bc.on_side(lambda: ops.gemm_tn(dmo, s.act, G(blk.mlp.fc2.weight).view(c, 4 * c)), dmo, s.act)
     # [M, 4C]: fc2's data-gradient with gelu'(hid) and fc1.bias's gradient (column sums) fused into its epilogue
-    dhid, db1 = ops.linear_dgrad_gelu(dmo, _transposed(s.w2, s.w2_t), s.hid)
-    G(blk.mlp.fc1.bias).add_(db1)
+    dhid, _ = ops.linear_dgrad_gelu(dmo, _transposed(s.w2, s.w2_t), s.hid, colsum_into=G(blk.mlp.fc1.bias))
     bc.on_side(lambda: ops.gemm_tn(dhid, s.x1, G(blk.mlp.fc1.weight).view(4 * c, c)), dhid, s.x1)
     # dx1 is the upstream gradient of norm2: its backward reduction over (dx1, po) rides in this data-gradient's epilogue
     dx1, part2 = _dgrad_add(dhid, s.w1, d2, s.w1_t, bnred=(s.po, s.st2, False))
@@ -332,12 +331,14 @@ def swin_block_backward(blk, s, dout, dt, bc, next_bn=None, part3=None):
     bc.on_side(lambda: ops.gemm_tn(dpo, s.ao, G(at.proj.weight)), dpo, s.ao)
     dao = ops.gemm_nt(dpo, _transposed(s.wproj, s.wproj_t))
     dqkv, _, _, gsum = ops.winattn_bwd(s.qkv, dao, s.bias, s.scale, b, h, w, at.num_heads, want_colsum=True,
-                                       dbias=s.dbias, dscale=s.dscale)      # d(bias), d(scale) accumulate in the batch's arena
+                                       dbias=s.dbias, dscale=s.dscale,      # d(bias), d(scale) accumulate in the batch's arena
+                                       qv_grads=(G(at.q_bias), G(at.v_bias)))
     if gsum is None:                                 # fp32 validation kernels: column sums by a ones-GEMM
         gsum = torch.zeros(3 * c, dtype=torch.float32, device=dout.device)
         _colsum_via_gemm(dqkv, gsum)
-    G(at.q_bias).add_(gsum[:c])
-    G(at.v_bias).add_(gsum[2 * c:])
+    if gsum is not True:                             # bf16 MFMA kernel: already added into the two gradient accumulators
+        G(at.q_bias).add_(gsum[:c])
+        G(at.v_bias).add_(gsum[2 * c:])
     bc.on_side(lambda: ops.gemm_tn(dqkv, s.x2, G(at.qkv.weight)), dqkv, s.x2)
     part = None
     if next_bn is not None:

@@ -342,6 +342,11 @@ int frhip_winattn_bwd(int dtype, const void* qkv, const void* dout, const float*
 int frhip_winattn_bwd_colsum(int dtype, const void* qkv, const void* dout, const float* bias, const float* scale,
                              void* dqkv, float* dbias, float* dscale, float* dqkv_colsum, int b, int h, int w, int c,
                              int heads, int ws, int shift, frhip_stream_t stream);
+/* frhip_winattn_bwd_colsum with the q third of the column sums added into dq_bias[c] and the v third into dv_bias[c] (fp32
+ * gradient accumulators of q_bias / v_bias, nets/SwinV2.py:150-154; either may be NULL); the k third is not formed */
+int frhip_winattn_bwd_qvbias(int dtype, const void* qkv, const void* dout, const float* bias, const float* scale,
+                             void* dqkv, float* dbias, float* dscale, float* dq_bias, float* dv_bias, int b, int h, int w,
+                             int c, int heads, int ws, int shift, frhip_stream_t stream);
 /* 1 (default): bf16 calls run the MFMA-tile kernels (bf16 GEMM operands, fp32 scores / softmax -- the reference's autocast
  * numerics); 0: the fp32-arithmetic VALU kernels for every dtype.  Negative: query.  Returns the old value */
 int frhip_set_winattn_mfma(int enabled);

@@ -85,6 +85,39 @@ def test_fp8_conv_matches_dequantised_reference(shape):
     np.testing.assert_allclose(s2.numpy(), got.flatten(0, 2).pow(2).sum(0).numpy(), rtol=2e-3)
 
 
+def test_fp8_lean_epilogue_is_bit_identical_to_the_general_one():
+    """fp8 launches made of whole tiles take the lean store epilogue of the bf16 kernels (igemm_nt.h; frhip_set_epi_lean): stored
+    values must be the bits of the general epilogue, the BatchNorm partials (matrix pipe against VALU) agree to fp32 summation order."""
+    from frhip import ops
+    from frhip._abi import lib
+    x = torch.relu(recipe.normal(9741, (64, 16, 16, 256))).cuda().bfloat16()
+    x8 = ops.quant_fp8(x)
+    w3, s3 = ops.quant_fp8_weights(recipe.normal(9742, (256, 3, 3, 256), 0.05).cuda())
+    w1, s1 = ops.quant_fp8_weights(recipe.normal(9743, (512, 1, 1, 256), 0.05).cuda())
+    bias = recipe.normal(9744, (512,), 0.1).cuda()
+    a8 = x8.view(-1, 256)
+    res = {}
+    for lean in (0, 1):
+        old = lib().frhip_set_epi_lean(lean)
+        try:
+            res[lean] = [ops.conv_fwd_fp8(x8, w3, s3, 1, 1, want_stats=True),          # LDS-halo kernel
+                         ops.conv_fwd_fp8(x8, w1, s1, 1, 0, want_stats=True),          # 256 x 256 tile
+                         ops.linear_fwd_fp8(a8, w1.view(512, 256), s1, bias=bias)]
+        finally:
+            lib().frhip_set_epi_lean(old)
+    for i, ((y0, p0), (y1, p1)) in enumerate(zip(res[0], res[1])):
+        assert torch.equal(y0, y1), i
+        if p0 is None:
+            assert p1 is None
+            continue
+        assert p0.shape == p1.shape
+        d = y1.double().view(-1, y1.shape[-1])
+        want = torch.stack([d.sum(0), (d * d).sum(0)])
+        e0 = (p0.double().sum(0) - want).abs().max()
+        e1 = (p1.double().sum(0) - want).abs().max()
+        assert float(e1) <= 4 * float(e0) + 1e-6 * float((d * d).sum(0).max()), (i, float(e0), float(e1))
+
+
 def test_fp8_linear_and_bn_apply_q8():
     from frhip import ops
     m, k, n = 300, 256, 384
