@@ -71,8 +71,9 @@ __global__ __launch_bounds__(256) void cpb_gather_kernel(const frhip_cpb_block* 
 //      One workgroup per (block, head); thread e walks all positions in order (deterministic, no atomics); the index table
 //      sits in LDS.  Also d logit_scale.
 __global__ __launch_bounds__(256) void cpb_dt_kernel(const frhip_cpb_block* __restrict__ blocks, float* __restrict__ dt_all, int t_stride) {
-    __shared__ unsigned char idx_lds[49 * 49];
-    __shared__ float g_lds[49 * 49];
+    constexpr int NNP = (49 * 49 + 15) / 16 * 16;                  // positions padded to whole 16-element vectors (zero gradient)
+    __shared__ __attribute__((aligned(16))) unsigned char idx_lds[NNP];
+    __shared__ __attribute__((aligned(16))) float g_lds[NNP];
     const frhip_cpb_block& d = blocks[blockIdx.y];
     const int h = blockIdx.x;
     if (h >= d.heads) return;
@@ -80,16 +81,34 @@ __global__ __launch_bounds__(256) void cpb_dt_kernel(const frhip_cpb_block* __re
     const int64_t* index = reinterpret_cast<const int64_t*>(d.index);
     const float* bias = reinterpret_cast<const float*>(d.bias) + (size_t)h * nn;
     const float* dbias = reinterpret_cast<const float*>(d.dbias) + (size_t)h * nn;
-    for (int p = threadIdx.x; p < nn; p += 256) {
-        idx_lds[p] = (unsigned char)index[p];
-        const float s = bias[p] * (1.f / 16.f);
-        g_lds[p] = dbias[p] * 16.f * s * (1.f - s);
+    const int nnp = (nn + 15) & ~15;
+    for (int p = threadIdx.x; p < nnp; p += 256) {
+        if (p < nn) {
+            idx_lds[p] = (unsigned char)index[p];
+            const float s = bias[p] * (1.f / 16.f);
+            g_lds[p] = dbias[p] * 16.f * s * (1.f - s);
+        } else {
+            idx_lds[p] = 0; g_lds[p] = 0.f;
+        }
     }
     __syncthreads();
+    // every thread reads the same LDS address (broadcast): 16 positions per trip from one 16-byte index read and four 16-byte
+    // gradient reads, four independent partial sums (a scalar walk here was latency-bound: 160 us for Swin34's ten blocks)
     for (int e = threadIdx.x; e < d.entries; e += 256) {
-        float acc = 0.f;
-        for (int p = 0; p < nn; ++p) acc += idx_lds[p] == e ? g_lds[p] : 0.f;
-        dt_all[(size_t)blockIdx.y * t_stride + e * d.heads + h] = acc;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        for (int p = 0; p < nnp; p += 16) {
+            const u32x4_t iv = *reinterpret_cast<const u32x4_t*>(idx_lds + p);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4_t gv = *reinterpret_cast<const f32x4_t*>(g_lds + p + 4 * q);
+                const uint32_t w = iv[q];
+                a0 += (int)(w & 0xff) == e ? gv[0] : 0.f;
+                a1 += (int)((w >> 8) & 0xff) == e ? gv[1] : 0.f;
+                a2 += (int)((w >> 16) & 0xff) == e ? gv[2] : 0.f;
+                a3 += (int)(w >> 24) == e ? gv[3] : 0.f;
+            }
+        }
+        dt_all[(size_t)blockIdx.y * t_stride + e * d.heads + h] = (a0 + a1) + (a2 + a3);
     }
     if (threadIdx.x == 0) {
         const float ls = reinterpret_cast<const float*>(d.logit_scale)[h];
@@ -104,17 +123,20 @@ __global__ __launch_bounds__(256) void cpb_dt_kernel(const frhip_cpb_block* __re
 __global__ __launch_bounds__(256) void cpb_param_kernel(const frhip_cpb_block* __restrict__ blocks, const float* __restrict__ dt_all,
                                                         int t_stride) {
     __shared__ float red[4][64][CPB_MAX_HEADS + 3];
+    __shared__ float dt_lds[CPB_MAX_T * CPB_MAX_HEADS];            // the block's dt table: broadcast LDS reads in the entry loop
     const frhip_cpb_block& d = blocks[blockIdx.y];
     const int jl = threadIdx.x & 63, el = threadIdx.x >> 6;
     const int j = blockIdx.x * 64 + jl;
     const float* tab = reinterpret_cast<const float*>(d.coords);
     const float* dt = dt_all + (size_t)blockIdx.y * t_stride;
     const float* w2 = reinterpret_cast<const float*>(d.w2);
+    for (int i = threadIdx.x; i < d.entries * d.heads; i += 256) dt_lds[i] = dt[i];
     const float wa = reinterpret_cast<const float*>(d.w0)[2 * j], wb = reinterpret_cast<const float*>(d.w0)[2 * j + 1];
     const float bb = reinterpret_cast<const float*>(d.b0)[j];
-    float gw2[CPB_MAX_HEADS];
+    float gw2[CPB_MAX_HEADS], w2r[CPB_MAX_HEADS];
 #pragma unroll
-    for (int h = 0; h < CPB_MAX_HEADS; ++h) gw2[h] = 0.f;
+    for (int h = 0; h < CPB_MAX_HEADS; ++h) { gw2[h] = 0.f; w2r[h] = h < d.heads ? w2[h * CPB_HIDDEN + j] : 0.f; }
+    __syncthreads();
     float g0 = 0.f, g1 = 0.f, gb = 0.f;
     for (int e = el; e < d.entries; e += 4) {
         const float c0 = tab[2 * e], c1 = tab[2 * e + 1];
@@ -124,9 +146,9 @@ __global__ __launch_bounds__(256) void cpb_param_kernel(const frhip_cpb_block* _
 #pragma unroll
         for (int h = 0; h < CPB_MAX_HEADS; ++h) {
             if (h < d.heads) {
-                const float dth = dt[e * d.heads + h];
+                const float dth = dt_lds[e * d.heads + h];
                 gw2[h] = fmaf(dth, hid, gw2[h]);
-                dh = fmaf(dth, w2[h * CPB_HIDDEN + j], dh);
+                dh = fmaf(dth, w2r[h], dh);
             }
         }
         if (pre > 0.f) { g0 = fmaf(dh, c0, g0); g1 = fmaf(dh, c1, g1); gb += dh; }
