@@ -43,6 +43,30 @@ __global__ __launch_bounds__(256) void quant_w8_kernel(const float* __restrict__
     }
 }
 
+// the same for every weight tensor of a step in one launch: one workgroup per output channel of the whole list, the tensor found by
+// a scan of the (short) table of first rows.  44 launches of 4.5 us each became one in the AlterNet50 fp8 step.
+__global__ __launch_bounds__(256) void quant_w8_multi_kernel(const frhip_q8w* __restrict__ table, int ntensors) {
+    __shared__ float red[256];
+    int t = 0;
+    while (t + 1 < ntensors && (int)blockIdx.x >= table[t + 1].row_begin) ++t;
+    const frhip_q8w d = table[t];
+    const int r = (int)blockIdx.x - d.row_begin;
+    const float* row = d.w + (size_t)r * d.rowlen;
+    float amax = 0.f;
+    for (int i = threadIdx.x; i < d.rowlen; i += 256) amax = fmaxf(amax, fabsf(row[i]));
+    red[threadIdx.x] = amax;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) { if ((int)threadIdx.x < s) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + s]); __syncthreads(); }
+    amax = red[0];
+    const float sc = amax > 0.f ? amax / FP8_MAX : 1.f, inv = 1.f / sc;
+    if (threadIdx.x == 0) d.scale[r] = sc;
+    uint32_t* o = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(d.w8) + (size_t)r * d.rowlen);
+    for (int i = threadIdx.x; i < d.rowlen / 4; i += 256) {
+        const f32x4_t v = *reinterpret_cast<const f32x4_t*>(row + 4 * i);
+        o[i] = pack4_fp8(v[0] * inv, v[1] * inv, v[2] * inv, v[3] * inv);
+    }
+}
+
 // Debug counter of saturated activations: pack4_fp8 clamps at +-448 without a trace, and the activation scale is a static
 // 1.0.  frhip_fp8_saturation(1) arms it: the activation quantisers then count the elements whose magnitude exceeds e4m3's range before
 // the clamp (one atomic per thread that saw any); production runs pass a null pointer and pay nothing.
@@ -290,6 +314,12 @@ extern "C" int frhip_quant_fp8_weights(const float* w, void* w8, float* scale, i
     if (k <= 0 || rowlen <= 0 || (rowlen % 4)) { set_error("frhip_quant_fp8_weights: bad shape k=%d rowlen=%d", k, rowlen); return FRHIP_EINVAL; }
     hipLaunchKernelGGL(quant_w8_kernel, dim3(k), dim3(256), 0, stream, w, (uint8_t*)w8, scale, rowlen);
     return check_launch("frhip_quant_fp8_weights");
+}
+
+extern "C" int frhip_quant_fp8_weights_multi(const frhip_q8w* table, int ntensors, int nrows, hipStream_t stream) {
+    if (!table || ntensors <= 0 || nrows <= 0) { set_error("frhip_quant_fp8_weights_multi: empty table"); return FRHIP_EINVAL; }
+    hipLaunchKernelGGL(quant_w8_multi_kernel, dim3(nrows), dim3(256), 0, stream, table, ntensors);
+    return check_launch("frhip_quant_fp8_weights_multi");
 }
 
 extern "C" int frhip_quant_fp8(int dtype, const void* x, void* x8, size_t n, float inv_scale, hipStream_t stream) {

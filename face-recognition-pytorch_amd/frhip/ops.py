@@ -763,6 +763,41 @@ def quant_fp8_weights(w_f32):
     return w8, scale
 
 
+_Q8W = {}
+
+
+def quant_fp8_weights_multi(weights):
+    """list of fp32 [K, ...] (physical, contiguous) weights -> [(fp8 bytes of the same shape, fp32 scale [K])], one launch into
+    arenas that are reused from step to step (the pointer table is cached, like prep_conv_weights)"""
+    import numpy as np
+    key = tuple(w.data_ptr() for w in weights)
+    hit = _Q8W.get(key)
+    if hit is None:
+        dev = weights[0].device
+        bytes8 = torch.empty(sum(w.numel() for w in weights), dtype=torch.uint8, device=dev)
+        scales = torch.empty(sum(w.shape[0] for w in weights), dtype=torch.float32, device=dev)
+        dt = np.dtype([("w", "<u8"), ("w8", "<u8"), ("scale", "<u8"), ("k", "<i4"), ("rowlen", "<i4"), ("row_begin", "<i4"), ("pad", "<i4")])
+        tab = np.zeros(len(weights), dtype=dt)
+        outs, off, rows = [], 0, 0
+        for i, w in enumerate(weights):
+            assert w.is_cuda and w.dtype == torch.float32 and w.is_contiguous()
+            k, n = w.shape[0], w.numel()
+            assert (n // k) % 4 == 0 and off % 4 == 0
+            w8 = bytes8[off:off + n].view(w.shape)
+            sc = scales[rows:rows + k]
+            tab[i] = (w.data_ptr(), w8.data_ptr(), sc.data_ptr(), k, n // k, rows, 0)
+            off += n
+            rows += k
+            outs.append((w8, sc))
+        table = torch.from_numpy(tab.view(np.uint8).copy()).to(dev)
+        if len(_Q8W) >= 8:
+            _Q8W.clear()
+        hit = _Q8W[key] = (table, len(weights), rows, outs, bytes8, scales, list(weights))
+    table, n, rows, outs = hit[:4]
+    check(lib().frhip_quant_fp8_weights_multi(_p(table), n, rows, _s()), "frhip_quant_fp8_weights_multi")
+    return outs
+
+
 def quant_fp8(x, inv_scale=1.0 / FP8_ACT_SCALE):
     x8 = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
     check(lib().frhip_quant_fp8(dt_of(x), _p(x), _p(x8), x.numel(), inv_scale, _s()), "frhip_quant_fp8")

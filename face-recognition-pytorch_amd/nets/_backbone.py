@@ -488,9 +488,8 @@ class Fp8Ctx:
     the fp8 copy of the activation tensor the last fused BatchNorm-apply pass wrote (the operand of the next GEMM)."""
 
     def __init__(self, weights):
-        self.packs = {}
-        for mod, w in weights:                         # w: fp32, physical [K, ...] with the reduction dims contiguous
-            self.packs[mod] = ops.quant_fp8_weights(w)
+        weights = list(weights)                        # w: fp32, physical [K, ...] with the reduction dims contiguous
+        self.packs = dict(zip([m for m, _ in weights], ops.quant_fp8_weights_multi([w for _, w in weights]))) if weights else {}
         self._of, self._x8 = None, None
 
     @staticmethod

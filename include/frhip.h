@@ -264,6 +264,10 @@ int frhip_conv_wgrad_bnrelu(int dtype, const void* dy, const void* x, const floa
  * e4m3 on v_mfma_scale_f32_16x16x128_f8f6f4; bf16 output = fp32 accumulator x act_scale x w_scale[k] ---- */
 /* w [k][rowlen] fp32 (a conv weight in its physical [K][R][S][C] order) -> w8 fp8 + scale[k] = amax(row) / 448 */
 int frhip_quant_fp8_weights(const float* w, void* w8, float* scale, int k, int rowlen, frhip_stream_t stream);
+/* the same for all weight tensors of a step in ONE launch (the weights change every optimizer step, model/FR_PartialFC.py:166-170):
+ * row_begin = number of output rows of the tensors before this one, nrows = the total; rowlen % 4 == 0.  Table in device memory */
+typedef struct { const float* w; void* w8; float* scale; int32_t k, rowlen, row_begin, pad_; } frhip_q8w;
+int frhip_quant_fp8_weights_multi(const frhip_q8w* table, int ntensors, int nrows, frhip_stream_t stream);
 /* debug counter of SATURATED activations in the fp8 quantisers (frhip_quant_fp8, frhip_bn_apply_q8 clamp at +-448 silently; the
  * activation scale is static): op 1 zeroes and arms it, op 0 disarms, op 2 returns the number of elements that exceeded e4m3's range
  * since it was armed (synchronises the device; capped at INT_MAX).  Process-global test hook, outside the threading contract */

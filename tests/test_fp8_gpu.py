@@ -54,6 +54,20 @@ def test_weight_quantisation_roundtrip():
     assert bool((err <= bound * 1.001).all())
 
 
+def test_weight_quantisation_of_a_list_in_one_launch():
+    """frhip_quant_fp8_weights_multi == frhip_quant_fp8_weights per tensor, bit for bit; a second call re-reads the (updated) weights"""
+    from frhip import ops
+    ws = [recipe.normal(9750 + i, sh, 0.05).cuda() for i, sh in enumerate([(96, 3, 3, 128), (256, 128), (8, 1, 1, 384), (130, 3, 3, 256)])]
+    ws[1][7] = 0.0
+    for rep in range(2):
+        multi = ops.quant_fp8_weights_multi(ws)
+        for w, (w8, sc) in zip(ws, multi):
+            r8, rs = ops.quant_fp8_weights(w)
+            assert w8.shape == w.shape and torch.equal(w8, r8) and torch.equal(sc, rs)
+        for w in ws:
+            w.mul_(1.7).add_(0.01)                       # an optimizer step in place: same storage, same cached table
+
+
 @pytest.mark.parametrize("shape", [(2, 12, 12, 128, 256, 3, 1), (3, 24, 24, 128, 128, 3, 2), (2, 12, 12, 256, 512, 1, 2),
                                    (64, 14, 14, 256, 256, 3, 1), (5, 7, 9, 384, 72, 3, 1)])
 def test_fp8_conv_matches_dequantised_reference(shape):
