@@ -258,9 +258,37 @@ __global__ __launch_bounds__(256) void iso_noise_kernel(const uint8_t* __restric
     }
 }
 
+// Dropout mask of the backbones' tail (reference nets/SwinV2.py:559, nets/AlterNet_SwinV2_FAN.py:743: nn.Dropout() before fc):
+// mask[i] = 1 / keep with probability keep, else 0, four elements per Philox call (key = seed, counter = i / 4).  One launch where
+// torch.rand -> compare -> cast -> divide were four passes over the [B, 25 088] tensor.
+template <typename T>
+__global__ __launch_bounds__(256) void dropout_mask_kernel(T* __restrict__ mask, size_t n, float keep, float inv_keep, uint64_t seed) {
+    const size_t n4 = (n + 3) / 4;
+    for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < n4; q += (size_t)gridDim.x * 256) {
+        uint32_t r[4];
+        philox4x32((uint32_t)q, (uint32_t)(q >> 32), (uint32_t)seed, (uint32_t)(seed >> 32), r);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (4 * q + e < n) mask[4 * q + e] = (T)(u01(r[e]) < keep ? inv_keep : 0.f);
+    }
+}
+
 }  // namespace frhip
 
 using namespace frhip;
+
+extern "C" int frhip_dropout_mask(int dtype, void* mask, size_t n, float keep, long long seed, hipStream_t stream) {
+    if (!(keep > 0.f) || keep > 1.f) { set_error("frhip_dropout_mask: keep probability %g outside (0, 1]", (double)keep); return FRHIP_EINVAL; }
+    if (n == 0) return FRHIP_OK;
+    size_t blocks = ((n + 3) / 4 + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    if (dtype == FRHIP_DT_BF16)
+        hipLaunchKernelGGL(dropout_mask_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, stream, (bf16_t*)mask, n, keep, 1.f / keep, (uint64_t)seed);
+    else if (dtype == FRHIP_DT_F32)
+        hipLaunchKernelGGL(dropout_mask_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, stream, (float*)mask, n, keep, 1.f / keep, (uint64_t)seed);
+    else { set_error("frhip_dropout_mask: bad dtype %d", dtype); return FRHIP_EINVAL; }
+    return check_launch("frhip_dropout_mask");
+}
 
 static int augment_run(const uint8_t* in, float* out, const int32_t* flip, const int32_t* holes, const uint8_t* lut, int nholes,
                        int b, int hin, int win, int size, hipStream_t stream) {

@@ -352,6 +352,15 @@ def colsum_accumulate(x2d, out_accum):
     return out_accum
 
 
+def dropout_mask(shape, dtype, keep, device, seed=None):
+    """mask of `shape`: 1/keep with probability keep, else 0 (one launch).  seed None: drawn from torch's CPU generator"""
+    if seed is None:
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+    mask = torch.empty(shape, dtype=dtype, device=device)
+    check(lib().frhip_dropout_mask(_DT[dtype], _p(mask), mask.numel(), float(keep), int(seed), _s()), "frhip_dropout_mask")
+    return mask
+
+
 def add_bias(x, bias):
     check(lib().frhip_add_bias(_p(x), _p(bias), x.shape[0], x.shape[1], _s()), "frhip_add_bias")
     return x

@@ -244,7 +244,7 @@ class AlterNet(nn.Module):
         mask = None
         if training and self.dropout.p > 0:
             keep = 1.0 - self.dropout.p
-            mask = (torch.rand(cur.shape, device=cur.device) < keep).to(cur.dtype) / keep
+            mask = ops.dropout_mask(cur.shape, cur.dtype, keep, cur.device)
         emb = tail_forward(self, cur, training, sv, dropout_mask=mask, relu=True)
         if save:
             sv.layers = saved

@@ -408,6 +408,11 @@ int frhip_stem_bwd_wgrad_gram(int dtype, const float* x, const void* wp, const v
 typedef struct { const float* w; void* wc; void* wt; int32_t k, rs, c, tile_begin; } frhip_wprep;
 int frhip_prep_conv_weights(int dtype, const frhip_wprep* table, int ntensors, int ntiles, frhip_stream_t stream);
 
+/* Dropout mask of the backbone tails (nn.Dropout() before fc: nets/SwinV2.py:559, nets/AlterNet_SwinV2_FAN.py:743): mask[i] = 1/keep
+ * with probability keep, else 0, in `dtype`; Philox-4x32-10, key = seed, counter = i / 4 (same seed -> same mask).  The caller draws
+ * the seed from torch's generator, so torch.manual_seed still pins a run */
+int frhip_dropout_mask(int dtype, void* mask, size_t n, float keep, long long seed, frhip_stream_t stream);
+
 /* ---- device input pipeline: Resize -> HorizontalFlip -> Normalize(0.5,0.5) -> CoarseDropout -> CHW fp32 of the reference's
  * albumentations chain (utils/data_partial.py:134-164) in one kernel.  in: uint8 [b,hin,win,3] (HWC, device);
  * out: fp32 [b,3,size,size]; flip: int32 [b] (may be NULL); holes: int32 [b][nholes][4] = x1,y1,x2,y2 in output

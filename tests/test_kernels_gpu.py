@@ -645,3 +645,31 @@ def test_batchnorm_passes_with_a_per_sample_scale(dtype):
     np.testing.assert_allclose(dg.cpu().numpy(), dg2.cpu().numpy(), **t)
     np.testing.assert_allclose(db.cpu().numpy(), db2.cpu().numpy(), **t)
     np.testing.assert_allclose(dy.float().cpu().numpy(), dy2.float().cpu().numpy(), **tol(dtype, 3.0))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_dropout_mask_kernel(dtype):
+    """frhip_dropout_mask: values are exactly 0 or 1/keep, the kept fraction is keep to binomial accuracy, a seed pins the mask,
+    different seeds and neighbouring elements are uncorrelated, odd lengths are filled to the end"""
+    ops = _ops()
+    n = 512 * 25088 + 3
+    for keep in (0.5, 0.8):
+        m = ops.dropout_mask((n,), dtype, keep, "cuda", seed=1234)
+        inv = torch.tensor(1.0 / keep, dtype=dtype).item()
+        kept = m != 0
+        assert bool(((m == 0) | (m == inv)).all())
+        frac = float(kept.float().mean())
+        assert abs(frac - keep) < 5 * (keep * (1 - keep) / n) ** 0.5, frac
+        assert torch.equal(m, ops.dropout_mask((n,), dtype, keep, "cuda", seed=1234))
+        other = ops.dropout_mask((n,), dtype, keep, "cuda", seed=1235) != 0
+        both = float((kept & other).float().mean())
+        assert abs(both - keep * keep) < 2e-3, both
+        lag = float((kept[1:] & kept[:-1]).float().mean())
+        assert abs(lag - keep * keep) < 2e-3, lag
+        assert bool(kept[-3:].any() | ~kept[-3:].any())          # the tail elements were written (no NaN garbage)
+        assert bool(torch.isfinite(m[-3:].float()).all())
+    torch.manual_seed(7)
+    a = ops.dropout_mask((4, 8), dtype, 0.5, "cuda")
+    torch.manual_seed(7)
+    assert torch.equal(a, ops.dropout_mask((4, 8), dtype, 0.5, "cuda"))          # torch.manual_seed pins the drawn seed
+
