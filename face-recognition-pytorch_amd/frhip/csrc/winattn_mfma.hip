@@ -56,18 +56,22 @@ __device__ __forceinline__ bf16x4_t wm_pack4(const f32x4_t& a) {
 __device__ __forceinline__ float wm_sum4g(float x) { return lane_sum_bit5(lane_sum_bit4(x)); }      // over the four lane groups
 __device__ __forceinline__ float wm_max4g(float x) { return lane_max_bit5(lane_max_bit4(x)); }      // (same lane & 15)
 
-// One token row (32 bf16) per lane: load, optionally l2-normalise, park in the LDS tile.  Returns 1 / max(|x|, eps).
-__device__ __forceinline__ float wm_stage_row(const bf16_t* src, char* tile, int lane, bool active, bool normalise) {
-    bf16x8_t v[4];
+// One token row (32 bf16) per lane: load (wm_load_row), then optionally l2-normalise and park in the LDS tile (wm_park_row; returns
+// 1 / max(|x|, eps)).  The two halves are separate so that the NEXT window's rows can be in flight while this one is computed: one wave
+// per SIMD (backward) has nothing else to cover the HBM latency with.
+struct WmRow { bf16x8_t v[4]; };
+__device__ __forceinline__ void wm_load_row(const bf16_t* src, WmRow& r) {
 #pragma unroll
-    for (int c = 0; c < 4; ++c) v[c] = *reinterpret_cast<const bf16x8_t*>(src + 8 * c);
+    for (int c = 0; c < 4; ++c) r.v[c] = *reinterpret_cast<const bf16x8_t*>(src + 8 * c);
+}
+__device__ __forceinline__ float wm_park_row(const WmRow& r, char* tile, int lane, bool active, bool normalise) {
     float inv = 1.f;
     if (normalise) {
         float nn = 0.f;
 #pragma unroll
         for (int c = 0; c < 4; ++c)
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { const float x = (float)v[c][e]; nn += x * x; }
+            for (int e = 0; e < 8; ++e) { const float x = (float)r.v[c][e]; nn += x * x; }
         inv = 1.f / fmaxf(sqrtf(nn), 1e-12f);
     }
     const float mul = active ? inv : 0.f;                        // padding tokens become zero rows
@@ -75,7 +79,7 @@ __device__ __forceinline__ float wm_stage_row(const bf16_t* src, char* tile, int
     for (int c = 0; c < 4; ++c) {
         bf16x8_t o;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = (bf16_t)((float)v[c][e] * mul);
+        for (int e = 0; e < 8; ++e) o[e] = (bf16_t)((float)r.v[c][e] * mul);
         *reinterpret_cast<bf16x8_t*>(tile + lane * WM_ROW + 16 * c) = o;
     }
     return inv;
@@ -166,16 +170,23 @@ __global__ __launch_bounds__(256, 2) void wm_fwd_kernel(const bf16_t* __restrict
     const bool active = lane < n;
     const int tok = active ? lane : 0;
     const int w_begin = chunk * win_per_block, w_end = min(nwin, w_begin + win_per_block);
+    WmRow nq, nk, nv;                                              // the next window's rows, in flight during this window's compute
+    int nregion = 0;
+    size_t npix = 0;
+    auto fetch = [&](int win) {
+        npix = wa_pixel(win, tok, g, &nregion);
+        const bf16_t* row = qkv + npix * 3 * C + h * WA_D;
+        wm_load_row(row, nq); wm_load_row(row + C, nk); wm_load_row(row + 2 * C, nv);
+    };
+    if (w_begin + wave < w_end) fetch(w_begin + wave);
     for (int win = w_begin + wave; win < w_end; win += 4) {
-        int region;
-        const size_t pix = wa_pixel(win, tok, g, &region);
-        const bf16_t* row = qkv + pix * 3 * C + h * WA_D;
         __builtin_amdgcn_wave_barrier();                           // the previous window's LDS reads are done
-        wm_stage_row(row, qh, lane, active, true);
-        wm_stage_row(row + C, kh, lane, active, true);
-        wm_stage_row(row + 2 * C, vt, lane, active, false);
-        spix[lane] = (int)pix;
-        sreg[lane] = region;
+        wm_park_row(nq, qh, lane, active, true);
+        wm_park_row(nk, kh, lane, active, true);
+        wm_park_row(nv, vt, lane, active, false);
+        spix[lane] = (int)npix;
+        sreg[lane] = nregion;
+        if (win + 4 < w_end) fetch(win + 4);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         f32x4_t st[4][4];
@@ -270,8 +281,25 @@ __global__ __launch_bounds__(256, 1) void wm_bwd_kernel(const bf16_t* __restrict
     const int h = (int)(lin % (uint32_t)heads), chunk = (int)(lin / (uint32_t)heads), n = g.n, grp = lane >> 4, c = lane & 15;
     const float sc = scale[h];
     const bool masked = g.shift > 0;
-    f32x4_t bs[4][4], db[4][4];
-    wm_load_bias(bias + (size_t)h * n * n, n, lane, bs);
+    // the head's bias tile in the score layout sits in LDS ([tile][lane] float4, one copy for the four waves) and is read per window:
+    // as 64 registers held across the loop it left no room for the next window's rows
+    f32x4_t* bs_lds = reinterpret_cast<f32x4_t*>(smem + 4 * WM_BWD_WAVE);
+    {
+        f32x4_t bs0[4][4];
+        wm_load_bias(bias + (size_t)h * n * n, n, lane, bs0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {                              // wave w parks tiles 4w .. 4w+3
+            const int t = 4 * wave + q;
+            f32x4_t v = bs0[0][0];
+#pragma unroll
+            for (int tj = 0; tj < 4; ++tj)
+#pragma unroll
+                for (int ti = 0; ti < 4; ++ti) if (4 * tj + ti == t) v = bs0[tj][ti];
+            bs_lds[t * 64 + lane] = v;
+        }
+    }
+    __syncthreads();
+    f32x4_t db[4][4];
 #pragma unroll
     for (int tj = 0; tj < 4; ++tj)
 #pragma unroll
@@ -285,26 +313,37 @@ __global__ __launch_bounds__(256, 1) void wm_bwd_kernel(const bf16_t* __restrict
     const bool active = lane < n;
     const int tok = active ? lane : 0;
     const int w_begin = chunk * win_per_block, w_end = min(nwin, w_begin + win_per_block);
+    WmRow nq, nk, nv, ng;                                          // the next window's rows, in flight during this window's compute
+    int nregion = 0;
+    size_t npix = 0;
+    auto fetch = [&](int win) {
+        npix = wa_pixel(win, tok, g, &nregion);
+        const bf16_t* row = qkv + npix * 3 * C + h * WA_D;
+        wm_load_row(row, nq); wm_load_row(row + C, nk); wm_load_row(row + 2 * C, nv);
+        wm_load_row(dout + npix * C + h * WA_D, ng);
+    };
+    if (w_begin + wave < w_end) fetch(w_begin + wave);
     for (int win = w_begin + wave; win < w_end; win += 4) {
-        int region;
-        const size_t pix = wa_pixel(win, tok, g, &region);
-        const bf16_t* row = qkv + pix * 3 * C + h * WA_D;
         __builtin_amdgcn_wave_barrier();
-        siq[lane] = wm_stage_row(row, qh, lane, active, true);
-        sik[lane] = wm_stage_row(row + C, kh, lane, active, true);
-        wm_stage_row(row + 2 * C, vt, lane, active, false);
-        wm_stage_row(dout + pix * C + h * WA_D, gt, lane, active, false);
-        spix[lane] = (int)pix;
-        sreg[lane] = region;
+        siq[lane] = wm_park_row(nq, qh, lane, active, true);
+        sik[lane] = wm_park_row(nk, kh, lane, active, true);
+        wm_park_row(nv, vt, lane, active, false);
+        wm_park_row(ng, gt, lane, active, false);
+        spix[lane] = (int)npix;
+        sreg[lane] = nregion;
+        if (win + 4 < w_end) fetch(win + 4);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        f32x4_t st[4][4], cs[4][4];
+        f32x4_t st[4][4];
         wm_scores(kh, qh, lane, st);
+        {
+            f32x4_t bs[4][4];
 #pragma unroll
-        for (int tj = 0; tj < 4; ++tj)
+            for (int tj = 0; tj < 4; ++tj)
 #pragma unroll
-            for (int ti = 0; ti < 4; ++ti) cs[tj][ti] = st[tj][ti];                 // cosines, for d(scale)
-        wm_softmax(st, bs, sc, sreg, masked, lane);
+                for (int ti = 0; ti < 4; ++ti) bs[tj][ti] = bs_lds[(4 * tj + ti) * 64 + lane];
+            wm_softmax(st, bs, sc, sreg, masked, lane);
+        }
         // dPt[j][i] = <v_j, dO_i>
         f32x4_t dp[4][4];
         {
@@ -336,10 +375,18 @@ __global__ __launch_bounds__(256, 1) void wm_bwd_kernel(const bf16_t* __restrict
                     const float ds = st[tj][ti][r] * (dp[tj][ti][r] - rd);
                     dp[tj][ti][r] = ds;
                     db[tj][ti][r] += ds;
-                    dsc += ds * cs[tj][ti][r];
                 }
             }
         }
+        // d(scale) += sum dS o cosines: the cosines are formed again (16 MFMAs) into the registers P has just left, instead of a copy
+        // kept across the softmax (64 registers that now hold the next window's rows)
+        wm_scores(kh, qh, lane, st);
+#pragma unroll
+        for (int tj = 0; tj < 4; ++tj)
+#pragma unroll
+            for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dsc += dp[tj][ti][r] * st[tj][ti][r];
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         f32x4_t xt[2][4];
@@ -487,7 +534,7 @@ int winattn_mfma_fwd(const void* qkv, const float* bias, const float* scale, voi
 
 int winattn_mfma_bwd(const void* qkv, const void* dout, const float* bias, const float* scale, void* dqkv, float* dbias,
                      float* dscale, const WaColsum& colsum, int nwin, const WaGeom& g, int C, int heads, hipStream_t stream) {
-    const int lds = 4 * WM_BWD_WAVE;
+    const int lds = 4 * WM_BWD_WAVE + 16 * 64 * 16;                  // + the head's bias tile in the score layout
     static bool attr_done = false;
     if (!attr_done) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(wm_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
