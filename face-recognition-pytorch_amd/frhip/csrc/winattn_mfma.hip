@@ -506,6 +506,20 @@ __global__ __launch_bounds__(256, 1) void wm_bwd_kernel(const bf16_t* __restrict
     if (threadIdx.x == 0) atomicAdd(dscale + h, red_s[0] + red_s[1] + red_s[2] + red_s[3]);
 }
 
+// Workgroups per launch.  Every workgroup pays a prologue (bias tile) and, in the backward kernel, an epilogue (four d(bias) tiles folded
+// through LDS, n*n + 96 atomics) that does not depend on how many windows it walked: with 1024 backward workgroups a wave saw four
+// windows and that fixed cost was a third of the launch.  One workgroup per CU (the backward kernel's LDS allows no second one anyway):
+// Swin34 15.93 -> 15.44 ms, AlterNet50 13.11 -> 12.68 ms (same-box A/B over 1024 / 512 / 384 / 256 / 192); forward 4 per CU (-0.05 ms).
+static int wm_cus() {
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        cus = v;
+    }
+    return cus;
+}
+
 static int wm_chunks(int nwin, int heads, int target_wgs, int* wpb_out) {
     int chunks = (target_wgs + heads - 1) / heads;
     int wpb = (nwin + chunks - 1) / chunks;
@@ -526,7 +540,8 @@ int winattn_mfma_fwd(const void* qkv, const float* bias, const float* scale, voi
         attr_done = true;
     }
     int wpb;
-    const int chunks = wm_chunks(nwin, heads, 2048, &wpb);
+    static const int target = getenv("FRHIP_WA_FWD_WGS") ? atoi(getenv("FRHIP_WA_FWD_WGS")) : 4 * wm_cus();
+    const int chunks = wm_chunks(nwin, heads, target, &wpb);
     hipLaunchKernelGGL(wm_fwd_kernel, dim3(heads * chunks), dim3(256), lds, stream, (const bf16_t*)qkv, bias, scale, (bf16_t*)out,
                        nwin, g, C, wpb, heads);
     return check_launch("frhip_winattn_fwd");
@@ -544,7 +559,8 @@ int winattn_mfma_bwd(const void* qkv, const void* dout, const float* bias, const
         attr_done = true;
     }
     int wpb;
-    const int chunks = wm_chunks(nwin, heads, 1024, &wpb);
+    static const int target = getenv("FRHIP_WA_BWD_WGS") ? atoi(getenv("FRHIP_WA_BWD_WGS")) : wm_cus();
+    const int chunks = wm_chunks(nwin, heads, target, &wpb);
     hipLaunchKernelGGL(wm_bwd_kernel, dim3(heads * chunks), dim3(256), lds, stream, (const bf16_t*)qkv, (const bf16_t*)dout, bias,
                        scale, (bf16_t*)dqkv, dbias, dscale, colsum, nwin, g, C, wpb, heads);
     return check_launch("frhip_winattn_bwd");
