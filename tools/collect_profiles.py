@@ -33,7 +33,8 @@ hdr_a = ("# AlterNet50 @192 with the fp8 forward path (BASELINE cfg 5), one trai
          "# rocprofv3 --kernel-trace -- python3 bench.py --network AlterNet50 --fp8 --steps 6 --warmup 3 --no-cpu-baseline ; tools/trace_summary.py\n")
 open(os.path.join(P, TAG + "_final_alternet50_fp8_step_anatomy.txt"), "w").write(hdr_a + open(os.path.join(F, "alt_step_anatomy.txt")).read())
 # MFMA utilisation counters of the dominant kernels (tools/pmc_run.sh: one rocprofv3 --pmc pass per counter group, kernel-trace only)
-with open(os.path.join(P, TAG + "_pmc_mfma_util.txt"), "w") as out:
+have_pmc = any(os.path.exists(os.path.join(F, "pmc_%s.txt" % w)) for w in ("fwd", "dgrad", "wgrad", "wgrad8"))
+with open(os.path.join(P, TAG + "_pmc_mfma_util.txt") if have_pmc else os.devnull, "w") as out:       # QUICK=1 runs keep the committed counters
     out.write("# rocprofv3 --pmc <group> --kernel-trace -- python3 tools/pmc_one.py fwd|dgrad|wgrad 14 256 256   (B = 512, 256-channel 14x14 layer, bf16)\n"
               "# groups: tools/pmc_run.sh.  MFMA utilisation = SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CU_CYCLES / 4 (four SIMDs per CU).\n"
               "# wgrad = the 4-wave co-resident tile the step uses; wgrad8 = the stand-alone-fastest 8-wave tile (FRHIP_T9_NARROW=0).\n")
@@ -71,8 +72,9 @@ for sub in ("fetch", "write"):
     for f in files[:-1]:
         for g in glob.glob(f.replace("_counter_collection.csv", "_*")):
             os.remove(g)
-subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "pmc_traffic_report.py"), os.path.join(ROOT, "gpurun_out", "pmc"), TAG],
-                      stdout=subprocess.DEVNULL)
+if glob.glob(os.path.join(ROOT, "gpurun_out", "pmc", "fetch", "*", "*_counter_collection.csv")):
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "pmc_traffic_report.py"), os.path.join(ROOT, "gpurun_out", "pmc"), TAG],
+                          stdout=subprocess.DEVNULL)
 print(d["value"], d["ms_per_step"], d["roofline"]["frac"], d["roofline"]["avg_launch_us"], d["cpu_baseline"]["value"])
 
 # in-kernel clock, ablation and inference throughput (tools/clock_probe.py, tools/ablate.py, tools/bench_eval.py)

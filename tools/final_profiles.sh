@@ -9,10 +9,15 @@ R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/final
 rm -rf $OUT; mkdir -p $OUT
 cd $R
+# QUICK=1: bench line, kernel stats and the step anatomies only -- for a refresh after changes that did not touch the conv kernels (the
+# committed PMC traffic report still matches their source digest; counters, clock stamps and the ablation are theirs)
+QUICK=${QUICK:-0}
 # PMC traffic passes first: bench.py reports roofline.traffic only from a pass whose kernel-source digest matches this tree
+if [ "$QUICK" = 0 ]; then
 rm -rf $R/gpurun_out/pmc
 bash tools/pmc_traffic.sh > $OUT/pmc.log 2>&1
 python tools/pmc_traffic_report.py gpurun_out/pmc ${TAG:-r03} > $OUT/pmc_report.log 2>&1
+fi
 python bench.py > $OUT/bench.json 2> $OUT/bench.log
 tail -1 $OUT/bench.json | cut -c1-200
 export FRHIP_BENCH_INSTEP=0
@@ -28,6 +33,8 @@ python tools/trace_summary.py $OUT/overlap_trace.csv > $OUT/step_anatomy_overlap
 python tools/trace_summary.py $(ls $OUT/swin/*kernel_trace.csv | head -1) > $OUT/swin_step_anatomy.txt
 python tools/trace_summary.py $(ls $OUT/alt/*kernel_trace.csv | head -1) > $OUT/alt_step_anatomy.txt
 rm -f $OUT/serial/*kernel_trace.csv $OUT/swin/*kernel_trace.csv $OUT/alt/*kernel_trace.csv $OUT/stats/*kernel_trace.csv $OUT/overlap_trace.csv
+python tools/bench_eval.py ResNet50 512 > $OUT/eval.txt 2>&1 || true
+if [ "$QUICK" != 0 ]; then ls $OUT | head -40; exit 0; fi
 # MFMA utilisation / LDS counters of the dominant kernels (256-channel 14x14 layer, B = 512), one rocprofv3 pass per counter group
 for what in fwd dgrad wgrad; do
   bash tools/pmc_run.sh $OUT/pmc_$what $what 14 256 256 > $OUT/pmc_$what.log 2>&1 || true
@@ -40,5 +47,4 @@ rm -rf $OUT/pmc_*/g*      # raw counter CSVs: summarised in pmc_*.txt
 # ablation of the 4-wave halo kernel (`ABL_ONLY=... python tools/ablate.py build`)
 CLOCK_SECS=1.5 python tools/clock_probe.py run > $OUT/clock.txt 2>&1 || true
 ABL_ONLY=full,nobar,nomfma,nodma,noepi,nolds,mfma_only,lds_only python tools/ablate.py run > $OUT/ablate.txt 2>&1 || true
-python tools/bench_eval.py ResNet50 512 > $OUT/eval.txt 2>&1 || true
 ls $OUT | head -40
