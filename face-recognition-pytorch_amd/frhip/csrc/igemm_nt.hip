@@ -17,15 +17,14 @@ int halo_run(int dtype, const void* a, const void* b, void* out, const void* res
 enum { EPI_STORE = 0, EPI_ATOMIC = 1, EPI_SLAB = 2, EPI_LEAN = 3 };    // SLAB: K split y stores its fp32 partial tile to slab y of `out`; LEAN: nt_epilogue_store_lean
 extern int g_epi_lean;      // igemm_halo.hip: frhip_set_epi_lean / FRHIP_EPI_LEAN
 
+// one output tile (logical id t of `total`)
 template <typename T, int WM, int WN, int MT, int EPI>
-__global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void nt_kernel(NtGeom g, const void* __restrict__ a,
-                                                           const void* __restrict__ b, void* __restrict__ out,
-                                                           const void* __restrict__ res, float* __restrict__ stats,
-                                                           EpiBnRed br, int mtiles, int ntiles) {
+__device__ __forceinline__ void nt_tile(const NtGeom& g, const void* __restrict__ a, const void* __restrict__ b, void* __restrict__ out,
+                                        const void* __restrict__ res, float* __restrict__ stats, const EpiBnRed& br, int ntiles,
+                                        uint32_t t, uint32_t total, char* smem) {
     typedef NtTile<T, WM, WN, MT> Tile;
     constexpr int WROWS = Tile::WROWS, THREADS = Tile::THREADS;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const uint32_t lin = xcd_remap(blockIdx.x, gridDim.x);
+    const uint32_t lin = xcd_remap(t, total);
     const int ntile = (int)(lin % (uint32_t)ntiles), mtile = (int)(lin / (uint32_t)ntiles);
     const int ks_begin = blockIdx.y * g.ksteps_per_split;
     const int ks_end = min(g.ksteps, ks_begin + g.ksteps_per_split);
@@ -79,6 +78,42 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void nt_kernel(NtGeom 
     }
 }
 
+// EPI_LEAN launches are PERSISTENT: gridDim.x = one workgroup per CU (this tile's LDS allows no second one) and every workgroup walks the
+// tiles t = blockIdx.x, + gridDim.x, ...  A workgroup that ends cannot free its CU before its stores have drained, and the next one then
+// starts from an empty memory pipeline; in the loop the drain runs under the next tile's first operand loads.  All other epilogues: one
+// tile per workgroup.
+template <typename T, int WM, int WN, int MT, int EPI>
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void nt_kernel(NtGeom g, const void* __restrict__ a,
+                                                           const void* __restrict__ b, void* __restrict__ out,
+                                                           const void* __restrict__ res, float* __restrict__ stats,
+                                                           EpiBnRed br, int mtiles, int ntiles) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const uint32_t total = (uint32_t)(mtiles * ntiles);
+    if constexpr (EPI == EPI_LEAN) {
+        for (uint32_t t = blockIdx.x; t < total; t += gridDim.x) {
+            nt_tile<T, WM, WN, MT, EPI>(g, a, b, out, res, stats, br, ntiles, t, total, smem);
+            if (t + gridDim.x < total) {                     // the epilogue's LDS reads are done before the next tile's operand loads land
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // there; the global stores are NOT waited for
+                __builtin_amdgcn_s_barrier();
+            }
+        }
+    } else {
+        nt_tile<T, WM, WN, MT, EPI>(g, a, b, out, res, stats, br, ntiles, blockIdx.x, total, smem);
+    }
+}
+
+// FRHIP_NT_PERSIST=0: one workgroup per tile also for the lean launches (A/B switch)
+static const int g_nt_persist = getenv("FRHIP_NT_PERSIST") ? atoi(getenv("FRHIP_NT_PERSIST")) : 1;
+static int nt_cus() {
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        cus = v;
+    }
+    return cus;
+}
+
 template <typename T, int WM, int WN, int MT, int EPI>
 static int nt_launch_cfg(const NtGeom& g, const void* a, const void* b, void* out, const void* res,
                          float* stats, const EpiBnRed& br, int splits, hipStream_t stream) {
@@ -95,6 +130,10 @@ static int nt_launch_cfg(const NtGeom& g, const void* a, const void* b, void* ou
         attr_done = true;
     }
     dim3 grid(mtiles * ntiles, splits);
+    if (EPI == EPI_LEAN && g_nt_persist) {
+        const unsigned wgs = (unsigned)nt_cus() & ~7u;         // a multiple of 8: a workgroup's tiles stay on its XCD's share of the remap
+        if (wgs >= 8 && grid.x > wgs) grid.x = wgs;
+    }
     hipLaunchKernelGGL(kern, grid, dim3(Tile::THREADS), lds, stream, g, a, b, out, res, stats, br, mtiles, ntiles);
     return check_launch("igemm_nt");
 }
