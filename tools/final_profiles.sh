@@ -10,10 +10,11 @@ OUT=$R/gpurun_out/final
 rm -rf $OUT; mkdir -p $OUT
 cd $R
 # QUICK=1: bench line, kernel stats and the step anatomies only -- for a refresh after changes that did not touch the conv kernels (the
-# committed PMC traffic report still matches their source digest; counters, clock stamps and the ablation are theirs)
+# committed PMC traffic report still matches their source digest; counters, clock stamps and the ablation are theirs).
+# QUICK=2: the same plus the PMC traffic passes (a change in igemm_nt* / igemm_halo* / common.h moves the digest bench.py checks)
 QUICK=${QUICK:-0}
 # PMC traffic passes first: bench.py reports roofline.traffic only from a pass whose kernel-source digest matches this tree
-if [ "$QUICK" = 0 ]; then
+if [ "$QUICK" != 1 ]; then
 rm -rf $R/gpurun_out/pmc
 bash tools/pmc_traffic.sh > $OUT/pmc.log 2>&1
 python tools/pmc_traffic_report.py gpurun_out/pmc ${TAG:-r03} > $OUT/pmc_report.log 2>&1
