@@ -47,6 +47,12 @@ __device__ __forceinline__ bf16x8_t wm_pack(const f32x4_t& a, const f32x4_t& b) 
     for (int e = 0; e < 4; ++e) { v[e] = (bf16_t)a[e]; v[4 + e] = (bf16_t)b[e]; }
     return v;
 }
+// K slots of key-tile pair s for query tile ti: tiles 2s and 2s + 1 of t[.][ti]; a tile beyond the NT the window needs is zero (its keys are padding)
+template <int NT>
+__device__ __forceinline__ bf16x8_t wm_pack2(const f32x4_t (&t)[NT][NT], int s, int ti) {
+    const f32x4_t zero = {0.f, 0.f, 0.f, 0.f};
+    return wm_pack(t[2 * s][ti], 2 * s + 1 < NT ? t[2 * s + 1 < NT ? 2 * s + 1 : 0][ti] : zero);
+}
 __device__ __forceinline__ bf16x4_t wm_pack4(const f32x4_t& a) {
     bf16x4_t v;
 #pragma unroll
@@ -86,12 +92,13 @@ __device__ __forceinline__ float wm_park_row(const WmRow& r, char* tile, int lan
 }
 
 // bias tile in the score layout: [tj][ti][r] = bias_h[i = 16ti + c][j = 16tj + 4g + r]; padded keys get -1e30
-__device__ __forceinline__ void wm_load_bias(const float* bias_h, int n, int lane, f32x4_t (&bs)[4][4]) {
+template <int NT>
+__device__ __forceinline__ void wm_load_bias(const float* bias_h, int n, int lane, f32x4_t (&bs)[NT][NT]) {
     const int g = lane >> 4, c = lane & 15;
 #pragma unroll
-    for (int tj = 0; tj < 4; ++tj)
+    for (int tj = 0; tj < NT; ++tj)
 #pragma unroll
-        for (int ti = 0; ti < 4; ++ti)
+        for (int ti = 0; ti < NT; ++ti)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int i = 16 * ti + c, j = 16 * tj + 4 * g + r;
@@ -100,29 +107,31 @@ __device__ __forceinline__ void wm_load_bias(const float* bias_h, int n, int lan
 }
 
 // St = K^ Q^t (cosines) for the staged window
-__device__ __forceinline__ void wm_scores(const char* kh, const char* qh, int lane, f32x4_t (&st)[4][4]) {
-    bf16x8_t a[4], b[4];
+template <int NT>
+__device__ __forceinline__ void wm_scores(const char* kh, const char* qh, int lane, f32x4_t (&st)[NT][NT]) {
+    bf16x8_t a[NT], b[NT];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) { a[t] = wm_row_frag(kh, t, lane); b[t] = wm_row_frag(qh, t, lane); }
+    for (int t = 0; t < NT; ++t) { a[t] = wm_row_frag(kh, t, lane); b[t] = wm_row_frag(qh, t, lane); }
 #pragma unroll
-    for (int tj = 0; tj < 4; ++tj)
+    for (int tj = 0; tj < NT; ++tj)
 #pragma unroll
-        for (int ti = 0; ti < 4; ++ti) {
+        for (int ti = 0; ti < NT; ++ti) {
             st[tj][ti] = f32x4_t{0.f, 0.f, 0.f, 0.f};
             st[tj][ti] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[tj], b[ti], st[tj][ti], 0, 0, 0);
         }
 }
 
 // in place: cosines -> probabilities (softmax over the keys of every query column)
-__device__ __forceinline__ void wm_softmax(f32x4_t (&st)[4][4], const f32x4_t (&bs)[4][4], float sc, const int* sreg,
+template <int NT>
+__device__ __forceinline__ void wm_softmax(f32x4_t (&st)[NT][NT], const f32x4_t (&bs)[NT][NT], float sc, const int* sreg,
                                            bool masked, int lane) {
     const int g = lane >> 4, c = lane & 15;
 #pragma unroll
-    for (int ti = 0; ti < 4; ++ti) {
+    for (int ti = 0; ti < NT; ++ti) {
         float mx = -INFINITY;
         const int rq = masked ? sreg[16 * ti + c] : 0;
 #pragma unroll
-        for (int tj = 0; tj < 4; ++tj) {
+        for (int tj = 0; tj < NT; ++tj) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float v = st[tj][ti][r] * sc + bs[tj][ti][r];
@@ -134,12 +143,12 @@ __device__ __forceinline__ void wm_softmax(f32x4_t (&st)[4][4], const f32x4_t (&
         mx = wm_max4g(mx);
         float sum = 0.f;
 #pragma unroll
-        for (int tj = 0; tj < 4; ++tj)
+        for (int tj = 0; tj < NT; ++tj)
 #pragma unroll
             for (int r = 0; r < 4; ++r) { const float e = __expf(st[tj][ti][r] - mx); st[tj][ti][r] = e; sum += e; }
         const float inv = 1.f / wm_sum4g(sum);
 #pragma unroll
-        for (int tj = 0; tj < 4; ++tj)
+        for (int tj = 0; tj < NT; ++tj)
 #pragma unroll
             for (int r = 0; r < 4; ++r) st[tj][ti][r] *= inv;
     }
@@ -148,6 +157,7 @@ __device__ __forceinline__ void wm_softmax(f32x4_t (&st)[4][4], const f32x4_t (&
 // grid = (heads, chunks), 4 waves; LDS per wave: Q^, K^, V tiles + pixel / region tables
 constexpr int WM_FWD_WAVE = 3 * WM_TILE + 512;
 
+template <int NT>
 __global__ __launch_bounds__(256, 2) void wm_fwd_kernel(const bf16_t* __restrict__ qkv, const float* __restrict__ bias,
                                                         const float* __restrict__ scale, bf16_t* __restrict__ out, int nwin,
                                                         WaGeom g, int C, int win_per_block, int heads) {
@@ -165,7 +175,7 @@ __global__ __launch_bounds__(256, 2) void wm_fwd_kernel(const bf16_t* __restrict
     const int h = (int)(lin % (uint32_t)heads), chunk = (int)(lin / (uint32_t)heads), n = g.n, grp = lane >> 4, c = lane & 15;
     const float sc = scale[h];
     const bool masked = g.shift > 0;
-    f32x4_t bs[4][4];
+    f32x4_t bs[NT][NT];
     wm_load_bias(bias + (size_t)h * n * n, n, lane, bs);
     const bool active = lane < n;
     const int tok = active ? lane : 0;
@@ -189,29 +199,29 @@ __global__ __launch_bounds__(256, 2) void wm_fwd_kernel(const bf16_t* __restrict
         if (win + 4 < w_end) fetch(win + 4);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        f32x4_t st[4][4];
+        f32x4_t st[NT][NT];
         wm_scores(kh, qh, lane, st);
         wm_softmax(st, bs, sc, sreg, masked, lane);
         // Ot[e][i] = sum_j Vt[e][j] P[i][j]
-        f32x4_t ot[2][4];
+        f32x4_t ot[2][NT];
 #pragma unroll
         for (int te = 0; te < 2; ++te)
 #pragma unroll
-            for (int ti = 0; ti < 4; ++ti) ot[te][ti] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            for (int ti = 0; ti < NT; ++ti) ot[te][ti] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
+        for (int s = 0; s < (NT + 1) / 2; ++s) {
             bf16x8_t va[2];
 #pragma unroll
             for (int te = 0; te < 2; ++te) va[te] = wm_tr_frag<WM_ROW>(vt, s, 16 * te, lane);
 #pragma unroll
-            for (int ti = 0; ti < 4; ++ti) {
-                const bf16x8_t pf = wm_pack(st[2 * s][ti], st[2 * s + 1][ti]);
+            for (int ti = 0; ti < NT; ++ti) {
+                const bf16x8_t pf = wm_pack2<NT>(st, s, ti);
 #pragma unroll
                 for (int te = 0; te < 2; ++te) ot[te][ti] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va[te], pf, ot[te][ti], 0, 0, 0);
             }
         }
 #pragma unroll
-        for (int ti = 0; ti < 4; ++ti) {
+        for (int ti = 0; ti < NT; ++ti) {
             const int i = 16 * ti + c;
             if (i < n) {
                 bf16_t* dst = out + (size_t)spix[i] * C + h * WA_D + 4 * grp;
@@ -226,11 +236,12 @@ __global__ __launch_bounds__(256, 2) void wm_fwd_kernel(const bf16_t* __restrict
 constexpr int WM_BWD_WAVE = 4 * WM_TILE + WM_PTILE + 1024;
 
 // xt[te][t][r] = d(x^)[token 16t + c][e = 16te + 4g + r] -> d(x) through x^ = x / |x|, stored as bf16 (8-byte pieces)
-__device__ __forceinline__ void wm_store_unnormalised(const f32x4_t (&xt)[2][4], const char* xh, const float* sinv, const int* spix,
+template <int NT>
+__device__ __forceinline__ void wm_store_unnormalised(const f32x4_t (&xt)[2][NT], const char* xh, const float* sinv, const int* spix,
                                                       float sc, bf16_t* dst_base, int C, int n, int lane, f32x4_t (&colsum)[2]) {
     const int grp = lane >> 4, c = lane & 15;
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
+    for (int t = 0; t < NT; ++t) {
         const int i = 16 * t + c;
         f32x4_t xv[2], dv[2];
         float dot = 0.f;
@@ -258,6 +269,7 @@ __device__ __forceinline__ void wm_store_unnormalised(const f32x4_t (&xt)[2][4],
     }
 }
 
+template <int NT>
 __global__ __launch_bounds__(256, 1) void wm_bwd_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dout,
                                                         const float* __restrict__ bias, const float* __restrict__ scale,
                                                         bf16_t* __restrict__ dqkv, float* __restrict__ dbias,
@@ -285,25 +297,22 @@ __global__ __launch_bounds__(256, 1) void wm_bwd_kernel(const bf16_t* __restrict
     // as 64 registers held across the loop it left no room for the next window's rows
     f32x4_t* bs_lds = reinterpret_cast<f32x4_t*>(smem + 4 * WM_BWD_WAVE);
     {
-        f32x4_t bs0[4][4];
+        f32x4_t bs0[NT][NT];
         wm_load_bias(bias + (size_t)h * n * n, n, lane, bs0);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {                              // wave w parks tiles 4w .. 4w+3
-            const int t = 4 * wave + q;
-            f32x4_t v = bs0[0][0];
+        for (int tj = 0; tj < NT; ++tj)
 #pragma unroll
-            for (int tj = 0; tj < 4; ++tj)
-#pragma unroll
-                for (int ti = 0; ti < 4; ++ti) if (4 * tj + ti == t) v = bs0[tj][ti];
-            bs_lds[t * 64 + lane] = v;
-        }
+            for (int ti = 0; ti < NT; ++ti)
+                if (((NT * tj + ti) & 3) == wave) bs_lds[(NT * tj + ti) * 64 + lane] = bs0[tj][ti];     // the four waves hold the same tiles: each parks a quarter
     }
+    // rows / columns of the P / dS tile beyond the NT x NT tiles are read (as K slots against zero operand rows) and never written: keep them finite
+    for (int i = lane; i < WM_PTILE / 16; i += 64) reinterpret_cast<f32x4_t*>(pt)[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     __syncthreads();
-    f32x4_t db[4][4];
+    f32x4_t db[NT][NT];
 #pragma unroll
-    for (int tj = 0; tj < 4; ++tj)
+    for (int tj = 0; tj < NT; ++tj)
 #pragma unroll
-        for (int ti = 0; ti < 4; ++ti) db[tj][ti] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        for (int ti = 0; ti < NT; ++ti) db[tj][ti] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     float dsc = 0.f;
     f32x4_t csum[3][2];                                            // column sums of the stored dq, dk, dv (bias gradients)
 #pragma unroll
@@ -334,41 +343,41 @@ __global__ __launch_bounds__(256, 1) void wm_bwd_kernel(const bf16_t* __restrict
         if (win + 4 < w_end) fetch(win + 4);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        f32x4_t st[4][4];
+        f32x4_t st[NT][NT];
         wm_scores(kh, qh, lane, st);
         {
-            f32x4_t bs[4][4];
+            f32x4_t bs[NT][NT];
 #pragma unroll
-            for (int tj = 0; tj < 4; ++tj)
+            for (int tj = 0; tj < NT; ++tj)
 #pragma unroll
-                for (int ti = 0; ti < 4; ++ti) bs[tj][ti] = bs_lds[(4 * tj + ti) * 64 + lane];
+                for (int ti = 0; ti < NT; ++ti) bs[tj][ti] = bs_lds[(NT * tj + ti) * 64 + lane];
             wm_softmax(st, bs, sc, sreg, masked, lane);
         }
         // dPt[j][i] = <v_j, dO_i>
-        f32x4_t dp[4][4];
+        f32x4_t dp[NT][NT];
         {
-            bf16x8_t a[4], b[4];
+            bf16x8_t a[NT], b[NT];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) { a[t] = wm_row_frag(vt, t, lane); b[t] = wm_row_frag(gt, t, lane); }
+            for (int t = 0; t < NT; ++t) { a[t] = wm_row_frag(vt, t, lane); b[t] = wm_row_frag(gt, t, lane); }
 #pragma unroll
-            for (int tj = 0; tj < 4; ++tj)
+            for (int tj = 0; tj < NT; ++tj)
 #pragma unroll
-                for (int ti = 0; ti < 4; ++ti) {
+                for (int ti = 0; ti < NT; ++ti) {
                     dp[tj][ti] = f32x4_t{0.f, 0.f, 0.f, 0.f};
                     dp[tj][ti] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[tj], b[ti], dp[tj][ti], 0, 0, 0);
                 }
         }
         // P -> LDS (row-major [i][j]) for the dV product; dS = P o (dP - rowsum(P o dP)) in place of dP
 #pragma unroll
-        for (int ti = 0; ti < 4; ++ti) {
+        for (int ti = 0; ti < NT; ++ti) {
             float rd = 0.f;
 #pragma unroll
-            for (int tj = 0; tj < 4; ++tj)
+            for (int tj = 0; tj < NT; ++tj)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) rd += st[tj][ti][r] * dp[tj][ti][r];
             rd = wm_sum4g(rd);
 #pragma unroll
-            for (int tj = 0; tj < 4; ++tj) {
+            for (int tj = 0; tj < NT; ++tj) {
                 *reinterpret_cast<bf16x4_t*>(pt + (16 * ti + c) * WM_PROW + (16 * tj + 4 * grp) * 2) = wm_pack4(st[tj][ti]);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -382,27 +391,27 @@ __global__ __launch_bounds__(256, 1) void wm_bwd_kernel(const bf16_t* __restrict
         // kept across the softmax (64 registers that now hold the next window's rows)
         wm_scores(kh, qh, lane, st);
 #pragma unroll
-        for (int tj = 0; tj < 4; ++tj)
+        for (int tj = 0; tj < NT; ++tj)
 #pragma unroll
-            for (int ti = 0; ti < 4; ++ti)
+            for (int ti = 0; ti < NT; ++ti)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) dsc += dp[tj][ti][r] * st[tj][ti][r];
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        f32x4_t xt[2][4];
+        f32x4_t xt[2][NT];
         // ---- dq^t[e][i] = sum_j K^t[e][j] dSt[j][i]   (B from registers)
 #pragma unroll
         for (int te = 0; te < 2; ++te)
 #pragma unroll
-            for (int t = 0; t < 4; ++t) xt[te][t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            for (int t = 0; t < NT; ++t) xt[te][t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
+        for (int s = 0; s < (NT + 1) / 2; ++s) {
             bf16x8_t ka[2];
 #pragma unroll
             for (int te = 0; te < 2; ++te) ka[te] = wm_tr_frag<WM_ROW>(kh, s, 16 * te, lane);
 #pragma unroll
-            for (int ti = 0; ti < 4; ++ti) {
-                const bf16x8_t df = wm_pack(dp[2 * s][ti], dp[2 * s + 1][ti]);
+            for (int ti = 0; ti < NT; ++ti) {
+                const bf16x8_t df = wm_pack2<NT>(dp, s, ti);
 #pragma unroll
                 for (int te = 0; te < 2; ++te) xt[te][ti] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka[te], df, xt[te][ti], 0, 0, 0);
             }
@@ -412,21 +421,21 @@ __global__ __launch_bounds__(256, 1) void wm_bwd_kernel(const bf16_t* __restrict
 #pragma unroll
         for (int te = 0; te < 2; ++te)
 #pragma unroll
-            for (int t = 0; t < 4; ++t) xt[te][t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            for (int t = 0; t < NT; ++t) xt[te][t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
+        for (int s = 0; s < (NT + 1) / 2; ++s) {
             bf16x8_t ga[2];
 #pragma unroll
             for (int te = 0; te < 2; ++te) ga[te] = wm_tr_frag<WM_ROW>(gt, s, 16 * te, lane);
 #pragma unroll
-            for (int tj = 0; tj < 4; ++tj) {
+            for (int tj = 0; tj < NT; ++tj) {
                 const bf16x8_t pf = wm_tr_frag<WM_PROW>(pt, s, 16 * tj, lane);
 #pragma unroll
                 for (int te = 0; te < 2; ++te) xt[te][tj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ga[te], pf, xt[te][tj], 0, 0, 0);
             }
         }
 #pragma unroll
-        for (int tj = 0; tj < 4; ++tj) {
+        for (int tj = 0; tj < NT; ++tj) {
             const int j = 16 * tj + c;
             if (j < n) {
                 bf16_t* dst = dqkv + (size_t)spix[j] * 3 * C + 2 * C + h * WA_D + 4 * grp;
@@ -442,23 +451,23 @@ __global__ __launch_bounds__(256, 1) void wm_bwd_kernel(const bf16_t* __restrict
         // ---- dS -> LDS over P, then dk^t[e][j] = sum_i Q^t[e][i] dS[i][j]
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int ti = 0; ti < 4; ++ti)
+        for (int ti = 0; ti < NT; ++ti)
 #pragma unroll
-            for (int tj = 0; tj < 4; ++tj)
+            for (int tj = 0; tj < NT; ++tj)
                 *reinterpret_cast<bf16x4_t*>(pt + (16 * ti + c) * WM_PROW + (16 * tj + 4 * grp) * 2) = wm_pack4(dp[tj][ti]);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int te = 0; te < 2; ++te)
 #pragma unroll
-            for (int t = 0; t < 4; ++t) xt[te][t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            for (int t = 0; t < NT; ++t) xt[te][t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
+        for (int s = 0; s < (NT + 1) / 2; ++s) {
             bf16x8_t qa[2];
 #pragma unroll
             for (int te = 0; te < 2; ++te) qa[te] = wm_tr_frag<WM_ROW>(qh, s, 16 * te, lane);
 #pragma unroll
-            for (int tj = 0; tj < 4; ++tj) {
+            for (int tj = 0; tj < NT; ++tj) {
                 const bf16x8_t df = wm_tr_frag<WM_PROW>(pt, s, 16 * tj, lane);
 #pragma unroll
                 for (int te = 0; te < 2; ++te) xt[te][tj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa[te], df, xt[te][tj], 0, 0, 0);
@@ -470,9 +479,9 @@ __global__ __launch_bounds__(256, 1) void wm_bwd_kernel(const bf16_t* __restrict
     __syncthreads();
     float* red = reinterpret_cast<float*>(smem);                   // [4][64][64]
 #pragma unroll
-    for (int tj = 0; tj < 4; ++tj)
+    for (int tj = 0; tj < NT; ++tj)
 #pragma unroll
-        for (int ti = 0; ti < 4; ++ti)
+        for (int ti = 0; ti < NT; ++ti)
             *reinterpret_cast<f32x4_t*>(red + wave * 4096 + (16 * ti + c) * 64 + 16 * tj + 4 * grp) = db[tj][ti];
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) dsc += __shfl_xor(dsc, d);
@@ -528,12 +537,15 @@ static int wm_chunks(int nwin, int heads, int target_wgs, int* wpb_out) {
     return (nwin + wpb - 1) / wpb;
 }
 
-int winattn_mfma_fwd(const void* qkv, const float* bias, const float* scale, void* out, int nwin, const WaGeom& g, int C,
-                     int heads, hipStream_t stream) {
+// The kernels are instantiated per NT = ceil(tokens / 16) 16-token tiles a window needs (7x7: 4, 6x6: 3, 3x3: 1): scores, softmax and the
+// five products walk NT x NT tiles instead of the padded 4 x 4 (a 6x6 window did 16 / 9 of the matrix and softmax work it needed).
+template <int NT>
+static int wm_fwd_launch(const void* qkv, const float* bias, const float* scale, void* out, int nwin, const WaGeom& g, int C,
+                         int heads, hipStream_t stream) {
     const int lds = 4 * WM_FWD_WAVE;
     static bool attr_done = false;
     if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(wm_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(wm_fwd_kernel<NT>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
             set_error("frhip_winattn_fwd: cannot raise dynamic LDS to %d bytes", lds);
             return FRHIP_ELAUNCH;
         }
@@ -542,17 +554,28 @@ int winattn_mfma_fwd(const void* qkv, const float* bias, const float* scale, voi
     int wpb;
     static const int target = getenv("FRHIP_WA_FWD_WGS") ? atoi(getenv("FRHIP_WA_FWD_WGS")) : 4 * wm_cus();
     const int chunks = wm_chunks(nwin, heads, target, &wpb);
-    hipLaunchKernelGGL(wm_fwd_kernel, dim3(heads * chunks), dim3(256), lds, stream, (const bf16_t*)qkv, bias, scale, (bf16_t*)out,
+    hipLaunchKernelGGL(wm_fwd_kernel<NT>, dim3(heads * chunks), dim3(256), lds, stream, (const bf16_t*)qkv, bias, scale, (bf16_t*)out,
                        nwin, g, C, wpb, heads);
     return check_launch("frhip_winattn_fwd");
 }
 
-int winattn_mfma_bwd(const void* qkv, const void* dout, const float* bias, const float* scale, void* dqkv, float* dbias,
-                     float* dscale, const WaColsum& colsum, int nwin, const WaGeom& g, int C, int heads, hipStream_t stream) {
+int winattn_mfma_fwd(const void* qkv, const float* bias, const float* scale, void* out, int nwin, const WaGeom& g, int C,
+                     int heads, hipStream_t stream) {
+    switch ((g.n + 15) / 16) {
+        case 1: return wm_fwd_launch<1>(qkv, bias, scale, out, nwin, g, C, heads, stream);
+        case 2: return wm_fwd_launch<2>(qkv, bias, scale, out, nwin, g, C, heads, stream);
+        case 3: return wm_fwd_launch<3>(qkv, bias, scale, out, nwin, g, C, heads, stream);
+        default: return wm_fwd_launch<4>(qkv, bias, scale, out, nwin, g, C, heads, stream);
+    }
+}
+
+template <int NT>
+static int wm_bwd_launch(const void* qkv, const void* dout, const float* bias, const float* scale, void* dqkv, float* dbias,
+                         float* dscale, const WaColsum& colsum, int nwin, const WaGeom& g, int C, int heads, hipStream_t stream) {
     const int lds = 4 * WM_BWD_WAVE + 16 * 64 * 16;                  // + the head's bias tile in the score layout
     static bool attr_done = false;
     if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(wm_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(wm_bwd_kernel<NT>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
             set_error("frhip_winattn_bwd: cannot raise dynamic LDS to %d bytes", lds);
             return FRHIP_ELAUNCH;
         }
@@ -561,9 +584,19 @@ int winattn_mfma_bwd(const void* qkv, const void* dout, const float* bias, const
     int wpb;
     static const int target = getenv("FRHIP_WA_BWD_WGS") ? atoi(getenv("FRHIP_WA_BWD_WGS")) : wm_cus();
     const int chunks = wm_chunks(nwin, heads, target, &wpb);
-    hipLaunchKernelGGL(wm_bwd_kernel, dim3(heads * chunks), dim3(256), lds, stream, (const bf16_t*)qkv, (const bf16_t*)dout, bias,
+    hipLaunchKernelGGL(wm_bwd_kernel<NT>, dim3(heads * chunks), dim3(256), lds, stream, (const bf16_t*)qkv, (const bf16_t*)dout, bias,
                        scale, (bf16_t*)dqkv, dbias, dscale, colsum, nwin, g, C, wpb, heads);
     return check_launch("frhip_winattn_bwd");
+}
+
+int winattn_mfma_bwd(const void* qkv, const void* dout, const float* bias, const float* scale, void* dqkv, float* dbias,
+                     float* dscale, const WaColsum& colsum, int nwin, const WaGeom& g, int C, int heads, hipStream_t stream) {
+    switch ((g.n + 15) / 16) {
+        case 1: return wm_bwd_launch<1>(qkv, dout, bias, scale, dqkv, dbias, dscale, colsum, nwin, g, C, heads, stream);
+        case 2: return wm_bwd_launch<2>(qkv, dout, bias, scale, dqkv, dbias, dscale, colsum, nwin, g, C, heads, stream);
+        case 3: return wm_bwd_launch<3>(qkv, dout, bias, scale, dqkv, dbias, dscale, colsum, nwin, g, C, heads, stream);
+        default: return wm_bwd_launch<4>(qkv, dout, bias, scale, dqkv, dbias, dscale, colsum, nwin, g, C, heads, stream);
+    }
 }
 
 }  // namespace frhip

@@ -83,6 +83,14 @@ def test_window_attention_mfma_matches_valu_kernels(geom):
     colsum = res[1][4].cpu().numpy()              # fused q_bias / v_bias gradient = column sums of the STORED dqkv
     stored = res[1][1].float().sum(0).cpu().numpy()
     np.testing.assert_allclose(colsum, stored, rtol=1e-3, atol=1e-3 * np.abs(res[1][1].float().cpu().numpy()).sum(0).max())
+    # the q / v thirds added straight into existing gradient accumulators (frhip_winattn_bwd_qvbias): same dqkv bits, accumulators = their
+    # old contents + the stored tensor's column sums
+    gq, gv = torch.full((c,), 0.5, device="cuda"), torch.full((c,), -0.25, device="cuda")
+    direct = ops.winattn_bwd(qkv, dout, bias, scale, b, hw, hw, heads, ws=ws, shift=shift, want_colsum=True, qv_grads=(gq, gv))
+    assert direct[3] is True and torch.equal(direct[0], res[1][1])
+    lim = 1e-3 * np.abs(res[1][1].float().cpu().numpy()).sum(0).max()
+    np.testing.assert_allclose(gq.cpu().numpy() - 0.5, stored[:c], rtol=1e-3, atol=lim)
+    np.testing.assert_allclose(gv.cpu().numpy() + 0.25, stored[2 * c:], rtol=1e-3, atol=lim)
     names = ("out", "dqkv", "dbias", "dscale")
     for name, a, r in zip(names, res[1], res[0]):
         a, r = a.float().cpu().numpy(), r.float().cpu().numpy()
