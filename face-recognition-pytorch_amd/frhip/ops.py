@@ -355,6 +355,10 @@ def colsum_accumulate(x2d, out_accum):
 def dropout_mask(shape, dtype, keep, device, seed=None):
     """mask of `shape`: 1/keep with probability keep, else 0 (one launch).  seed None: drawn from torch's CPU generator"""
     if seed is None:
+        if torch.cuda.is_current_stream_capturing():
+            # a captured graph would replay ONE host-drawn seed, i.e. the same mask every step: torch's device generator is graph-safe
+            # (its Philox offset advances per replay), so the capture records the four-pass torch formulation instead
+            return (torch.rand(shape, device=device) < keep).to(dtype) / keep
         seed = int(torch.randint(0, 2 ** 62, (1,)).item())
     mask = torch.empty(shape, dtype=dtype, device=device)
     check(lib().frhip_dropout_mask(_DT[dtype], _p(mask), mask.numel(), float(keep), int(seed), _s()), "frhip_dropout_mask")
