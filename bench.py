@@ -5,6 +5,7 @@ faces (BASELINE.json metric), one process per GPU.
   python bench.py --gpus 1 --steps K --warmup W
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
          bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N ...            (no launcher: starts the N ranks itself, as a child torch.distributed.run)
 
 A step = Model.training_step (zero_grad, backbone fwd, normalise, margin-softmax head, backward, clip, SGD step)
 on a pre-staged synthetic batch.  Rank 0 prints ONE JSON line.  `roofline` is measured live: every launch of the
@@ -244,6 +245,28 @@ def cpu_baseline(classes, batch=16, steps=12):
                       "steps (%.1f s)" % (classes, batch, steps, dt)}
 
 
+def cpu_baseline_cfg1(batch=16, steps=10):
+    """BASELINE cfg 1 (the reference's own CPU-runnable case): ResNet-18 + ArcFace head, 256 ids, B = 16, fp32, all host cores"""
+    from oracle import recipe, resnet_ref, train_ref
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    blocks = resnet_ref.BLOCKS["ResNet18"]
+    sd = recipe.fill_state(resnet_ref.resnet_spec(blocks), 1)
+    w = recipe.normal(2, (256, 512), 0.01)
+    img, ids = recipe.images(3, batch), recipe.labels(4, batch, 256)
+    opt = train_ref.SGDState(0.1, 0.9, 5e-4)
+    for _ in range(3):
+        train_ref.train_step(sd, w, img, ids, blocks, 256, opt)
+    t0 = time.time()
+    for _ in range(steps):
+        train_ref.train_step(sd, w, img, ids, blocks, 256, opt)
+    dt = time.time() - t0
+    log("cpu_baseline_cfg1: %.2f s" % dt)
+    return {"value": round(batch * steps / dt, 2), "unit": "imgs/sec", "cores": cores, "kind": "port",
+            "sample": "oracle/ CPU restatement, BASELINE cfg 1: ResNet-18 + ArcFace head C=256, B=%d fp32, 3 warm-up + %d timed SGD steps (%.1f s)"
+                      % (batch, steps, dt)}
+
+
 FLOP_IMG = {"ResNet50": 33.92e9, "ResNet18": 10.3e9, "Swin34": 10.2e9,
             "AlterNet50": 6 * 2.1025e9}       # tools/count_macs.py: 2.1025 GMAC forward at 192 x 192
 
@@ -281,6 +304,28 @@ def extra_config(network, batch, fp8, classes, steps=10, warmup=3):
     return rec
 
 
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher (where the reference does mp.spawn(train, nprocs=world_size), main/main.py:255-259):
+    start N ranks of this script under torch.distributed.run as a CHILD process and return its exit code.  This process has made no HIP
+    call at this point (importing torch does not initialise the device) and it never replaces itself: the ranks inherit stdout, so rank 0's
+    JSON line is this command's output."""
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "4")
+    print("[bench] starting %d ranks: %s" % (n, " ".join(cmd)), file=sys.stderr, flush=True)
+    return subprocess.run(cmd, env=env).returncode
+
+
 def log(msg):
     if int(os.environ.get("RANK", "0")) == 0:
         print("[bench %7.1fs] %s" % (time.time() - T_START, msg), file=sys.stderr, flush=True)
@@ -313,10 +358,12 @@ def main():
     if args.batch is None:
         args.batch = 256 if args.network.startswith("AlterNet") else BATCH
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus))               # `python bench.py --gpus N` starts its own ranks (reference main/main.py:255-259)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    assert world == args.gpus, "WORLD_SIZE=%d but --gpus %d" % (world, args.gpus)
     # rehearsal hook (one-GPU boxes): FRHIP_BENCH_BACKEND=gloo runs the N > 1 code path with every rank on cuda:0
     backend = os.environ.get("FRHIP_BENCH_BACKEND", "nccl")
     if backend != "nccl":
@@ -327,7 +374,7 @@ def main():
     elif world > 1 or args.dist_path:
         if world == 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            os.environ.setdefault("MASTER_PORT", "29533")
+            os.environ.setdefault("MASTER_PORT", str(free_port()))
             os.environ.setdefault("RANK", "0")
             os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
@@ -469,6 +516,7 @@ def main():
                                     "launches": f8_n // in_steps, "avg_launch_us": round(f8_ms * 1e3 / f8_n, 2)}
         if world == 1 and not args.no_cpu_baseline and args.network == "ResNet50":
             line["cpu_baseline"] = cpu_baseline(args.classes)
+            line["cpu_baseline_cfg1"] = cpu_baseline_cfg1()
         # BASELINE cfg 4 / cfg 5 in the same process, after (and outside) the headline's timed region; the headline fields above are
         # final at this point.  Only in the plain headline run: N = 1, ResNet50, default batch, eager.
         if (world == 1 and args.network == "ResNet50" and args.batch == BATCH and not args.dist_path and not use_graph and not args.fp8

@@ -75,3 +75,18 @@ def summary(t, k=8):
     if head.numel() < k:
         head = torch.cat([head, torch.zeros(k - head.numel(), dtype=torch.float64)])
     return torch.cat([t.sum().view(1), t.norm().view(1), head]).numpy()
+
+
+def probe_positions(numel, k=256):
+    """portable positions a probe() reads: every element of a small tensor, else k positions drawn from PCG64 seeded by the size"""
+    if numel <= k:
+        return np.arange(numel, dtype=np.int64)
+    return rng(0x9E3779B1 ^ numel).integers(0, numel, size=(k,), dtype=np.int64)
+
+
+def probe(t, k=256):
+    """Checksum of a tensor that a permutation of its elements cannot pass: [sum, l2, the elements at probe_positions()]
+    of the tensor flattened in its LOGICAL (row-major over .shape) order."""
+    t = t.detach().double().reshape(-1)
+    pos = torch.from_numpy(probe_positions(t.numel(), k))
+    return torch.cat([t.sum().view(1), t.norm().view(1), t[pos]]).numpy()

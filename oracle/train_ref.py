@@ -7,8 +7,8 @@ Composition follows /root/reference/model/FR_PartialFC.py:162-193 (non-mixed bra
 with ONE optimizer over param groups [encoder, head] (:434-449, SGD momentum + weight decay
 on every tensor, BN affine included).  train_step: world_size 1 (BASELINE cfg 1 / cfg 2); train_step_ranks: a world of N
 ranks in one process (DDP-averaged backbone gradients, class-sharded head), pinned by the ws-2 reference fixtures.
-The SGD update itself is restated by hand (torch.optim.SGD semantics: d = g + wd*p;
-buf = d on the first step else mom*buf + d; p -= lr*buf).
+The updates are restated by hand: SGDState (torch.optim.SGD semantics: d = g + wd*p;
+buf = d on the first step else mom*buf + d; p -= lr*buf) and AdamWState (torch.optim.AdamW, the reference's shipped recipe main/train.sh:12).
 """
 import torch
 import torch.nn.functional as F
@@ -28,6 +28,60 @@ class SGDState:
         else:
             self.buf[name] = d.clone()
         p.sub_(self.lr * self.buf[name])
+
+    def head_update(self, head_w, idx, d_w, sample_rate):
+        """rows `idx` of the class-centre shard (not clipped: the clip is over encoder.parameters() only, :187)"""
+        first = "head" not in self.buf
+        if first:
+            self.buf["head"] = torch.zeros_like(head_w)
+        w_rows = head_w[idx]
+        d = d_w + self.wd * w_rows
+        # torch SGD initialises the buffer to d only when the state is EMPTY; PartialFC with
+        # sample_rate<1 always installs a momentum tensor (zeros at first), so the general
+        # formula mom*buf + d applies there; at sample_rate==1 the first step sets buf = d.
+        if sample_rate < 1 or not first:
+            buf_rows = self.buf["head"][idx] * self.momentum + d
+        else:
+            buf_rows = d
+        self.buf["head"][idx] = buf_rows
+        head_w[idx] = w_rows - self.lr * buf_rows
+
+
+class AdamWState:
+    """torch.optim.AdamW (decoupled weight decay; reference model/FR_PartialFC.py:436-442, configs/ms1m_arcface_122.py:222-224),
+    restated by hand:  p *= 1 - lr*wd;  m = b1*m + (1-b1)*g;  v = b2*v + (1-b2)*g*g;  t += 1;
+    p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps).
+    Head rows (PartialFCAdamW, nets/PartialFC.py:309-327, :337-342): exp_avg / exp_avg_sq live in full [num_local, D] tables and travel
+    with the sampled rows.  With sampling, sample() counts calls in self.step and writes that count into optimizer.state['step'] BEFORE
+    the optimizer bumps it, so the head's bias corrections use t = (#sample calls so far) + 1 -- one ahead of the encoder's."""
+
+    def __init__(self, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=5e-4):
+        self.lr, self.b1, self.b2, self.eps, self.wd = lr, float(betas[0]), float(betas[1]), eps, weight_decay
+        self.m, self.v, self.t = {}, {}, {}
+        self.head_calls = 0
+
+    def _adam(self, p, g, m, v, t):
+        p.mul_(1.0 - self.lr * self.wd)
+        m.mul_(self.b1).add_(g, alpha=1.0 - self.b1)
+        v.mul_(self.b2).addcmul_(g, g, value=1.0 - self.b2)
+        bc1, bc2 = 1.0 - self.b1 ** t, 1.0 - self.b2 ** t
+        denom = (v.sqrt() / (bc2 ** 0.5)).add_(self.eps)
+        p.addcdiv_(m, denom, value=-self.lr / bc1)
+
+    def apply(self, name, p, g):
+        if name not in self.m:
+            self.m[name], self.v[name], self.t[name] = torch.zeros_like(p), torch.zeros_like(p), 0
+        self.t[name] += 1
+        self._adam(p, g, self.m[name], self.v[name], self.t[name])
+
+    def head_update(self, head_w, idx, d_w, sample_rate):
+        if "head" not in self.m:
+            self.m["head"], self.v["head"] = torch.zeros_like(head_w), torch.zeros_like(head_w)
+        self.head_calls += 1
+        t = self.head_calls + 1 if sample_rate < 1 else self.head_calls
+        p, m, v = head_w[idx], self.m["head"][idx], self.v["head"][idx]
+        self._adam(p, d_w, m, v, t)
+        head_w[idx], self.m["head"][idx], self.v["head"][idx] = p, m, v
 
 
 def clip_coef(grads, max_norm=5.0):
@@ -59,25 +113,9 @@ def train_step(sd, head_w, img, ids, blocks, num_classes, opt, s=30.0, m=0.35,
     with torch.no_grad():
         for k in names:
             opt.apply(k, sd[k], leaves[k].grad * coef)
-        # head rows (not clipped: clip is over encoder.parameters() only, :187)
         idx = h["index"][0]
-        if "head" not in opt.buf:
-            opt.buf["head"] = torch.zeros_like(head_w)
-            first = True
-        else:
-            first = False
-        w_rows = head_w[idx]
-        d = h["d_w_act"][0] + opt.wd * w_rows
-        # torch SGD initialises the buffer to d only when the state is EMPTY; PartialFC with
-        # sample_rate<1 always installs a momentum tensor (zeros at first), so the general
-        # formula mom*buf + d applies there; at sample_rate==1 the first step sets buf = d.
-        if sample_rate < 1 or not first:
-            buf_rows = opt.buf["head"][idx] * opt.momentum + d
-        else:
-            buf_rows = d
-        opt.buf["head"][idx] = buf_rows
-        head_w[idx] = w_rows - opt.lr * buf_rows
-    return dict(loss=h["loss"], feat=feat.detach(), grad_norm=total, index=idx)
+        opt.head_update(head_w, idx, h["d_w_act"][0], sample_rate)
+    return dict(loss=h["loss"], feat=feat.detach(), grad_norm=total, index=idx, grads={k: leaves[k].grad * coef for k in names})
 
 
 def train_step_ranks(sds, head_ws, imgs, idss, blocks, num_classes, opts, s=30.0, m=0.35, emd_size=512,
@@ -112,13 +150,5 @@ def train_step_ranks(sds, head_ws, imgs, idss, blocks, num_classes, opts, s=30.0
         for r in range(ws):
             for k in names:
                 opts[r].apply(k, sds[r][k], avg[k] * coef)
-            idx = h["index"][r]
-            first = "head" not in opts[r].buf
-            if first:
-                opts[r].buf["head"] = torch.zeros_like(head_ws[r])
-            w_rows = head_ws[r][idx]
-            d = h["d_w_act"][r] + opts[r].wd * w_rows
-            buf_rows = opts[r].buf["head"][idx] * opts[r].momentum + d if (sample_rate < 1 or not first) else d
-            opts[r].buf["head"][idx] = buf_rows
-            head_ws[r][idx] = w_rows - opts[r].lr * buf_rows
+            opts[r].head_update(head_ws[r], h["index"][r], h["d_w_act"][r], sample_rate)
     return dict(loss=h["loss"], grad_norm=total, index=h["index"])

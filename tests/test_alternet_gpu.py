@@ -49,7 +49,7 @@ def test_attention_pair_fp32_matches_reference_fixture(golden, tag):
                                            atol=(2e-3 if k.endswith(NOISE) else 5e-3 * np.abs(want).max() + 1e-5), err_msg=k)
 
 
-def test_alternet50_fp32_eval_and_bf16_train(golden):
+def test_alternet50_fp32_eval(golden):
     import nets.AlterNet_SwinV2_FAN as A
     g = golden("alternet50_b2_eval")
     spec = alternet_ref.alter_spec("AlterNet50")
@@ -60,9 +60,36 @@ def test_alternet50_fp32_eval_and_bf16_train(golden):
     with torch.no_grad():
         y = net(recipe.images(7301, 2, 192, 192).cuda())
     np.testing.assert_allclose(y.cpu().numpy(), g["out"], rtol=1e-3, atol=3e-4)
-    net16 = A.Encoder(types.SimpleNamespace(network="AlterNet50", emd_size=512, img_size=192, frhip_dtype="bf16"))
-    net16.load_state_dict(sd, strict=True)
-    net16 = net16.cuda().train()
-    out = net16(recipe.images(7301, 4, 192, 192).cuda())
-    out.sum().backward()
-    assert torch.isfinite(out).all() and all(torch.isfinite(p.grad).all() for p in net16.parameters())
+
+
+
+def _alternet50(dtype, seed):
+    import nets.AlterNet_SwinV2_FAN as A
+    spec = alternet_ref.alter_spec("AlterNet50")
+    sd = alternet_ref.fill_special(recipe.fill_state(spec, seed), spec)
+    net = A.Encoder(types.SimpleNamespace(network="AlterNet50", emd_size=512, img_size=192, frhip_dtype=dtype))
+    net.load_state_dict(sd, strict=True)
+    return net.cuda()
+
+
+def test_alternet50_whole_net_training_mode_fp32_matches_reference_fixture(golden):
+    """BASELINE cfg 5's network (/root/reference/nets/AlterNet_SwinV2_FAN.py:637-751) in training mode against the real reference, batch 8 at
+    192 x 192: stride-2 stem (im2col route), conv <-> (W-MSA, SW-MSA) interleave, bn2 -> ReLU -> Dropout(p = 0) -> AAP(6,6) -> fc -> bn3."""
+    from wholenet import check_whole_net_train, whole_net_train_on_gpu
+    g = golden("alternet50_b8_train")
+    grads, out, bufs = whole_net_train_on_gpu(_alternet50("fp32", int(g["seed"])), g, 192, 192)
+    check_whole_net_train(g, grads, out, bufs, rtol=1e-2, noise=("fc.bias",))
+
+
+def test_alternet50_bf16_training_step_tracks_the_reference_fixture(golden):
+    from wholenet import whole_net_train_on_gpu
+    g = golden("alternet50_b8_train")
+    grads, out, _ = whole_net_train_on_gpu(_alternet50("bf16", int(g["seed"])), g, 192, 192)
+    assert np.isfinite(out).all() and all(torch.isfinite(v).all() for v in grads.values())
+    assert np.linalg.norm(out - g["out"]) <= 5e-2 * np.linalg.norm(g["out"])
+    for k in [k[6:] for k in g if k.startswith("gfull.")]:
+        want = g["gfull." + k].reshape(-1).astype(np.float64)
+        got = grads[k].numpy().reshape(-1).astype(np.float64)
+        if want.size >= 1024:
+            cos = float(got @ want / (np.linalg.norm(got) * np.linalg.norm(want)))
+            assert cos >= 0.95, (k, cos)

@@ -32,6 +32,16 @@ def test_resnet18_train_fp32_matches_reference_fixture(golden):
     for k, p in net.named_parameters():
         got, want = recipe.summary(p.grad.cpu()), g["gsum." + k]
         np.testing.assert_allclose(got, want, rtol=5e-3, atol=5e-5 + 2e-3 * abs(want[1]), err_msg=k)
+        # element by element at 256 portable positions of the LOGICAL [K,C,R,S] / [out,in] order: no layout permutation passes
+        want = g["gprobe." + k]
+        rms = want[1] / p.numel() ** 0.5
+        np.testing.assert_allclose(recipe.probe(p.grad.cpu())[2:], want[2:], rtol=5e-3, atol=1e-2 * rms + 2e-6, err_msg=k + " (probe)")
+    for k in ("conv1.weight", "layer1.0.conv1.weight"):                        # whole tensors
+        want = g["gfull." + k]
+        got = dict(net.named_parameters())[k].grad.cpu().numpy()
+        np.testing.assert_allclose(got, want, rtol=5e-3, atol=1e-2 * float(np.sqrt((want.astype(np.float64) ** 2).mean())), err_msg=k)
+    want = g["gprobe16k.fc.weight"]                                            # 16 384 elements of the (c,h,w) -> (h,w,c) permuted fc columns
+    np.testing.assert_allclose(recipe.probe(net.fc.weight.grad.cpu(), 16384)[2:], want[2:], rtol=5e-3, atol=1e-2 * want[1] / net.fc.weight.numel() ** 0.5)
     for k, b in net.named_buffers():
         np.testing.assert_allclose(recipe.summary(b.float().cpu()), g["after." + k], rtol=1e-3, atol=1e-5, err_msg=k)
 

@@ -84,3 +84,77 @@ def test_partial_fc_hip_head_multi_rank_vs_reference(golden, name, use_prepare):
             for key, ref in (("d_emb", g["r%d_d_emb" % r]), ("d_w", g["r%d_d_w_act" % r])):
                 np.testing.assert_allclose(out[key], ref, rtol=1e-3, atol=1e-3 * float(np.abs(ref).max()) * 1e-2,
                                            err_msg="rank %d %s" % (r, key))
+
+
+# ------------------------------------------------------------------------------------------------ AdamW flavour (the reference's shipped recipe)
+def _adamw_worker(rank, ws, path, name, ret):
+    for p in (ROOT, os.path.join(ROOT, "face-recognition-pytorch_amd"), os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from oracle import recipe
+    import nets.PartialFC as P
+    from frhip import optim as fo
+    torch.set_num_threads(1)
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    g = dict(np.load(os.path.join(ROOT, "tests", "golden", name + ".npz")))
+    dist.init_process_group("gloo", init_method="file://" + path, rank=rank, world_size=ws)
+    C, B, D, rate, steps = int(g["C"]), int(g["B"]), int(g["D"]), float(g["rate"]), int(g["steps"])
+    conf = types.SimpleNamespace(emd_size=D, sample_rate=rate, mixed_precision=False, loss_s=float(g["s"]), loss_m=float(g["m"]), frhip_dtype="fp32")
+    pfc = P.PartialFCAdamW(conf, C).to(dev)
+    assert type(pfc.kernels).__name__ == "HipHeadKernels"
+    with torch.no_grad():
+        pfc.weight.copy_(recipe.normal(500 + rank, (pfc.num_local, D), 0.05).to(dev))
+    dummy = torch.nn.Parameter(torch.zeros(1, device=dev))
+    opt = fo.AdamW([{"params": [dummy]}, {"params": pfc.parameters()}], lr=float(g["lr"]), weight_decay=float(g["wd"]), eps=float(g["eps"]),
+                   betas=tuple(float(b) for b in g["betas"]))
+    out = {}
+    for st in range(steps):
+        opt.zero_grad()
+        emb = recipe.normal(100 + rank + 10 * st, (B, D)).to(dev).requires_grad_(True)
+        lab = recipe.labels(200 + rank + 10 * st, B, C)
+        lab[0] = 3
+        lab[1] = 3
+        lab_in = lab.clone().to(dev)
+        torch.manual_seed(1000 + rank + 100 * st)
+        if st % 2 == 1:
+            pfc.prepare(lab_in, opt)                        # both routes of the label side
+        loss = pfc(emb, lab_in, opt)
+        loss.backward()
+        ok = opt.param_groups[-1]["params"][0] is pfc.weight_activated and opt.state[pfc.weight_activated]["exp_avg"] is pfc.weight_activated_exp_avg \
+            and opt.state[pfc.weight_activated]["exp_avg_sq"] is pfc.weight_activated_exp_avg_sq
+        opt.step()
+        out["loss%d" % st], out["d_emb%d" % st], out["index%d" % st] = float(loss.detach()), emb.grad.cpu().numpy(), pfc.weight_index.cpu().numpy()
+        out["ok%d" % st] = bool(ok)
+    pfc.update()
+    np.savez(os.path.join(ret, "rank%d.npz" % rank), weight=pfc.weight.cpu().numpy(), exp_avg=pfc.weight_exp_avg.cpu().numpy(),
+             exp_avg_sq=pfc.weight_exp_avg_sq.cpu().numpy(), **out)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name", ["head_adamw_ws1_rate03", "head_adamw_ws2_rate03"])
+def test_partial_fc_adamw_three_steps_vs_reference(golden, name):
+    """PartialFCAdamW on the HIP head kernels + frhip.optim.AdamW (fused multi-tensor kernel) against the real reference's PartialFCAdamW +
+    torch.optim.AdamW (/root/reference/nets/PartialFC.py:235-432; lr 5e-4, wd 5e-4 = main/train.sh:12): three steps with fresh embeddings,
+    sample rate 0.3 -- the exp_avg / exp_avg_sq rows travel in and out of the full tables with the sampled rows, and the head's step counter
+    runs one ahead of an ordinary parameter's (sample() writes its own count into the optimizer state before the optimizer bumps it)."""
+    g = golden(name)
+    ws, steps, lr = int(g["ws"]), int(g["steps"]), float(g["lr"])
+    with tempfile.TemporaryDirectory() as td:
+        mp.spawn(_adamw_worker, args=(ws, os.path.join(td, "pg"), name, td), nprocs=ws, join=True)
+        for r in range(ws):
+            out = dict(np.load(os.path.join(td, "rank%d.npz" % r)))
+            for st in range(steps):
+                assert bool(out["ok%d" % st])
+                assert np.array_equal(out["index%d" % st], g["r%d_index_step%d" % (r, st)]), "rank %d step %d: sampled rows differ" % (r, st)
+                np.testing.assert_allclose(float(out["loss%d" % st]), g["r%d_loss_step%d" % (r, st)], rtol=1e-4)
+                ref = g["r%d_d_emb_step%d" % (r, st)]
+                np.testing.assert_allclose(out["d_emb%d" % st], ref, rtol=1e-3, atol=1e-5 * float(np.abs(ref).max()))
+            # Adam normalises the step: an element whose gradient is rounding noise moves by ~lr in a direction no two implementations
+            # share.  Nearly all elements agree to 1e-6, every element within what three steps can cover.
+            d = np.abs(out["weight"] - g["r%d_weight" % r])
+            assert (d <= 2e-6).mean() >= 0.999 and d.max() <= 2.2 * lr * steps, ((d <= 2e-6).mean(), d.max())
+            np.testing.assert_allclose(out["exp_avg"], g["r%d_exp_avg" % r], rtol=2e-3, atol=1e-5 * float(np.abs(g["r%d_exp_avg" % r]).max()))
+            np.testing.assert_allclose(out["exp_avg_sq"], g["r%d_exp_avg_sq" % r], rtol=4e-3, atol=1e-5 * float(np.abs(g["r%d_exp_avg_sq" % r]).max()))
+            untouched = np.setdiff1d(np.arange(out["weight"].shape[0]), np.concatenate([g["r%d_index_step%d" % (r, st)] for st in range(steps)]))
+            assert not out["exp_avg"][untouched].any() and not out["exp_avg_sq"][untouched].any()      # rows never sampled: moments stay zero

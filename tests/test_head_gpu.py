@@ -43,6 +43,11 @@ def test_head_matches_oracle_at_cfg2_size():
     _check_head_against_oracle(torch.bfloat16, (512, 122000, 512))
 
 
+def test_head_matches_oracle_at_cfg2_size_fp32():
+    """the same 512 x 122 000 x 512 problem in the fp32 validation mode: north_star's `fp32 logits and loss within 1e-3 relative`"""
+    _check_head_against_oracle(torch.float32, (512, 122000, 512))
+
+
 def _check_head_against_oracle(dtype, shape):
     from frhip import ops
     n, classes, d = shape

@@ -41,3 +41,19 @@ def test_alternet50_eval(golden):
     with torch.no_grad():
         y = alternet_ref.alter_forward(sd, recipe.images(7301, 2, 192, 192), "AlterNet50", False)
     np.testing.assert_allclose(y.numpy(), g["out"], rtol=1e-3, atol=1e-4)
+
+
+def test_alternet50_whole_net_training_mode(golden):
+    """/root/reference/nets/AlterNet_SwinV2_FAN.py:637-751 in training mode at 192 x 192, batch 8: stride-2 stem, conv <-> (W-MSA, SW-MSA)
+    interleave, bn2 -> ReLU -> Dropout(p = 0 here) -> AAP(6,6) -> fc -> bn3 tail"""
+    from wholenet import check_whole_net_train
+    g = golden("alternet50_b8_train")
+    spec = alternet_ref.alter_spec("AlterNet50")
+    sd = alternet_ref.fill_special(recipe.fill_state(spec, int(g["seed"])), spec)
+    names = [k for k, _, kind in spec if kind in ("conv", "linear_w", "linear_b", "bn_w", "bn_b", "logit_scale")]
+    for k in names:
+        sd[k].requires_grad_(True)
+    y = alternet_ref.alter_forward(sd, recipe.images(int(g["seed"]) + 1, int(g["batch"]), 192, 192), "AlterNet50", True)
+    y.backward(recipe.normal(int(g["seed"]) + 2, tuple(y.shape), 0.05))
+    assert {"gprobe." + k for k in names} == {k for k in g if k.startswith("gprobe.")}
+    check_whole_net_train(g, {k: sd[k].grad for k in names}, y.detach().numpy(), {k: v.detach() for k, v in sd.items()}, noise=("fc.bias",))

@@ -3,7 +3,7 @@ import numpy as np
 import pytest
 import torch
 
-from oracle import head_ref, recipe
+from oracle import head_ref, recipe, train_ref
 
 T = torch.from_numpy
 
@@ -79,3 +79,33 @@ def test_shard_arithmetic_covers_all_classes():
         assert spans[0][0] == 0 and sum(n for _, n in spans) == C
         for (a, n), (b, _) in zip(spans, spans[1:]):
             assert a + n == b
+
+
+@pytest.mark.parametrize("name", ["head_adamw_ws1_rate03", "head_adamw_ws2_rate03"])
+def test_head_adamw_steps_match_reference(golden, name):
+    """PartialFCAdamW + torch.optim.AdamW (reference nets/PartialFC.py:235-432, the shipped recipe main/train.sh:12), three steps with
+    fresh embeddings each: per-step loss, sampled rows (bit-exact), dE; then the class centres and both moment tables after update()."""
+    g = golden(name)
+    ws, C, B, D, rate, steps = int(g["ws"]), int(g["C"]), int(g["B"]), int(g["D"]), float(g["rate"]), int(g["steps"])
+    weights = [recipe.normal(500 + r, head_ref.shard_range(C, ws, r)[1:] + (D,), 0.05) for r in range(ws)]
+    opts = [train_ref.AdamWState(float(g["lr"]), tuple(g["betas"]), float(g["eps"]), float(g["wd"])) for _ in range(ws)]
+    for st in range(steps):
+        embs, labs, us = [], [], []
+        for r in range(ws):
+            embs.append(recipe.normal(100 + r + 10 * st, (B, D)))
+            lab = recipe.labels(200 + r + 10 * st, B, C)
+            lab[0] = 3
+            lab[1] = 3
+            labs.append(lab)
+            torch.manual_seed(1000 + r + 100 * st)              # the draw the reference made on rank r (nets/PartialFC.py:312)
+            us.append(torch.rand(weights[r].shape[0]))
+        out = head_ref.head_all_shards(embs, labs, weights, C, float(g["s"]), float(g["m"]), sample_rate=rate, uniforms=us)
+        for r in range(ws):
+            np.testing.assert_allclose(out["loss"].item(), g["r%d_loss_step%d" % (r, st)], rtol=3e-6)
+            assert np.array_equal(out["index"][r].numpy(), g["r%d_index_step%d" % (r, st)])
+            np.testing.assert_allclose(out["d_emb"][r].numpy(), g["r%d_d_emb_step%d" % (r, st)], rtol=2e-4, atol=2e-7)
+            opts[r].head_update(weights[r], out["index"][r], out["d_w_act"][r], rate)
+    for r in range(ws):
+        np.testing.assert_allclose(weights[r].numpy(), g["r%d_weight" % r], rtol=1e-5, atol=2e-6)
+        np.testing.assert_allclose(opts[r].m["head"].numpy(), g["r%d_exp_avg" % r], rtol=2e-4, atol=1e-8)
+        np.testing.assert_allclose(opts[r].v["head"].numpy(), g["r%d_exp_avg_sq" % r], rtol=4e-4, atol=1e-12)

@@ -60,6 +60,10 @@ def test_resnet18_train_and_eval(golden):
     np.testing.assert_allclose(y.detach().numpy(), g["out"], rtol=1e-3, atol=1e-4)
     for k in names:
         _summary_close(sd[k].grad, g["gsum." + k], 2e-3, 2e-5)
+        np.testing.assert_allclose(recipe.probe(sd[k].grad), g["gprobe." + k], rtol=2e-3, atol=2e-5, err_msg=k)    # elementwise: no permutation passes
+    for k in ("conv1.weight", "layer1.0.conv1.weight"):
+        np.testing.assert_allclose(sd[k].grad.numpy(), g["gfull." + k], rtol=2e-3, atol=2e-5, err_msg=k)
+    np.testing.assert_allclose(recipe.probe(sd["fc.weight"].grad, 16384), g["gprobe16k.fc.weight"], rtol=2e-3, atol=2e-5)
     for k in sd:
         if k not in names:
             _summary_close(sd[k].detach().float(), g["after." + k], 1e-4, 1e-6)
@@ -147,3 +151,54 @@ def test_train_steps_two_ranks(golden, tag):
         for k in ("conv1.weight", "layer2.0.downsample.0.weight", "layer4.1.bn2.weight", "fc.weight", "bn3.running_var", "bn1.running_mean"):
             _summary_close(sds[r][k].float(), g["r%d_after.%s" % (r, k)], 5e-3, 5e-5)
         _summary_close(Ws[r], g["r%d_after.head_weight" % r], 5e-3, 5e-5)
+
+
+def _adam_close(got, want, lr, steps, err_msg=""):
+    """Adam moves every element by ~lr per step whatever the size of its gradient (m/sqrt(v) = +-1 on step one): an element whose gradient
+    is rounding noise takes a random direction in any two implementations.  So: nearly all probed elements agree tightly, every one of them
+    stays within the distance the steps can cover, and the l2 norm agrees."""
+    got, want = np.asarray(got, dtype=np.float64), np.asarray(want, dtype=np.float64)
+    d = np.abs(got[2:] - want[2:])
+    assert (d <= 2e-5 + 2e-3 * np.abs(want[2:])).mean() >= 0.97, (err_msg, float((d <= 2e-5 + 2e-3 * np.abs(want[2:])).mean()))
+    assert d.max() <= 2.2 * lr * steps, (err_msg, d.max())
+    np.testing.assert_allclose(got[1], want[1], rtol=2e-3, err_msg=err_msg)
+
+
+@pytest.mark.parametrize("tag", ["rate03", "rate10"])
+def test_train_steps_adamw(golden, tag):
+    """The reference's shipped recipe (main/train.sh:12: --optimizer AdamW --sample_rate 0.3 --lr 5e-4) on BASELINE cfg 1's network:
+    PartialFCAdamW + torch.optim.AdamW over [encoder, head], 3 steps."""
+    g = golden("train_step_resnet18_c256_adamw_" + tag)
+    C, B, steps, rate, lr = int(g["C"]), int(g["B"]), int(g["steps"]), float(g["rate"]), float(g["lr"])
+    blocks = resnet_ref.BLOCKS["ResNet18"]
+    spec = resnet_ref.resnet_spec(blocks)
+    sd = recipe.fill_state(spec, 777)
+    for k, _, kind in spec:
+        if kind in ("bn_w", "bn_rv"):
+            sd[k].fill_(1.0)
+        elif kind in ("bn_b", "bn_rm"):
+            sd[k].zero_()
+    W = recipe.normal(778, (C, 512), 0.01)
+    opt = train_ref.AdamWState(lr, tuple(g["betas"]), float(g["eps"]), float(g["wd"]))
+    for st in range(steps):
+        img, ids = recipe.images(779 + 10 * st, B), recipe.labels(780 + 10 * st, B, C)      # a fresh batch per step
+        u = None
+        if rate < 1:
+            torch.manual_seed(3000 + st)
+            u = [torch.rand(C)]
+        out = train_ref.train_step(sd, W, img, ids, blocks, C, opt, sample_rate=rate, uniforms=u)
+        np.testing.assert_allclose(out["loss"].item(), g["losses"][st], rtol=1e-3 if st == 0 else 5e-3)
+        np.testing.assert_allclose(out["grad_norm"].item(), g["grad_norms"][st], rtol=5e-3 if st == 0 else 2e-2)
+        if rate < 1:
+            assert np.array_equal(out["index"].numpy(), g["index_step%d" % st])
+        if st == 0:
+            for k in [k[6:] for k in g if k.startswith("grad0.")]:
+                np.testing.assert_allclose(recipe.probe(out["grads"][k]), g["grad0." + k], rtol=5e-3, atol=2e-5 + 2e-3 * g["grad0." + k][1] / 16, err_msg=k)
+    for k in [k[6:] for k in g if k.startswith("after.") and not k.startswith("after.head")]:
+        if "running" in k:
+            np.testing.assert_allclose(recipe.probe(sd[k].float()), g["after." + k], rtol=2e-2, atol=1e-5, err_msg=k)
+        else:
+            _adam_close(recipe.probe(sd[k].float()), g["after." + k], lr, steps, k)
+    _adam_close(recipe.probe(W, 4096), g["after.head_weight"], lr, steps, "head weight")
+    np.testing.assert_allclose(recipe.probe(opt.m["head"], 4096)[1], g["after.head_exp_avg"][1], rtol=2e-2)
+    np.testing.assert_allclose(recipe.probe(opt.v["head"], 4096)[1], g["after.head_exp_avg_sq"][1], rtol=4e-2)

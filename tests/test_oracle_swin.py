@@ -65,3 +65,20 @@ def test_swin18_eval_train_and_swin34_eval(golden):
     with torch.no_grad():
         y34 = swin_ref.swin_forward(sd34, recipe.images(6301, 2), "Swin34", False)
     np.testing.assert_allclose(y34.numpy(), g34["eval_out"], rtol=1e-3, atol=1e-4)
+
+
+from wholenet import check_whole_net_train
+
+
+def test_swin34_whole_net_training_mode(golden):
+    """/root/reference/nets/SwinV2.py:534-565 at depth 34, training mode (batch statistics everywhere), batch 8"""
+    g = golden("swin34_b8_train")
+    spec = swin_ref.swin_spec("Swin34")
+    sd = swin_ref.fill_special(recipe.fill_state(spec, int(g["seed"])), spec)
+    names = [k for k, _, kind in spec if kind in ("conv", "linear_w", "linear_b", "bn_w", "bn_b", "logit_scale")]
+    for k in names:
+        sd[k].requires_grad_(True)
+    y = swin_ref.swin_forward(sd, recipe.images(int(g["seed"]) + 1, int(g["batch"])), "Swin34", True)
+    y.backward(recipe.normal(int(g["seed"]) + 2, tuple(y.shape), 0.05))
+    assert {"gprobe." + k for k in names} == {k for k in g if k.startswith("gprobe.")}
+    check_whole_net_train(g, {k: sd[k].grad for k in names}, y.detach().numpy(), {k: v.detach() for k, v in sd.items()}, noise=("fc.bias", "bn2.bias"))

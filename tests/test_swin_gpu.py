@@ -171,16 +171,37 @@ def test_swin18_fp32_eval_and_train_match_reference_fixture(golden):
         np.testing.assert_allclose(got[2:], want[2:], rtol=6e-2, atol=6e-2 * abs(want[1]) + 1e-4, err_msg=k)
 
 
-def test_swin34_fp32_eval_and_bf16_train_step(golden):
+def test_swin34_fp32_eval(golden):
     g = golden("swin34_b2")
     net = _net("Swin34", "fp32", 6300)
     net.eval()
     with torch.no_grad():
         np.testing.assert_allclose(net(recipe.images(6301, 2).cuda()).cpu().numpy(), g["eval_out"], rtol=1e-3, atol=3e-4)
-    net16 = _net("Swin34", "bf16", 6300).train()
-    y = net16(recipe.images(6301, 4).cuda())
-    y.sum().backward()
-    assert torch.isfinite(y).all() and all(torch.isfinite(p.grad).all() for p in net16.parameters())
+
+
+def test_swin34_whole_net_training_mode_fp32_matches_reference_fixture(golden):
+    """BASELINE cfg 4's network (/root/reference/nets/SwinV2.py:534-565 at depth 34) in training mode against the real reference, batch 8:
+    embeddings, EVERY parameter gradient (l2 + 256 elements at portable positions), full tensors of the stem / downsample convs, the first
+    attention block's qkv / position-bias-MLP / logit-scale / q-bias gradients and the tail BatchNorms, running statistics."""
+    from wholenet import check_whole_net_train, whole_net_train_on_gpu
+    g = golden("swin34_b8_train")
+    grads, out, bufs = whole_net_train_on_gpu(_net("Swin34", "fp32", int(g["seed"])), g)
+    check_whole_net_train(g, grads, out, bufs, rtol=1e-2, noise=("fc.bias", "bn2.bias"))
+
+
+def test_swin34_bf16_training_step_tracks_the_reference_fixture(golden):
+    """bf16 MFMA mode on the same inputs: embeddings within 5 %, the large gradients point the reference's way"""
+    from wholenet import whole_net_train_on_gpu
+    g = golden("swin34_b8_train")
+    grads, out, _ = whole_net_train_on_gpu(_net("Swin34", "bf16", int(g["seed"])), g)
+    assert np.isfinite(out).all() and all(torch.isfinite(v).all() for v in grads.values())
+    assert np.linalg.norm(out - g["out"]) <= 5e-2 * np.linalg.norm(g["out"])
+    for k in [k[6:] for k in g if k.startswith("gfull.")]:
+        want = g["gfull." + k].reshape(-1).astype(np.float64)
+        got = grads[k].numpy().reshape(-1).astype(np.float64)
+        if want.size >= 1024:
+            cos = float(got @ want / (np.linalg.norm(got) * np.linalg.norm(want)))
+            assert cos >= 0.97, (k, cos)
 
 
 @pytest.mark.parametrize("ws,heads", [(7, 4), (6, 8), (3, 16)])

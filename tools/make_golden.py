@@ -184,6 +184,10 @@ def gen_resnet():
     arrs = dict(out=y.detach())
     for k, p in net.named_parameters():
         arrs["gsum." + k] = recipe.summary(p.grad)
+        arrs["gprobe." + k] = recipe.probe(p.grad)            # elements at portable positions: a permutation cannot pass
+    arrs["gfull.conv1.weight"] = net.conv1.weight.grad.clone()
+    arrs["gfull.layer1.0.conv1.weight"] = net.layer1[0].conv1.weight.grad.clone()
+    arrs["gprobe16k.fc.weight"] = recipe.probe(net.fc.weight.grad, 16384)
     for k, b in net.named_buffers():
         arrs["after." + k] = recipe.summary(b.float())
     save("resnet18_b4_train", **arrs)
@@ -322,6 +326,175 @@ def gen_train_steps_ws2():
             save("train_step_resnet18_c256_ws2_" + tag, **arrs)
 
 
+# ----------------------------------------------------------------------------- AdamW flavour (the reference's shipped recipe, main/train.sh:12)
+ADAMW = dict(lr=5e-4, wd=5e-4, eps=1e-8, betas=(0.9, 0.999))      # configs/ms1m_arcface_122.py:222-224, main/train.sh:12
+
+
+def _tensor_step(opt):
+    """Container-only shim: PartialFCAdamW.sample() stores a python int in optimizer.state[...]['step'] (nets/PartialFC.py:327);
+    torch >= 2 wants a tensor there.  Same value, tensor type."""
+    for st in opt.state.values():
+        if "step" in st and not torch.is_tensor(st["step"]):
+            st["step"] = torch.tensor(float(st["step"]))
+
+
+def _head_adamw_worker(rank, ws, path, cfg, out_dir):
+    _, P, _ = _ref()
+    _init_pg(rank, ws, path)
+    C, B, D, rate, steps = cfg["C"], cfg["B"], cfg["D"], cfg["rate"], cfg["steps"]
+    conf = types.SimpleNamespace(emd_size=D, sample_rate=rate, mixed_precision=False, loss_s=30.0, loss_m=0.35)
+    pfc = P.PartialFCAdamW(conf, C)
+    W = recipe.normal(500 + rank, (pfc.num_local, D), 0.05)
+    with torch.no_grad():
+        (pfc.weight if rate < 1 else pfc.weight_activated.data).copy_(W)
+    dummy = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.AdamW([{"params": [dummy]}, {"params": pfc.parameters()}], lr=ADAMW["lr"], weight_decay=ADAMW["wd"],
+                            eps=ADAMW["eps"], betas=ADAMW["betas"])
+    arrs = dict(class_start=pfc.class_start, num_local=pfc.num_local, num_sample=pfc.num_sample)
+    for st in range(steps):
+        opt.zero_grad()
+        emb = recipe.normal(100 + rank + 10 * st, (B, D)).requires_grad_(True)
+        lab = recipe.labels(200 + rank + 10 * st, B, C)
+        lab[0] = 3
+        lab[1] = 3
+        torch.manual_seed(1000 + rank + 100 * st)
+        loss = pfc(emb, lab.clone(), opt)
+        loss.backward()
+        _tensor_step(opt)
+        opt.step()
+        arrs["loss_step%d" % st] = loss.detach().clone()
+        arrs["d_emb_step%d" % st] = emb.grad.clone()
+        arrs["index_step%d" % st] = (pfc.weight_index if rate < 1 else torch.arange(pfc.num_local)).clone().long()
+    pfc.update()
+    if rate < 1:
+        arrs.update(weight=pfc.weight.clone(), exp_avg=pfc.weight_exp_avg.clone(), exp_avg_sq=pfc.weight_exp_avg_sq.clone())
+    else:
+        stt = opt.state[pfc.weight_activated]
+        arrs.update(weight=pfc.weight_activated.data.clone(), exp_avg=stt["exp_avg"].clone(), exp_avg_sq=stt["exp_avg_sq"].clone())
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), **{k: (v.detach().numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in arrs.items()})
+    dist.destroy_process_group()
+
+
+def gen_head_adamw(ws, rate=0.3, C=503, B=6, D=128, steps=3):
+    cfg = dict(C=C, B=B, D=D, rate=rate, steps=steps)
+    with tempfile.TemporaryDirectory() as td:
+        if ws == 1:
+            _head_adamw_worker(0, 1, os.path.join(td, "pg"), cfg, td)
+        else:
+            mp.spawn(_head_adamw_worker, args=(ws, os.path.join(td, "pg"), cfg, td), nprocs=ws, join=True)
+        arrs = dict(C=C, B=B, D=D, rate=rate, steps=steps, ws=ws, s=30.0, m=0.35, lr=ADAMW["lr"], wd=ADAMW["wd"], eps=ADAMW["eps"],
+                    betas=np.asarray(ADAMW["betas"]))
+        for r in range(ws):
+            for k, v in np.load(os.path.join(td, "rank%d.npz" % r)).items():
+                arrs["r%d_%s" % (r, k)] = v
+        save("head_adamw_ws%d_rate%s" % (ws, str(rate).replace(".", "")), **arrs)
+
+
+TRAIN_PROBED = ("conv1.weight", "layer2.0.downsample.0.weight", "layer3.1.conv2.weight", "layer4.1.bn2.weight", "fc.weight",
+                "bn3.weight", "bn3.running_var", "bn1.running_mean")
+
+
+def gen_train_steps_adamw():
+    """model/FR_PartialFC.py:162-193 with the AdamW branch of configure_optimizers (:436-442) and PartialFCAdamW, rate 0.3."""
+    _, P, R = _ref()
+    import torch.nn.functional as F
+    for tag, rate in {"rate03": 0.3, "rate10": 1.0}.items():
+        with tempfile.TemporaryDirectory() as td:
+            _init_pg(0, 1, os.path.join(td, "pg"))
+            C, B, steps = 256, 16, 3
+            conf = types.SimpleNamespace(network="ResNet18", emd_size=512, sample_rate=rate, mixed_precision=False, loss_s=30.0, loss_m=0.35)
+            enc = R.ResNet18(conf)
+            spec = resnet_ref.resnet_spec(resnet_ref.BLOCKS["ResNet18"])
+            sd = recipe.fill_state(spec, 777)
+            for k, _, kind in spec:
+                if kind == "bn_w" or kind == "bn_rv":
+                    sd[k].fill_(1.0)
+                elif kind in ("bn_b", "bn_rm"):
+                    sd[k].zero_()
+            enc.load_state_dict(sd, strict=True)
+            pfc = P.PartialFCAdamW(conf, C)
+            W = recipe.normal(778, (C, 512), 0.01)
+            with torch.no_grad():
+                (pfc.weight if rate < 1 else pfc.weight_activated.data).copy_(W)
+            opt = torch.optim.AdamW([{"params": enc.parameters()}, {"params": pfc.parameters()}], lr=ADAMW["lr"], weight_decay=ADAMW["wd"],
+                                    eps=ADAMW["eps"], betas=ADAMW["betas"])
+            arrs = dict(C=C, B=B, steps=steps, rate=rate, lr=ADAMW["lr"], wd=ADAMW["wd"], eps=ADAMW["eps"], betas=np.asarray(ADAMW["betas"]))
+            losses, gnorms = [], []
+            for st in range(steps):
+                # a fresh batch per step: one Adam step memorises a repeated 16-image batch (loss 15 -> 1e-6) and later steps would pin nothing
+                img = recipe.images(779 + 10 * st, B)
+                ids = recipe.labels(780 + 10 * st, B, C)
+                opt.zero_grad()
+                enc.train()
+                feat = F.normalize(enc(img))
+                torch.manual_seed(3000 + st)
+                loss = pfc(feat, ids.clone(), opt)
+                loss.backward()
+                gn = torch.nn.utils.clip_grad_norm_(enc.parameters(), 5)
+                if st == 0:
+                    for k, p_ in enc.named_parameters():
+                        if k in TRAIN_PROBED:
+                            arrs["grad0." + k] = recipe.probe(p_.grad)      # the (clipped) gradients of step 0: sign-insensitive pin
+                _tensor_step(opt)
+                opt.step()
+                losses.append(loss.detach().clone())
+                gnorms.append(gn.detach().clone())
+                if rate < 1:
+                    arrs["index_step%d" % st] = pfc.weight_index.clone()
+            if rate < 1:
+                pfc.update()
+                arrs.update({"after.head_weight": recipe.probe(pfc.weight, 4096), "after.head_exp_avg": recipe.probe(pfc.weight_exp_avg, 4096),
+                             "after.head_exp_avg_sq": recipe.probe(pfc.weight_exp_avg_sq, 4096)})
+            else:
+                stt = opt.state[pfc.weight_activated]
+                arrs.update({"after.head_weight": recipe.probe(pfc.weight_activated.data, 4096), "after.head_exp_avg": recipe.probe(stt["exp_avg"], 4096),
+                             "after.head_exp_avg_sq": recipe.probe(stt["exp_avg_sq"], 4096)})
+            arrs.update(losses=torch.stack(losses), grad_norms=torch.stack(gnorms))
+            esd = enc.state_dict()
+            for k in TRAIN_PROBED:
+                arrs["after." + k] = recipe.probe(esd[k].float())
+            for k, p_ in enc.named_parameters():
+                if k in TRAIN_PROBED:
+                    arrs["exp_avg." + k] = recipe.probe(opt.state[p_]["exp_avg"])
+                    arrs["exp_avg_sq." + k] = recipe.probe(opt.state[p_]["exp_avg_sq"])
+            save("train_step_resnet18_c256_adamw_" + tag, **arrs)
+            dist.destroy_process_group()
+
+
+FULL_SWIN34 = ("conv1.weight", "layer2.0.weight", "layer3.0.weight", "layer3.1.attn.qkv.weight", "layer3.1.attn.cpb_mlp.0.weight", "layer3.1.attn.cpb_mlp.2.weight",
+               "layer3.1.attn.logit_scale", "layer3.1.attn.q_bias", "bn2.weight",
+               "bn3.weight", "bn3.bias")
+FULL_ALTERNET50 = ("conv1.weight", "layer1.0.conv1.weight", "layer2.2.attn.qkv.weight", "layer2.2.attn.cpb_mlp.0.weight", "layer2.2.attn.cpb_mlp.2.weight",
+                   "layer2.3.attn.qkv.weight", "layer2.3.attn.logit_scale", "layer2.1.conv2.weight", "layer4.0.downsample.0.weight", "bn2.weight", "bn3.weight",
+                   "bn3.bias")
+
+
+def _whole_net_train(name, net, spec, fill_special, seed, x, full):
+    """One training-mode forward/backward of a whole reference backbone (BatchNorm in batch-statistics mode, stochastic depth = identity
+    through the DropPath stub, tail Dropout p = 0: RNG-free), batch 8 so that the tail BatchNorm1d is well conditioned.  Stored: the
+    embeddings, a probe (sum, l2, 256 elements at portable positions) of EVERY parameter gradient, full tensors of the named ones and of
+    every attention block's first-in-stage qkv / cpb gradients that fit, probes of the running statistics."""
+    assert [k for k, _, _ in spec] == list(net.state_dict().keys()), name
+    sd = fill_special(recipe.fill_state(spec, seed), spec)
+    net.load_state_dict(sd, strict=True)
+    net.train()
+    net.dropout.p = 0.0
+    y = net(x)
+    y.backward(recipe.normal(seed + 2, tuple(y.shape), 0.05))
+    arrs = dict(out=y.detach(), batch=x.shape[0], seed=seed)
+    for k, p in net.named_parameters():
+        arrs["gprobe." + k] = recipe.probe(p.grad)
+        if k in full:
+            assert p.numel() <= (1 << 20), k
+            arrs["gfull." + k] = p.grad.clone()
+    assert all(("gfull." + k) in arrs for k in full), [k for k in full if ("gfull." + k) not in arrs]
+    arrs["gprobe16k.fc.weight"] = recipe.probe(net.fc.weight.grad, 16384)
+    for k, b in net.named_buffers():
+        if "running" in k:
+            arrs["after." + k] = recipe.probe(b.float())
+    save(name, **arrs)
+
+
 # ----------------------------------------------------------------------------- SwinV2-style backbone
 def _swin_ref():
     """reference nets/SwinV2.py needs three symbols of timm.models.layers: stubbed, container only"""
@@ -390,6 +563,8 @@ def gen_swin():
                 if "running" in k:
                     arrs["after." + k] = recipe.summary(b.float())
         save(name.lower() + "_b2", **arrs)
+    _whole_net_train("swin34_b8_train", S.Swin34(types.SimpleNamespace(network="Swin34", emd_size=512)), swin_ref.swin_spec("Swin34"),
+                     swin_ref.fill_special, 6400, recipe.images(6401, 8), FULL_SWIN34)
 
 
 # ----------------------------------------------------------------------------- hybrid AlterNet backbone
@@ -437,6 +612,7 @@ def gen_alternet():
     net.eval()
     with torch.no_grad():
         save("alternet50_b2_eval", out=net(recipe.images(7301, 2, 192, 192)), n_keys=len(spec))
+    _whole_net_train("alternet50_b8_train", A.AlterNet50(conf), spec, alternet_ref.fill_special, 7400, recipe.images(7401, 8, 192, 192), FULL_ALTERNET50)
 
 
 # ----------------------------------------------------------------------------- verification metrics
@@ -522,6 +698,9 @@ GENS = {
     "resnet": gen_resnet,
     "train": gen_train_steps,
     "train_ws2": gen_train_steps_ws2,
+    "head_adamw_ws1": lambda: gen_head_adamw(1),
+    "head_adamw_ws2": lambda: gen_head_adamw(2),
+    "train_adamw": gen_train_steps_adamw,
 }
 
 if __name__ == "__main__":
