@@ -191,8 +191,11 @@ static size_t EW_NT_BYTES = (size_t)(getenv("FRHIP_EW_NT_MB") ? atoi(getenv("FRH
 // tensor the convolution has just written: 26.34 vs 26.40 ms over four same-box A/B rounds, 26.67 vs 26.73 over two more.)
 static int g_ew_nt = getenv("FRHIP_EW_NT") ? atoi(getenv("FRHIP_EW_NT")) : 1;
 
-template <typename T, bool NTL, bool NTS, bool RS = false>
-__global__ __launch_bounds__(EW_THREADS) void bn_apply_kernel(const T* __restrict__ y, const float* __restrict__ scale,
+// INPLACE: out IS y (frhip_conv_fwd_affine's unfused route normalises the convolution's output where it lies).  Two __restrict__ pointers
+// to one buffer would be undefined behaviour -- the compiler may then move a later row's load across an earlier row's store -- so this
+// instantiation reads through `out` itself.
+template <typename T, bool NTL, bool NTS, bool RS = false, bool INPLACE = false>
+__global__ __launch_bounds__(EW_THREADS) void bn_apply_kernel(const T* __restrict__ y_in, const float* __restrict__ scale,
                                                               const float* __restrict__ shift, const T* __restrict__ res,
                                                               const float* __restrict__ rscale, const float* __restrict__ rshift,
                                                               int relu, T* __restrict__ out, int rows, int C,
@@ -201,6 +204,7 @@ __global__ __launch_bounds__(EW_THREADS) void bn_apply_kernel(const T* __restric
     const int vpr = C / EPV;
     const int cg = threadIdx.x % vpr, rl = threadIdx.x / vpr, rlanes = EW_THREADS / vpr;
     float sc[EPV], sh[EPV], rs[EPV], rb[EPV];
+    const T* y = INPLACE ? out : y_in;
 #pragma unroll
     for (int e = 0; e < EPV; ++e) {
         sc[e] = scale[cg * EPV + e]; sh[e] = shift[cg * EPV + e];
@@ -477,6 +481,15 @@ extern "C" int frhip_bn_apply(int dtype, const void* y, const float* scale, cons
 #define BN_APPLY_PICK(T)                                                                                                      \
     do { if (ntl && nts) BN_APPLY_GO(T, true, true); else if (ntl) BN_APPLY_GO(T, true, false);                               \
          else if (nts) BN_APPLY_GO(T, false, true); else BN_APPLY_GO(T, false, false); } while (0)
+    if (y == out) {            // in place: the instantiation that reads through `out` (plain loads and stores)
+        if (dtype == FRHIP_DT_BF16)
+            hipLaunchKernelGGL((bn_apply_kernel<bf16_t, false, false, false, true>), dim3(blocks), dim3(EW_THREADS), 0, stream, nullptr, scale, shift,
+                               (const bf16_t*)res, res_scale, res_shift, relu, (bf16_t*)out, rows, c);
+        else
+            hipLaunchKernelGGL((bn_apply_kernel<float, false, false, false, true>), dim3(blocks), dim3(EW_THREADS), 0, stream, nullptr, scale, shift,
+                               (const float*)res, res_scale, res_shift, relu, (float*)out, rows, c);
+        return check_launch("frhip_bn_apply");
+    }
     if (dtype == FRHIP_DT_BF16) BN_APPLY_PICK(bf16_t); else BN_APPLY_PICK(float);
 #undef BN_APPLY_PICK
 #undef BN_APPLY_GO

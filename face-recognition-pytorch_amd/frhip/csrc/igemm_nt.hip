@@ -105,13 +105,15 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN) / 4) void nt_kernel(NtGeom 
 // FRHIP_NT_PERSIST=0: one workgroup per tile also for the lean launches (A/B switch)
 static const int g_nt_persist = getenv("FRHIP_NT_PERSIST") ? atoi(getenv("FRHIP_NT_PERSIST")) : 1;
 static int nt_cus() {
-    static int cus = 0;
-    if (!cus) {
-        int dev = 0, v = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
-        cus = v;
+    static int cus[16] = {0};                      // per device: a process that drives a second GPU sizes its grids for THAT chip
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) { (void)hipGetLastError(); return 256; }
+    if (!cus[dev]) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        cus[dev] = v;
     }
-    return cus;
+    return cus[dev];
 }
 
 template <typename T, int WM, int WN, int MT, int EPI>

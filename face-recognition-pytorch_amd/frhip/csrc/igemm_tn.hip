@@ -665,12 +665,15 @@ constexpr int T9_TAB_GEOMS = 8, T9_TAB_MAXP = 64;
 __device__ unsigned long long g_t9_masks[T9_TAB_GEOMS][T9_TAB_MAXP * 16];
 static int g_t9_tab = getenv("FRHIP_T9_MASK_TABLE") ? atoi(getenv("FRHIP_T9_MASK_TABLE")) : 1;
 static bool t9_mask_table(TnGeom& g, hipStream_t stream) {
-    static struct { int h, w, period; const unsigned long long* dev; } cache[T9_TAB_GEOMS];
+    // keyed by DEVICE too: g_t9_masks is module memory, every device has its own copy at its own address
+    static struct { int device, h, w, period; const unsigned long long* dev; } cache[T9_TAB_GEOMS];
     static int used = 0;
     g.mask_tab = nullptr; g.mask_period = 0;
     if (!g_t9_tab) return false;
+    int device = 0;
+    if (hipGetDevice(&device) != hipSuccess) { (void)hipGetLastError(); return false; }
     for (int i = 0; i < used; ++i)
-        if (cache[i].h == g.H && cache[i].w == g.W) { g.mask_tab = cache[i].dev; g.mask_period = cache[i].period; return true; }
+        if (cache[i].device == device && cache[i].h == g.H && cache[i].w == g.W) { g.mask_tab = cache[i].dev; g.mask_period = cache[i].period; return true; }
     const int hw = g.H * g.W;
     int a = hw, b = 64;
     while (b) { const int t = a % b; a = b; b = t; }
@@ -699,7 +702,7 @@ static bool t9_mask_table(TnGeom& g, hipStream_t stream) {
     if (hipGetSymbolAddress(&sym, HIP_SYMBOL(g_t9_masks)) != hipSuccess) return false;
     unsigned long long* dev = reinterpret_cast<unsigned long long*>(sym) + (size_t)used * T9_TAB_MAXP * 16;
     if (hipMemcpy(dev, host, sizeof(unsigned long long) * period * 16, hipMemcpyHostToDevice) != hipSuccess) { (void)hipGetLastError(); return false; }
-    cache[used].h = g.H; cache[used].w = g.W; cache[used].period = period; cache[used].dev = dev;
+    cache[used].device = device; cache[used].h = g.H; cache[used].w = g.W; cache[used].period = period; cache[used].dev = dev;
     ++used;
     g.mask_tab = dev; g.mask_period = period;
     return true;

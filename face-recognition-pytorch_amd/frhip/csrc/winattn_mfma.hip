@@ -520,13 +520,15 @@ __global__ __launch_bounds__(256, 1) void wm_bwd_kernel(const bf16_t* __restrict
 // windows and that fixed cost was a third of the launch.  One workgroup per CU (the backward kernel's LDS allows no second one anyway):
 // Swin34 15.93 -> 15.44 ms, AlterNet50 13.11 -> 12.68 ms (same-box A/B over 1024 / 512 / 384 / 256 / 192); forward 4 per CU (-0.05 ms).
 static int wm_cus() {
-    static int cus = 0;
-    if (!cus) {
-        int dev = 0, v = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
-        cus = v;
+    static int cus[16] = {0};                      // per device: a process that drives a second GPU sizes its grids for THAT chip
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) { (void)hipGetLastError(); return 256; }
+    if (!cus[dev]) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        cus[dev] = v;
     }
-    return cus;
+    return cus[dev];
 }
 
 static int wm_chunks(int nwin, int heads, int target_wgs, int* wpb_out) {
@@ -552,7 +554,8 @@ static int wm_fwd_launch(const void* qkv, const float* bias, const float* scale,
         attr_done = true;
     }
     int wpb;
-    static const int target = getenv("FRHIP_WA_FWD_WGS") ? atoi(getenv("FRHIP_WA_FWD_WGS")) : 4 * wm_cus();
+    static const int env_fwd = getenv("FRHIP_WA_FWD_WGS") ? atoi(getenv("FRHIP_WA_FWD_WGS")) : 0;
+    const int target = env_fwd ? env_fwd : 4 * wm_cus();
     const int chunks = wm_chunks(nwin, heads, target, &wpb);
     hipLaunchKernelGGL(wm_fwd_kernel<NT>, dim3(heads * chunks), dim3(256), lds, stream, (const bf16_t*)qkv, bias, scale, (bf16_t*)out,
                        nwin, g, C, wpb, heads);
@@ -582,7 +585,8 @@ static int wm_bwd_launch(const void* qkv, const void* dout, const float* bias, c
         attr_done = true;
     }
     int wpb;
-    static const int target = getenv("FRHIP_WA_BWD_WGS") ? atoi(getenv("FRHIP_WA_BWD_WGS")) : wm_cus();
+    static const int env_bwd = getenv("FRHIP_WA_BWD_WGS") ? atoi(getenv("FRHIP_WA_BWD_WGS")) : 0;
+    const int target = env_bwd ? env_bwd : wm_cus();
     const int chunks = wm_chunks(nwin, heads, target, &wpb);
     hipLaunchKernelGGL(wm_bwd_kernel<NT>, dim3(heads * chunks), dim3(256), lds, stream, (const bf16_t*)qkv, (const bf16_t*)dout, bias,
                        scale, (bf16_t*)dqkv, dbias, dscale, colsum, nwin, g, C, wpb, heads);

@@ -1,4 +1,6 @@
 """Tensor-level wrappers over the C ABI (torch is used for device memory + the current HIP stream only)."""
+import weakref
+
 import torch
 
 from . import _abi
@@ -352,14 +354,29 @@ def colsum_accumulate(x2d, out_accum):
     return out_accum
 
 
+_DROP_GEN = None
+
+
+def _drop_generator():
+    """CPU generator of the dropout / stochastic-depth seeds, seeded once from torch.initial_seed().  NOT torch's default CPU generator:
+    that one feeds PartialFC.sample's torch.rand(num_local) (/root/reference/nets/PartialFC.py:110), and the reference's nn.Dropout draws
+    from the DEVICE generator -- a Swin / AlterNet step must leave the CPU stream exactly where the reference leaves it, or the sampled
+    negative rows stop matching it seed for seed."""
+    global _DROP_GEN
+    if _DROP_GEN is None:
+        _DROP_GEN = torch.Generator()
+        _DROP_GEN.manual_seed(torch.initial_seed() & ((1 << 63) - 1))
+    return _DROP_GEN
+
+
 def dropout_mask(shape, dtype, keep, device, seed=None):
-    """mask of `shape`: 1/keep with probability keep, else 0 (one launch).  seed None: drawn from torch's CPU generator"""
+    """mask of `shape`: 1/keep with probability keep, else 0 (one launch).  seed None: drawn from a generator of its own (_drop_generator)"""
     if seed is None:
         if torch.cuda.is_current_stream_capturing():
             # a captured graph would replay ONE host-drawn seed, i.e. the same mask every step: torch's device generator is graph-safe
             # (its Philox offset advances per replay), so the capture records the four-pass torch formulation instead
             return (torch.rand(shape, device=device) < keep).to(dtype) / keep
-        seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+        seed = int(torch.randint(0, 2 ** 62, (1,), generator=_drop_generator()).item())
     mask = torch.empty(shape, dtype=dtype, device=device)
     check(lib().frhip_dropout_mask(_DT[dtype], _p(mask), mask.numel(), float(keep), int(seed), _s()), "frhip_dropout_mask")
     return mask
@@ -785,6 +802,8 @@ def quant_fp8_weights_multi(weights):
     import numpy as np
     key = tuple(w.data_ptr() for w in weights)
     hit = _Q8W.get(key)
+    if hit is not None and any(r() is None for r in hit[6]):
+        hit = None                                   # a weight of that entry is gone (its address was recycled): rebuild
     if hit is None:
         dev = weights[0].device
         bytes8 = torch.empty(sum(w.numel() for w in weights), dtype=torch.uint8, device=dev)
@@ -802,10 +821,17 @@ def quant_fp8_weights_multi(weights):
             off += n
             rows += k
             outs.append((w8, sc))
-        table = torch.from_numpy(tab.view(np.uint8).copy()).to(dev)
+        # staged through a pinned slot with an async copy (a memcpy node when the first fp8 forward happens inside a graph capture, where a
+        # blocking pageable copy is illegal), like optim._build_table; the slot lives as long as the cache entry
+        raw = torch.from_numpy(tab.view(np.uint8).copy())
+        pin = torch.empty(raw.numel(), dtype=torch.uint8, pin_memory=True)
+        pin.copy_(raw)
+        table = torch.empty(raw.numel(), dtype=torch.uint8, device=dev)
+        table.copy_(pin, non_blocking=True)
         if len(_Q8W) >= 8:
             _Q8W.clear()
-        hit = _Q8W[key] = (table, len(weights), rows, outs, bytes8, scales, list(weights))
+        # weights held by weak reference: the cache must not keep a dead model's parameters alive
+        hit = _Q8W[key] = (table, len(weights), rows, outs, bytes8, scales, [weakref.ref(w) for w in weights], pin)
     table, n, rows, outs = hit[:4]
     check(lib().frhip_quant_fp8_weights_multi(_p(table), n, rows, _s()), "frhip_quant_fp8_weights_multi")
     return outs

@@ -158,6 +158,10 @@ class SGD(torch.optim.SGD):
         for st in self._early.values():
             torch.cuda.current_stream().wait_stream(st)
         self._early = {}
+        # a head update still parked for a backward pass that never reached a frhip backbone belongs to the step that ends here
+        self._frhip_step_token = getattr(self, "_frhip_step_token", 0) + 1
+        from nets import _backbone as _bb
+        _bb.drop_deferred(self)
         return super().zero_grad(set_to_none=set_to_none)
 
     def _fallback(self, clip, done=()):

@@ -109,8 +109,7 @@ class Model(nn.Module):
         loss.backward()
         # an early head update the backbone's backward pass did not get to launch (the hook fired behind it): launch it now, so that
         # nothing parked survives into the next step
-        while _bb.DEFERRED_SIDE:
-            _bb.DEFERRED_SIDE.pop(0)()
+        _bb.run_deferred_side()
         if hasattr(self.opt, "last_grad_norm"):          # frhip.optim.SGD: the clip rides inside the fused update
             self.opt.step(clip=(self.encoder.parameters(), 5))
         else:

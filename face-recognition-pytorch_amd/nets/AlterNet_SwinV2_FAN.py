@@ -21,7 +21,7 @@ import torch.nn as nn
 from frhip import ops
 
 from . import SwinV2 as _S
-from ._backbone import (BackwardCtx, BasicBlock, Fp8Ctx, Saved, _BN, _Conv, _Linear, basic_block_backward,  # noqa: F401
+from ._backbone import (BackwardCtx, BasicBlock, DEFER_EARLY_BLOCKS, Fp8Ctx, Saved, _BN, _Conv, _Linear, basic_block_backward,  # noqa: F401
                         basic_block_forward, bn_forward_state, compute_dtype, encoder_call, prepare_conv_weights,
                         stem_backward,
                         stem_forward, tail_backward, tail_forward, use_fp8)
@@ -265,6 +265,8 @@ class AlterNet(nn.Module):
                 dout, part = res if nxt is not None else (res, None)
             else:
                 dout, part = attn_block_backward(mod, s, dout, dt, bc), None
+            if len(layers) - 1 - i == DEFER_EARLY_BLOCKS:
+                bc.run_deferred()                          # the head's early parameter update: beside the blocks, not beside the tail
         stem_backward(self, sv, dout, bc)
         return bc.join()
 

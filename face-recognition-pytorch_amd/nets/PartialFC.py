@@ -541,8 +541,7 @@ class _PartialFCBase(torch.nn.Module):
             def launch():
                 opt.step_group_early(len(opt.param_groups) - 1, bb.side_stream(param.device))
             if bb.DEFER_EARLY_BLOCKS >= 0:
-                del bb.DEFERRED_SIDE[:]            # at most one parked update (a stale one belongs to a backward pass that never ran)
-                bb.DEFERRED_SIDE.append(launch)    # the backbone's backward pass launches it a few blocks in (or its join() does)
+                bb.park_deferred(opt, launch)      # the backbone's backward pass launches it a few blocks in (or its join() does)
             else:
                 launch()
 

@@ -27,7 +27,7 @@ import torch.nn.functional as F
 
 from frhip import ops
 
-from ._backbone import (BackwardCtx, BasicBlock, Saved, _BN, _Conv, _Linear, bn_forward_state, compute_dtype,  # noqa: F401
+from ._backbone import (BackwardCtx, BasicBlock, DEFER_EARLY_BLOCKS, Saved, _BN, _Conv, _Linear, bn_forward_state, compute_dtype,  # noqa: F401
                         stem_reduction_operands,
                         encoder_call, phys_grad, stem_backward, stem_forward, tail_backward, tail_forward)
 
@@ -449,6 +449,8 @@ class Swin(nn.Module):
                 nxt = None
             res = swin_block_backward(mod, s, dout, dt, bc, next_bn=nxt, part3=part)
             dout, part = res if nxt is not None else (res, None)
+            if len(layers) - 1 - i == DEFER_EARLY_BLOCKS:
+                bc.run_deferred()                          # the head's early parameter update: beside the blocks, not beside the tail
         stem_backward(self, sv, dout, bc, part)
         return bc.join()
 

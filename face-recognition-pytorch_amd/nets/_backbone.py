@@ -219,7 +219,30 @@ def side_stream(device):
 # PartialFC head parks its early parameter update here (1.25 GB of HBM traffic at 122 000 classes).  Launched right away it collides with
 # the backbone's tail -- a chain of a dozen small, latency-bound kernels (bn3 / fc / bn2 backward) whose every load then queues behind a
 # saturated memory system; a few blocks later the main stream runs MFMA-bound 512-channel convolutions that do not mind.
+# Entries are (owner optimizer, the owner's step token when parked, launch): an entry whose owner has since begun another step (zero_grad()
+# bumps the token) or was collected is dropped, never launched -- a closure parked by a backward pass that did not reach a frhip backbone
+# (frozen / foreign encoder, exception) cannot fire on a later step's gradients or under another model's backward pass.
 DEFERRED_SIDE = []
+
+
+def park_deferred(owner, launch):
+    import weakref
+    del DEFERRED_SIDE[:]                  # at most one parked update
+    DEFERRED_SIDE.append((weakref.ref(owner), getattr(owner, "_frhip_step_token", 0), launch))
+
+
+def run_deferred_side():
+    while DEFERRED_SIDE:
+        ref, token, launch = DEFERRED_SIDE.pop(0)
+        owner = ref()
+        if owner is not None and getattr(owner, "_frhip_step_token", 0) == token:
+            launch()
+
+
+def drop_deferred(owner):
+    DEFERRED_SIDE[:] = [e for e in DEFERRED_SIDE if e[0]() is not None and e[0]() is not owner]
+
+
 DEFER_EARLY_BLOCKS = int(os.environ.get("FRHIP_EARLY_HEAD_DEFER", "2"))      # blocks of the backward pass to let go by (-1: launch at once)
 
 
@@ -304,8 +327,7 @@ class BackwardCtx:
 
     def run_deferred(self):
         """launch the side-stream work other modules parked for the backward pass (DEFERRED_SIDE: the head's early parameter update)"""
-        while DEFERRED_SIDE:
-            DEFERRED_SIDE.pop(0)()
+        run_deferred_side()
 
     def join(self):
         self.run_deferred()

@@ -124,9 +124,10 @@ def test_resnet50_bf16_training_step_vs_oracle(pg):
     bad = []
     for k, (c, r, n) in hip.items():
         factor = 1.5 if n > 10000 else 2.0           # BatchNorm vectors of 64-512 elements: the per-tensor statistic itself is noisy
-        # absolute floor 0.90 -- unless the storage-only emulation itself sits at it (layer1.2.bn2.bias: 0.9000 emulated; builds
-        # that differ only in summation order gave 0.90 - 0.94 for that 64-element vector): then the floor follows the emulation
-        if (1.0 - c) > factor * (1.0 - emu[k]) + 2e-3 or c < min(0.90, emu[k] - 0.02) or not (0.88 < r < 1.12):
+        # absolute floor 0.90 for every tensor but ONE, named: layer1.2.bn2.bias, a 64-element vector whose storage-only emulation itself
+        # sits at 0.9000 (builds that differ only in summation order gave 0.90 - 0.94 for it); its floor follows the emulation
+        floor = min(0.90, emu[k] - 0.02) if k == "layer1.2.bn2.bias" else 0.90
+        if (1.0 - c) > factor * (1.0 - emu[k]) + 2e-3 or c < floor or not (0.88 < r < 1.12):
             bad.append("%s: cosine vs fp32 %.4f (bf16-storage emulation: %.4f), norm ratio %.3f" % (k, c, emu[k], r))
     assert not bad, "bf16 gradients worse than bf16 storage explains:\n" + "\n".join(bad)
     mean_hip = float(np.mean([1.0 - c for c, _, _ in hip.values()])), float(np.mean([1.0 - c for c in emu.values()]))

@@ -193,7 +193,8 @@ def test_train_steps_adamw(golden, tag):
             assert np.array_equal(out["index"].numpy(), g["index_step%d" % st])
         if st == 0:
             for k in [k[6:] for k in g if k.startswith("grad0.")]:
-                np.testing.assert_allclose(recipe.probe(out["grads"][k]), g["grad0." + k], rtol=5e-3, atol=2e-5 + 2e-3 * g["grad0." + k][1] / 16, err_msg=k)
+                want = g["grad0." + k]
+                np.testing.assert_allclose(recipe.probe(out["grads"][k]), want, rtol=5e-3, atol=5e-3 * want[1] / out["grads"][k].numel() ** 0.5, err_msg=k)
     for k in [k[6:] for k in g if k.startswith("after.") and not k.startswith("after.head")]:
         if "running" in k:
             np.testing.assert_allclose(recipe.probe(sd[k].float()), g["after." + k], rtol=2e-2, atol=1e-5, err_msg=k)

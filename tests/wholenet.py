@@ -7,11 +7,22 @@ from oracle import recipe
 NOISE_TAILS = ("proj.bias", "fc2.bias", "v_bias")
 
 
-def check_whole_net_train(g, grads, out, running, rtol=5e-3, noise=()):
+def check_whole_net_train(g, grads, out, running, rtol=5e-3, noise=(), kink_rtol=None, kink_free=()):
     """shared by the oracle (CPU) and the HIP (GPU) whole-network training-mode tests: embeddings, a probe of EVERY parameter gradient
     (sum, l2, 256 elements at portable positions -- a layout permutation cannot pass), full tensors where the fixture holds them, running
-    statistics.  Element tolerance = rtol of the value + rtol x the tensor's rms (fp32 summation order through 30-50 BatchNorm'd blocks)."""
+    statistics.  Element tolerance = rtol of the value + 2 rtol x the tensor's rms (fp32 summation order through 30-50 BatchNorm'd blocks).
+
+    kink_rtol: AlterNet's tail is bn2 -> ReLU -> fc, and of its 147 456 pre-ReLU values seven lie within 1e-4 of zero on the fixture's input.
+    An implementation whose bn2 output differs from the reference's by 1e-4 (fp32 round-off after 50 blocks) takes the other side of the kink
+    for a few of them, which moves EVERY upstream gradient by about 1.4 % of its rms -- measured on the oracle by shifting the kink by 1e-4:
+    5 elements flip, layer4.3.attn.qkv.weight moves by 1.40e-2 rms (the HIP fp32 path: 1.39e-2), the tail's own gradients (fc, bn3, bn2,
+    layer4.3's proj / norm2) by < 3e-4.  So: the tensors named by `kink_free` prefixes are held to rtol, everything upstream of the kink to
+    kink_rtol -- still 30x below what any indexing / layout defect produces (an error of the order of the rms itself)."""
     np.testing.assert_allclose(out, g["out"], rtol=rtol, atol=rtol * float(np.abs(g["out"]).max()))
+
+    def tol_of(k):
+        return rtol if (kink_rtol is None or k.startswith(tuple(kink_free))) else kink_rtol
+
     for key in [k for k in g if k.startswith("gprobe.")]:
         k = key[7:]
         want = g[key]
@@ -20,17 +31,42 @@ def check_whole_net_train(g, grads, out, running, rtol=5e-3, noise=()):
         if k.endswith(NOISE_TAILS) or k in noise or rms < 1e-7:           # analytically-zero gradients (a shift in front of a training-mode BatchNorm): size only
             assert np.abs(got[2:]).max() <= 1e-3 + 50 * np.abs(want[2:]).max(), k
             continue
-        np.testing.assert_allclose(got[1], want[1], rtol=rtol, atol=1e-7, err_msg=k + " (l2)")
-        np.testing.assert_allclose(got[2:], want[2:], rtol=rtol, atol=2 * rtol * rms + 1e-8, err_msg=k)
+        t = tol_of(k)
+        np.testing.assert_allclose(got[1], want[1], rtol=t if grads[k].numel() < 1024 else max(rtol, 0.2 * t), atol=1e-7, err_msg=k + " (l2)")
+        np.testing.assert_allclose(got[2:], want[2:], rtol=t, atol=2 * t * rms + 1e-8, err_msg=k)
     for key in [k for k in g if k.startswith("gfull.")]:
         k = key[6:]
         want = g[key]
         rms = float(np.sqrt((want.astype(np.float64) ** 2).mean()))
-        np.testing.assert_allclose(grads[k].numpy().reshape(want.shape), want, rtol=rtol, atol=2 * rtol * rms + 1e-8, err_msg=k + " (full)")
+        t = tol_of(k)
+        np.testing.assert_allclose(grads[k].numpy().reshape(want.shape), want, rtol=t, atol=2 * t * rms + 1e-8, err_msg=k + " (full)")
     want = g["gprobe16k.fc.weight"]
     np.testing.assert_allclose(recipe.probe(grads["fc.weight"], 16384)[2:], want[2:], rtol=rtol, atol=2 * rtol * want[1] / grads["fc.weight"].numel() ** 0.5)
     for key in [k for k in g if k.startswith("after.")]:
         np.testing.assert_allclose(recipe.probe(running[key[6:]].float()), g[key], rtol=1e-3, atol=1e-5, err_msg=key)
+
+
+def alternet50_bf16_storage_emulation(g):
+    """relative l2 error of the training-mode embeddings when the ORACLE keeps every activation and convolution weight in bf16 between
+    fp32-accumulating ops (oracle.resnet_ref.storage_cast; attention blocks: block output rounded) -- what any bf16-storage
+    implementation of the network has by construction, no HIP code involved.  Measured 0.197 on the fixture's input."""
+    import torch.nn.functional as F
+    from oracle import alternet_ref, resnet_ref
+    name = "AlterNet50"
+    spec = alternet_ref.alter_spec(name)
+    seed = int(g["seed"])
+    sd = alternet_ref.fill_special(recipe.fill_state(spec, seed), spec)
+    q = resnet_ref.storage_cast(torch.bfloat16)
+    with torch.no_grad():
+        y = q(F.conv2d(q(recipe.images(seed + 1, int(g["batch"]), 192, 192)), q(sd["conv1.weight"]), None, 2, 1))
+        y = q(F.max_pool2d(F.relu(resnet_ref._bn(sd, "bn1", y, True)), 3, 2, 1))
+        for li, idx, kind, cin, cout, stride, ds, hd, ws, shift, res in alternet_ref.alter_plan(name, 512, 192):
+            p = "layer%d.%d" % (li, idx)
+            y = resnet_ref.basic_block(sd, p, y, stride, ds, True, q=q) if kind == "basic" else q(alternet_ref.attn_block(sd, p, y, hd, ws, shift, True))
+        y = q(F.relu(resnet_ref._bn(sd, "bn2", y, True)))
+        y = F.adaptive_avg_pool2d(y, (6, 6)).reshape(y.shape[0], -1)
+        y = resnet_ref._bn(sd, "bn3", F.linear(y, q(sd["fc.weight"]), sd["fc.bias"]), True)
+    return float(np.linalg.norm(y.numpy() - g["out"]) / np.linalg.norm(g["out"]))
 
 
 def whole_net_train_on_gpu(net, g, h=112, w=112):
