@@ -369,18 +369,26 @@ def main():
     if backend != "nccl":
         local = 0
     torch.cuda.set_device(local)
-    if backend != "nccl" and world > 1:
-        dist.init_process_group(backend)
-    elif world > 1 or args.dist_path:
-        if world == 1:
-            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            os.environ.setdefault("MASTER_PORT", str(free_port()))
-            os.environ.setdefault("RANK", "0")
-            os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-    else:
-        dist.init_process_group("gloo", init_method="file://" + os.path.join(tempfile.mkdtemp(), "pg"),
-                                rank=0, world_size=1)
+    # gloo's C++ side prints a connection banner on STDOUT: keep stdout for the one JSON line (fd 1 points at stderr during the rendezvous)
+    sys.stdout.flush()
+    saved_fd = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        if backend != "nccl" and world > 1:
+            dist.init_process_group(backend)
+        elif world > 1 or args.dist_path:
+            if world == 1:
+                os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+                os.environ.setdefault("MASTER_PORT", str(free_port()))
+                os.environ.setdefault("RANK", "0")
+                os.environ.setdefault("WORLD_SIZE", "1")
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group("gloo", init_method="file://" + os.path.join(tempfile.mkdtemp(), "pg"),
+                                    rank=0, world_size=1)
+    finally:
+        os.dup2(saved_fd, 1)
+        os.close(saved_fd)
 
     import __graft_entry__ as ge
     if rank == 0:

@@ -629,10 +629,7 @@ __device__ __forceinline__ void nt_epilogue_store_lean(const char* mine, int P, 
             if (gbw) {
 #pragma unroll
                 for (int e = 0; e < EPV; ++e) {
-                    const float hh = yv[j].get(e);
-                    float cdf, pdf;
-                    gelu_parts(hh, cdf, pdf);
-                    v.set(e, v.get(e) * (cdf + hh * pdf));
+                    v.set(e, v.get(e) * gelu_slope<T>(yv[j].get(e)));
                 }
             }
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v.v), ro, voff, it * vstep, EPI_NT_STORE ? 2 : 0);
@@ -640,10 +637,7 @@ __device__ __forceinline__ void nt_epilogue_store_lean(const char* mine, int P, 
                 Vec16<T> ga;
 #pragma unroll
                 for (int e = 0; e < EPV; ++e) {
-                    const float hr = v.get(e);
-                    float cdf, pdf;
-                    gelu_parts(hr, cdf, pdf);
-                    ga.set(e, hr * cdf);
+                    ga.set(e, gelu_value<T>(v.get(e)));
                 }
                 const __amdgpu_buffer_rsrc_t ra = make_rsrc(br.act, bytes);
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, ga.v), ra, voff, it * vstep, 0);
@@ -740,10 +734,7 @@ __device__ __forceinline__ void nt_epilogue_store(const char* mine, int P, char*
                     const Vec16<T> hv = ops.y_row(it);
 #pragma unroll
                     for (int e = 0; e < EPV; ++e) {
-                        const float hh = hv.get(e);
-                        float cdf, pdf;
-                        gelu_parts(hh, cdf, pdf);
-                        v.set(e, v.get(e) * (cdf + hh * pdf));
+                        v.set(e, v.get(e) * gelu_slope<T>(hv.get(e)));
                     }
                 }
                 const size_t orow = (size_t)br.map.row(m);
@@ -752,10 +743,7 @@ __device__ __forceinline__ void nt_epilogue_store(const char* mine, int P, char*
                     Vec16<T> ga;
 #pragma unroll
                     for (int e = 0; e < EPV; ++e) {
-                        const float hr = v.get(e);
-                        float cdf, pdf;
-                        gelu_parts(hr, cdf, pdf);
-                        ga.set(e, hr * cdf);
+                        ga.set(e, gelu_value<T>(v.get(e)));
                     }
                     *reinterpret_cast<Vec16<T>*>(ao + orow * Nout + n) = ga;
                 }

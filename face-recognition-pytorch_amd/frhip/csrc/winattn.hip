@@ -282,10 +282,7 @@ __global__ __launch_bounds__(256) void bias_gelu_fwd_kernel(T* __restrict__ y, c
         for (int e = 0; e < EPV; ++e) {
             const float hh = x.get(e) + bias[c0 + e];
             x.set(e, hh);
-            const float hr = x.get(e);                    // GELU of the STORED (rounded) pre-activation
-            float cdf, pdf;
-            gelu_parts(hr, cdf, pdf);
-            g.set(e, hr * cdf);
+            g.set(e, gelu_value<T>(x.get(e)));            // GELU of the STORED (rounded) pre-activation
         }
         *reinterpret_cast<Vec16<T>*>(y + v * EPV) = x;
         if (a) *reinterpret_cast<Vec16<T>*>(a + v * EPV) = g;
@@ -301,10 +298,7 @@ __global__ __launch_bounds__(256) void gelu_bwd_kernel(const T* __restrict__ da,
         Vec16<T> x = *reinterpret_cast<const Vec16<T>*>(h + v * EPV);
 #pragma unroll
         for (int e = 0; e < EPV; ++e) {
-            const float hh = x.get(e);
-            float cdf, pdf;
-            gelu_parts(hh, cdf, pdf);
-            x.set(e, g.get(e) * (cdf + hh * pdf));
+            x.set(e, g.get(e) * gelu_slope<T>(x.get(e)));
         }
         *reinterpret_cast<Vec16<T>*>(dh + v * EPV) = x;
     }

@@ -355,17 +355,25 @@ def colsum_accumulate(x2d, out_accum):
 
 
 _DROP_GEN = None
+_DROP_SEEN = None
+
+
+def seed_dropout(seed):
+    """pin the stream of dropout / stochastic-depth seeds (what torch.cuda.manual_seed is to the reference's nn.Dropout)"""
+    global _DROP_GEN, _DROP_SEEN
+    _DROP_GEN = torch.Generator()
+    _DROP_GEN.manual_seed(int(seed) & ((1 << 63) - 1))
+    _DROP_SEEN = torch.initial_seed()
 
 
 def _drop_generator():
-    """CPU generator of the dropout / stochastic-depth seeds, seeded once from torch.initial_seed().  NOT torch's default CPU generator:
-    that one feeds PartialFC.sample's torch.rand(num_local) (/root/reference/nets/PartialFC.py:110), and the reference's nn.Dropout draws
-    from the DEVICE generator -- a Swin / AlterNet step must leave the CPU stream exactly where the reference leaves it, or the sampled
-    negative rows stop matching it seed for seed."""
-    global _DROP_GEN
-    if _DROP_GEN is None:
-        _DROP_GEN = torch.Generator()
-        _DROP_GEN.manual_seed(torch.initial_seed() & ((1 << 63) - 1))
+    """CPU generator of the dropout / stochastic-depth seeds, (re)seeded from torch.initial_seed() whenever that changes (a new
+    torch.manual_seed(s)) or explicitly by seed_dropout().  NOT torch's default CPU generator: that one feeds PartialFC.sample's
+    torch.rand(num_local) (/root/reference/nets/PartialFC.py:110), and the reference's nn.Dropout draws from the DEVICE generator -- a
+    Swin / AlterNet step must leave the CPU stream exactly where the reference leaves it, or the sampled negative rows stop matching it seed
+    for seed."""
+    if _DROP_GEN is None or _DROP_SEEN != torch.initial_seed():
+        seed_dropout(torch.initial_seed())
     return _DROP_GEN
 
 
