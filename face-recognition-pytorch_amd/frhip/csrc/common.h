@@ -148,13 +148,16 @@ __device__ __forceinline__ void gelu_parts(float h, float& cdf, float& pdf) {
 // instructions (32 issue cycles per element) against 12 + 2 (64) of the A&S 7.1.26 form, which the fp32 validation mode keeps.
 // The Swin MLP epilogues are bound by exactly this arithmetic (a 256 x 256 x 256 tile: 3.4 us of MFMA, 9 us of exact GELU).
 // gelu'(h) is the derivative of the SAME approximation (one shared exponential, no second transcendental).
+#ifndef FRHIP_GELU_EXACT
+#define FRHIP_GELU_EXACT 0            // A/B switch: 1 = the exact erf form in bf16 mode too
+#endif
 constexpr float GELU_C1 = 0.7999131f, GELU_C3 = 0.03497319f, GELU_L2E2 = 2.f * 1.4426950408889634f;
 __device__ __forceinline__ float gelu_fast_sigma(float h, float h2) {
     const float w = h * __builtin_fmaf(h2, GELU_C3 * GELU_L2E2, GELU_C1 * GELU_L2E2);      // 2u log2(e)
     return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-w));
 }
 template <typename T> __device__ __forceinline__ float gelu_value(float h) {
-    if constexpr (sizeof(T) == 2) {
+    if constexpr (sizeof(T) == 2 && !FRHIP_GELU_EXACT) {
         return h * gelu_fast_sigma(h, h * h);
     } else {
         float cdf, pdf;
@@ -163,7 +166,7 @@ template <typename T> __device__ __forceinline__ float gelu_value(float h) {
     }
 }
 template <typename T> __device__ __forceinline__ float gelu_slope(float h) {
-    if constexpr (sizeof(T) == 2) {
+    if constexpr (sizeof(T) == 2 && !FRHIP_GELU_EXACT) {
         const float h2 = h * h, r = gelu_fast_sigma(h, h2);
         const float q = __builtin_fmaf(h2, 6.f * GELU_C3, 2.f * GELU_C1);                   // d(2u)/dh
         return __builtin_fmaf(h * __builtin_fmaf(-r, r, r), q, r);                          // r + h r (1 - r) q
