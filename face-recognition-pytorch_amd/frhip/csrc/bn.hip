@@ -76,14 +76,26 @@ __global__ __launch_bounds__(EW_THREADS) void colreduce_kernel(const T* __restri
     }
 }
 
-// partial[nparts][2][C] -> out[RED_GROUPS][2][C]   (block = 64 columns x 4 partial-lanes, 4 independent loads in flight)
+// partial[nparts][2][C] -> out[gridDim.y][2][C]   (block = 64 columns x 4 partial-lanes).  A lane's rows are ALL requested before the first
+// add (up to RP_MAX independent loads in flight): the kernel is a chain of L2 / HBM round trips, not bandwidth -- with one load in flight per
+// trip the 6 272-row fold of a 56 x 56 layer took 8 - 10 us on the conv -> BatchNorm critical path of every such layer (round 4: 256 groups,
+// <= 16 loads per lane and trip).
+constexpr int RP_MAX = 16;
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ in, float* __restrict__ out, int nparts, int C) {
     __shared__ float red[4][64];
     const int tl = threadIdx.x & 63, pl = threadIdx.x >> 6;
     const int t = blockIdx.x * 64 + tl;                        // over 2*C
     float acc = 0.f;
-    if (t < 2 * C)
-        for (int p = blockIdx.y * 4 + pl; p < nparts; p += gridDim.y * 4) acc += in[(size_t)p * 2 * C + t];
+    if (t < 2 * C) {
+        const int stride = gridDim.y * 4;
+        for (int p0 = blockIdx.y * 4 + pl; p0 < nparts; p0 += stride * RP_MAX) {
+            float v[RP_MAX];
+#pragma unroll
+            for (int u = 0; u < RP_MAX; ++u) { const int p = p0 + u * stride; v[u] = p < nparts ? in[(size_t)p * 2 * C + t] : 0.f; }
+#pragma unroll
+            for (int u = 0; u < RP_MAX; ++u) acc += v[u];      // fixed order: deterministic
+        }
+    }
     red[pl][tl] = acc;
     __syncthreads();
     if (pl == 0 && t < 2 * C) out[(size_t)blockIdx.y * 2 * C + t] = red[0][tl] + red[1][tl] + red[2][tl] + red[3][tl];
@@ -98,7 +110,14 @@ __device__ __forceinline__ void sum_parts(const float* __restrict__ parts, int n
     float a1 = 0.f, a2 = 0.f;
     if (c < C) {
         int p = pl;
-        for (; p + 3 * PL < nparts; p += 4 * PL) {        // four independent row pairs in flight
+        for (; p + 7 * PL < nparts; p += 8 * PL) {        // eight independent row pairs in flight (sixteen loads per round trip)
+            float x[8], y[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const float* r = parts + (size_t)(p + u * PL) * 2 * C; x[u] = r[c]; y[u] = r[C + c]; }
+            a1 += ((x[0] + x[1]) + (x[2] + x[3])) + ((x[4] + x[5]) + (x[6] + x[7]));
+            a2 += ((y[0] + y[1]) + (y[2] + y[3])) + ((y[4] + y[5]) + (y[6] + y[7]));
+        }
+        for (; p + 3 * PL < nparts; p += 4 * PL) {
             const float* r0 = parts + (size_t)p * 2 * C, *r1 = r0 + (size_t)PL * 2 * C, *r2 = r1 + (size_t)PL * 2 * C,
                         *r3 = r2 + (size_t)PL * 2 * C;
             const float x0 = r0[c], y0 = r0[C + c], x1 = r1[c], y1 = r1[C + c], x2 = r2[c], y2 = r2[C + c], x3 = r3[c], y3 = r3[C + c];
@@ -388,8 +407,9 @@ extern "C" int frhip_bn_bwd_reduce(int dtype, const void* dout, const void* y, c
 constexpr int FOLD_LIMIT = 512;
 static const float* fold_partials(const float* partial, int& nparts, int c, float* scratch, hipStream_t stream) {
     if (nparts <= FOLD_LIMIT) return partial;
-    // scratch holds 64 rows of [2][c]: fold to 64 rows (enough blocks to stream thousands of partial rows of a narrow layer)
-    const int groups = nparts > 4 * FOLD_LIMIT ? 64 : RED_GROUPS;
+    // scratch holds 64 rows of [2][c]: always fold to 64 rows -- a lane of the fold kernel then owns <= 7 rows of a 28 x 28 layer (one round
+    // trip of loads) and 25 of a 56 x 56 layer (two)
+    const int groups = 64;
     hipLaunchKernelGGL(reduce_partials_kernel, dim3((2 * c + 63) / 64, groups), dim3(256), 0, stream,
                        partial, scratch, nparts, c);
     nparts = groups;

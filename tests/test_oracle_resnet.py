@@ -203,3 +203,37 @@ def test_train_steps_adamw(golden, tag):
     _adam_close(recipe.probe(W, 4096), g["after.head_weight"], lr, steps, "head weight")
     np.testing.assert_allclose(recipe.probe(opt.m["head"], 4096)[1], g["after.head_exp_avg"][1], rtol=2e-2)
     np.testing.assert_allclose(recipe.probe(opt.v["head"], 4096)[1], g["after.head_exp_avg_sq"][1], rtol=4e-2)
+
+
+@pytest.mark.parametrize("tag", ["rate10", "rate03"])
+def test_train_steps_fresh_batches(golden, tag):
+    """three SGD steps on a NEW synthetic batch each (the repeated batch of test_train_steps is memorised after one step): every step's loss
+    and gradient norm at the first step's tolerance, sampled rows bit-exact, element probes of six backbone tensors and the head after the steps"""
+    g = golden("train_step_resnet18_c256_fresh_" + tag)
+    C, B, steps, rate = int(g["C"]), int(g["B"]), int(g["steps"]), float(g["rate"])
+    blocks = resnet_ref.BLOCKS["ResNet18"]
+    spec = resnet_ref.resnet_spec(blocks)
+    sd = recipe.fill_state(spec, 777)
+    for k, _, kind in spec:
+        if kind in ("bn_w", "bn_rv"):
+            sd[k].fill_(1.0)
+        elif kind in ("bn_b", "bn_rm"):
+            sd[k].zero_()
+    W = recipe.normal(778, (C, 512), 0.01)
+    opt = train_ref.SGDState(float(g["lr"]), float(g["momentum"]), float(g["wd"]))
+    for st in range(steps):
+        img, ids = recipe.images(779 + 10 * st, B), recipe.labels(780 + 10 * st, B, C)
+        u = [T(g["u"][st])] if rate < 1 else None
+        out = train_ref.train_step(sd, W, img, ids, blocks, C, opt, sample_rate=rate, uniforms=u)
+        np.testing.assert_allclose(out["loss"].item(), g["losses"][st], rtol=2e-3)
+        np.testing.assert_allclose(out["grad_norm"].item(), g["grad_norms"][st], rtol=5e-3)
+        if rate < 1:
+            assert np.array_equal(out["index"].numpy(), g["index_step%d" % st])
+    for k in [k[6:] for k in g if k.startswith("probe.") and k != "probe.head_weight"]:
+        want, got = g["probe." + k], recipe.probe(sd[k].float())
+        # three clipped lr-0.1 steps move a parameter by up to its own size; ReLU / max-pool kinks make the steps' gradients differ by a few
+        # per cent of their rms between any two fp32 evaluations (tests/wholenet.py), hence 5 % of the PARAMETER's rms per element
+        np.testing.assert_allclose(got[1], want[1], rtol=2e-3, err_msg=k)
+        np.testing.assert_allclose(got[2:], want[2:], rtol=5e-3, atol=5e-2 * want[1] / sd[k].numel() ** 0.5 + 1e-7, err_msg=k)
+    want, got = g["probe.head_weight"], recipe.probe(W, 4096)
+    np.testing.assert_allclose(got[1:], want[1:], rtol=5e-3, atol=2e-2 * want[1] / W.numel() ** 0.5)

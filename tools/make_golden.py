@@ -209,7 +209,14 @@ def gen_resnet():
 
 
 # ----------------------------------------------------------------------------- training steps
-def gen_train_steps():
+TRAIN_PROBED = ("conv1.weight", "layer2.0.downsample.0.weight", "layer3.1.conv2.weight", "layer4.1.bn2.weight", "fc.weight",
+                "bn3.weight", "bn3.running_var", "bn1.running_mean")
+
+
+def gen_train_steps(fresh=False):
+    """fresh: a new synthetic batch every step (train_step_resnet18_c256_fresh_*): the repeated 16-image batch of the original fixtures is
+    memorised after one lr-0.1 step (loss 15 -> 1e-5), so their steps 1-2 pin little; with fresh batches every step's loss is O(10) and is
+    held to the same tolerance as step 0.  Also stored there: element probes (not 10-number summaries) of six backbone tensors and the head."""
     _, P, R = _ref()
     import torch.nn.functional as F
     for tag, rate in {"rate10": 1.0, "rate03": 0.3}.items():
@@ -239,6 +246,8 @@ def gen_train_steps():
             arrs = dict(C=C, B=B, steps=steps, rate=rate, lr=0.1, momentum=0.9, wd=5e-4)
             losses, gnorms, us = [], [], []
             for st in range(steps):
+                if fresh:
+                    img, ids = recipe.images(779 + 10 * st, B), recipe.labels(780 + 10 * st, B, C)
                 opt.zero_grad()
                 enc.train()
                 feat = F.normalize(enc(img))
@@ -259,7 +268,11 @@ def gen_train_steps():
                 arrs["after." + k] = recipe.summary(v.float())
             wfin = pfc.weight if rate < 1 else pfc.weight_activated.data
             arrs["after.head_weight"] = recipe.summary(wfin)
-            save("train_step_resnet18_c256_" + tag, **arrs)
+            if fresh:
+                for k in TRAIN_PROBED:
+                    arrs["probe." + k] = recipe.probe(enc.state_dict()[k].float())
+                arrs["probe.head_weight"] = recipe.probe(wfin, 4096)
+            save("train_step_resnet18_c256_" + ("fresh_" if fresh else "") + tag, **arrs)
             dist.destroy_process_group()
 
 
@@ -388,10 +401,6 @@ def gen_head_adamw(ws, rate=0.3, C=503, B=6, D=128, steps=3):
             for k, v in np.load(os.path.join(td, "rank%d.npz" % r)).items():
                 arrs["r%d_%s" % (r, k)] = v
         save("head_adamw_ws%d_rate%s" % (ws, str(rate).replace(".", "")), **arrs)
-
-
-TRAIN_PROBED = ("conv1.weight", "layer2.0.downsample.0.weight", "layer3.1.conv2.weight", "layer4.1.bn2.weight", "fc.weight",
-                "bn3.weight", "bn3.running_var", "bn1.running_mean")
 
 
 def gen_train_steps_adamw():
@@ -701,6 +710,7 @@ GENS = {
     "head_adamw_ws1": lambda: gen_head_adamw(1),
     "head_adamw_ws2": lambda: gen_head_adamw(2),
     "train_adamw": gen_train_steps_adamw,
+    "train_fresh": lambda: gen_train_steps(fresh=True),
 }
 
 if __name__ == "__main__":
