@@ -91,16 +91,17 @@ def clip_coef(grads, max_norm=5.0):
 
 
 def train_step(sd, head_w, img, ids, blocks, num_classes, opt, s=30.0, m=0.35,
-               emd_size=512, sample_rate=1.0, uniforms=None, head_state=None):
+               emd_size=512, sample_rate=1.0, uniforms=None, head_state=None, forward=None, names=None):
     """One step at world_size 1.  Mutates sd (params + BN stats), head_w and opt in place.
     With sample_rate < 1 the activated rows carry their own momentum rows
     (nets/PartialFC.py:120-129, :142-143), kept in opt.buf['head'] as a full [num_local,D] table.
     Returns dict(loss, feat, grad_norm)."""
-    names = resnet_ref.trainable_names(sd)
+    # forward(work, img) -> embeddings and names = trainable keys: another backbone's functional forward (oracle.swin_ref / alternet_ref)
+    names = resnet_ref.trainable_names(sd) if names is None else list(names)
     leaves = {k: sd[k].detach().clone().requires_grad_(True) for k in names}
     work = dict(sd)
     work.update(leaves)
-    raw = resnet_ref.resnet_forward(work, img, blocks, True, emd_size)
+    raw = resnet_ref.resnet_forward(work, img, blocks, True, emd_size) if forward is None else forward(work, img)
     for k in sd:   # running stats / counters were updated on `work`
         if k not in leaves:
             sd[k] = work[k]

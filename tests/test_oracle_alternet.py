@@ -57,3 +57,32 @@ def test_alternet50_whole_net_training_mode(golden):
     y.backward(recipe.normal(int(g["seed"]) + 2, tuple(y.shape), 0.05))
     assert {"gprobe." + k for k in names} == {k for k in g if k.startswith("gprobe.")}
     check_whole_net_train(g, {k: sd[k].grad for k in names}, y.detach().numpy(), {k: v.detach() for k, v in sd.items()}, noise=("fc.bias",))
+
+
+def test_shipped_recipe_two_steps(golden):
+    """/root/reference/main/train.sh:12 end to end (AlterNet50 @192 + PartialFCAdamW rate 0.3 + AdamW lr 5e-4 + clip 5), two steps on fresh batches"""
+    from oracle import train_ref
+    g = golden("recipe_alternet50_adamw_rate03")
+    C, B, steps, rate, lr = int(g["C"]), int(g["B"]), int(g["steps"]), float(g["rate"]), float(g["lr"])
+    spec = alternet_ref.alter_spec("AlterNet50")
+    sd = alternet_ref.fill_special(recipe.fill_state(spec, int(g["seed"])), spec)
+    names = [k for k, _, kind in spec if kind in ("conv", "linear_w", "linear_b", "bn_w", "bn_b", "logit_scale")]
+    W = recipe.normal(9101, (C, 512), 0.01)
+    opt = train_ref.AdamWState(lr, tuple(g["betas"]), float(g["eps"]), float(g["wd"]))
+    fwd = lambda work, img: alternet_ref.alter_forward(work, img, "AlterNet50", True)      # noqa: E731
+    for st in range(steps):
+        img, ids = recipe.images(9110 + 10 * st, B, 192, 192), recipe.labels(9111 + 10 * st, B, C)
+        torch.manual_seed(9200 + st)
+        u = [torch.rand(C)]
+        out = train_ref.train_step(sd, W, img, ids, None, C, opt, sample_rate=rate, uniforms=u, forward=fwd, names=names)
+        np.testing.assert_allclose(out["loss"].item(), g["losses"][st], rtol=1e-3 if st == 0 else 1e-2)
+        np.testing.assert_allclose(out["grad_norm"].item(), g["grad_norms"][st], rtol=5e-3 if st == 0 else 5e-2)
+        assert np.array_equal(out["index"].numpy(), g["index_step%d" % st])
+        if st == 0:
+            for k in [k[6:] for k in g if k.startswith("grad0.")]:
+                want = g["grad0." + k]
+                np.testing.assert_allclose(recipe.probe(out["grads"][k])[1:], want[1:], rtol=1e-2, atol=5e-2 * want[1] / out["grads"][k].numel() ** 0.5, err_msg=k)
+    for k in [k[6:] for k in g if k.startswith("after.") and not k.startswith("after.head")]:
+        got, want = recipe.probe(sd[k].float()), g["after." + k]
+        np.testing.assert_allclose(got[1], want[1], rtol=2e-3, err_msg=k)
+        assert np.abs(got[2:] - want[2:]).max() <= 2.2 * lr * steps, k

@@ -199,6 +199,55 @@ def test_three_adamw_steps_match_reference(golden, pg, tag):
     np.testing.assert_allclose(recipe.probe(v.cpu(), 4096)[1], g["after.head_exp_avg_sq"][1], rtol=4e-2)
 
 
+def test_shipped_recipe_alternet50_adamw_rate03_matches_reference(golden, pg):
+    """The reference's one shipped command line -- /root/reference/main/train.sh:12: `--mode train --sample_rate 0.3 --optimizer AdamW --network
+    AlterNet50 --lr 5e-4` -- through the product end to end: `Model` builds nets.AlterNet_SwinV2_FAN.Encoder @192, PartialFCAdamW and
+    frhip.optim.AdamW (configure_optimizers' AdamW branch) and runs two training steps on fresh batches of 8, fp32 validation mode, against the real
+    reference (fixture recipe_alternet50_adamw_rate03; tail Dropout p = 0 and stochastic depth off on both sides: RNG-free)."""
+    from model.FR_PartialFC import Model
+    from oracle import alternet_ref
+    g = golden("recipe_alternet50_adamw_rate03")
+    rate, C, B, lr, steps = float(g["rate"]), int(g["C"]), int(g["B"]), float(g["lr"]), int(g["steps"])
+    torch.cuda.set_device(0)
+    conf = _conf(rate, "fp32")
+    conf.network, conf.img_size = "AlterNet50", 192
+    conf.optimizer, conf.lr, conf.wd, conf.eps, conf.betas = "AdamW", lr, float(g["wd"]), float(g["eps"]), tuple(float(b) for b in g["betas"])
+    model = Model(conf, None, "train")
+    assert type(model.loss).__name__ == "PartialFCAdamW" and type(model.encoder).__name__ == "AlterNet"
+    spec = alternet_ref.alter_spec("AlterNet50")
+    model.encoder.load_state_dict(alternet_ref.fill_special(recipe.fill_state(spec, int(g["seed"])), spec), strict=True)
+    model.encoder.dropout.p = 0.0
+    for m in model.encoder.modules():
+        if hasattr(m, "drop_path_rate"):
+            m.drop_path_rate = 0.0
+    with torch.no_grad():
+        model.loss.weight.copy_(recipe.normal(9101, (C, 512), 0.01).cuda())
+    params = dict(model.encoder.named_parameters())
+    for st in range(steps):
+        img, ids = recipe.images(9110 + 10 * st, B, 192, 192), recipe.labels(9111 + 10 * st, B, C)
+        torch.manual_seed(9200 + st)
+        out = model.training_step((img, ids.clone()))
+        np.testing.assert_allclose(float(out["loss"]), g["losses"][st], rtol=1e-3 if st == 0 else 1e-2)
+        np.testing.assert_allclose(float(model.opt.last_grad_norm()), g["grad_norms"][st], rtol=5e-3 if st == 0 else 5e-2)
+        assert np.array_equal(model.loss.weight_index.cpu().numpy(), g["index_step%d" % st])       # bit-exact
+        if st == 0:
+            coef = min(1.0, 5.0 / (float(g["grad_norms"][0]) + 1e-6))
+            for k in [k[6:] for k in g if k.startswith("grad0.")]:
+                want = g["grad0." + k]
+                got = recipe.probe(params[k].grad.float().cpu() * coef)
+                np.testing.assert_allclose(got[1], want[1], rtol=5e-3, err_msg=k)
+                np.testing.assert_allclose(got[2:], want[2:], rtol=1e-2, atol=5e-2 * want[1] / params[k].numel() ** 0.5, err_msg=k)   # ReLU kinks: tests/wholenet.py
+    esd = model.encoder.state_dict()
+    for k in [k[6:] for k in g if k.startswith("after.") and not k.startswith("after.head")]:
+        got, want = recipe.probe(esd[k].float().cpu()), g["after." + k]
+        np.testing.assert_allclose(got[1], want[1], rtol=2e-3, err_msg=k)
+        assert np.abs(got[2:] - want[2:]).max() <= 2.2 * lr * steps, k
+    model.loss.update()
+    _adam_close(recipe.probe(model.loss.weight.cpu(), 4096), g["after.head_weight"], lr, steps, "head weight")
+    np.testing.assert_allclose(recipe.probe(model.loss.weight_exp_avg.cpu(), 4096)[1], g["after.head_exp_avg"][1], rtol=2e-2)
+    np.testing.assert_allclose(recipe.probe(model.loss.weight_exp_avg_sq.cpu(), 4096)[1], g["after.head_exp_avg_sq"][1], rtol=4e-2)
+
+
 def test_dropout_backbone_leaves_the_cpu_generator_to_the_head(pg):
     """Swin18 (tail Dropout(0.5), active) + PartialFC at rate 0.3: the sampled rows of every step must be the ones the reference's formulation
     gives from the CPU seed ALONE (torch.rand(num_local) is the only CPU draw of a reference step, nets/PartialFC.py:110; its nn.Dropout

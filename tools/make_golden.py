@@ -689,6 +689,66 @@ def gen_scheduler():
     save("scheduler_lrs", **out)
 
 
+# ----------------------------------------------------------------------------- the shipped recipe end to end (main/train.sh:12)
+def gen_recipe_alternet50():
+    """main/train.sh:12 -- `--sample_rate 0.3 --optimizer AdamW --network AlterNet50 --lr 5e-4` -- composed as model/FR_PartialFC.py:162-193 does:
+    AlterNet50 @192 encoder, F.normalize, PartialFCAdamW(rate 0.3), AdamW over [encoder, head], clip_grad_norm_(encoder, 5); two steps on fresh
+    batches of 8.  RNG-free: tail Dropout p = 0, DropPath = identity (the timm stub)."""
+    from oracle import alternet_ref
+    _, P, _ = _ref()
+    _swin_ref()
+    sys.modules.setdefault("einops", types.ModuleType("einops"))
+    if not hasattr(sys.modules["einops"], "rearrange"):
+        sys.modules["einops"].rearrange = lambda *a, **k: (_ for _ in ()).throw(RuntimeError("unused"))
+        sys.modules["einops"].repeat = sys.modules["einops"].rearrange
+    import torch.nn.functional as F
+    import nets.AlterNet_SwinV2_FAN as A
+    with tempfile.TemporaryDirectory() as td:
+        _init_pg(0, 1, os.path.join(td, "pg"))
+        C, B, steps, rate = 256, 8, 2, 0.3
+        conf = types.SimpleNamespace(network="AlterNet50", emd_size=512, img_size=192, sample_rate=rate, mixed_precision=False, loss_s=30.0, loss_m=0.35)
+        enc = A.AlterNet50(conf)
+        spec = alternet_ref.alter_spec("AlterNet50")
+        enc.load_state_dict(alternet_ref.fill_special(recipe.fill_state(spec, 9100), spec), strict=True)
+        enc.dropout.p = 0.0
+        pfc = P.PartialFCAdamW(conf, C)
+        with torch.no_grad():
+            pfc.weight.copy_(recipe.normal(9101, (C, 512), 0.01))
+        opt = torch.optim.AdamW([{"params": enc.parameters()}, {"params": pfc.parameters()}], lr=ADAMW["lr"], weight_decay=ADAMW["wd"],
+                                eps=ADAMW["eps"], betas=ADAMW["betas"])
+        arrs = dict(C=C, B=B, steps=steps, rate=rate, lr=ADAMW["lr"], wd=ADAMW["wd"], eps=ADAMW["eps"], betas=np.asarray(ADAMW["betas"]), seed=9100)
+        losses, gnorms = [], []
+        names = ("conv1.weight", "layer1.0.conv1.weight", "layer2.2.attn.qkv.weight", "layer2.3.attn.cpb_mlp.2.weight", "layer3.5.conv2.weight",
+                 "layer4.3.attn.proj.weight", "bn2.weight", "fc.weight", "bn3.weight")
+        for st in range(steps):
+            img, ids = recipe.images(9110 + 10 * st, B, 192, 192), recipe.labels(9111 + 10 * st, B, C)
+            opt.zero_grad()
+            enc.train()
+            feat = F.normalize(enc(img))
+            torch.manual_seed(9200 + st)
+            loss = pfc(feat, ids.clone(), opt)
+            loss.backward()
+            gn = torch.nn.utils.clip_grad_norm_(enc.parameters(), 5)
+            if st == 0:
+                for k, p_ in enc.named_parameters():
+                    if k in names:
+                        arrs["grad0." + k] = recipe.probe(p_.grad)
+            _tensor_step(opt)
+            opt.step()
+            losses.append(loss.detach().clone())
+            gnorms.append(gn.detach().clone())
+            arrs["index_step%d" % st] = pfc.weight_index.clone()
+        pfc.update()
+        arrs.update(losses=torch.stack(losses), grad_norms=torch.stack(gnorms))
+        esd = enc.state_dict()
+        for k in names:
+            arrs["after." + k] = recipe.probe(esd[k].float())
+        arrs.update({"after.head_weight": recipe.probe(pfc.weight, 4096), "after.head_exp_avg": recipe.probe(pfc.weight_exp_avg, 4096),
+                     "after.head_exp_avg_sq": recipe.probe(pfc.weight_exp_avg_sq, 4096)})
+        save("recipe_alternet50_adamw_rate03", **arrs)
+        dist.destroy_process_group()
+
+
 GENS = {
     "scheduler": gen_scheduler,
     "swin": gen_swin,
@@ -711,6 +771,7 @@ GENS = {
     "head_adamw_ws2": lambda: gen_head_adamw(2),
     "train_adamw": gen_train_steps_adamw,
     "train_fresh": lambda: gen_train_steps(fresh=True),
+    "recipe_alternet50": gen_recipe_alternet50,
 }
 
 if __name__ == "__main__":
