@@ -15,6 +15,8 @@ DropPath(0.1) (:371) is stochastic depth per sample: identity in eval; in traini
 applied to the normalised branch.  One autograd node for the whole net; no CPU fallback.
 """
 import numpy as np
+import os
+
 import torch
 import torch.nn as nn
 
@@ -126,14 +128,18 @@ def attn_block_forward(blk, x, dt, training, save, wprep=None, q8=None, keep=Non
     return out, s
 
 
-def attn_block_backward(blk, s, dout, dt, bc):
+def attn_block_backward(blk, s, dout, dt, bc, part2=None, next_bn=None):
+    """part2: the BatchNorm-backward partial sums of (dout, s.po) when the kernel that produced dout already reduced them (only without
+    stochastic depth: the per-sample factor is not known to that kernel).  next_bn=(y, st[, relu]): the BatchNorm that consumes the returned
+    dx; its reduction then rides in the epilogue of the qkv data-gradient and (dx, partial) is returned (as nets.SwinV2.swin_block_backward)."""
     G = bc.G
     b, h, w, c = s.shape
     m = b * h * w
     at = blk.attn
     d2 = dout.reshape(m, c)
+    assert part2 is None or s.keep is None
     dpo = ops.bn_backward(d2, s.po, s.st2, blk.norm2.weight.data, G(blk.norm2.weight), G(blk.norm2.bias),
-                          rowscale=s.keep, rows_per=h * w)
+                          rowscale=s.keep, rows_per=h * w, part=part2)
     # proj.bias only shifts the input of a training-mode BatchNorm: analytically zero gradient (nets/SwinV2.py), left at zero
     bc.on_side(lambda: ops.gemm_tn(dpo, s.ao, G(at.proj.weight)), dpo, s.ao)
     dao = ops.gemm_nt(dpo, _S._transposed(s.wproj, s.wproj_t))
@@ -147,9 +153,16 @@ def attn_block_backward(blk, s, dout, dt, bc):
         G(at.q_bias).add_(gsum[:c])
         G(at.v_bias).add_(gsum[2 * c:])
     bc.on_side(lambda: ops.gemm_tn(dqkv, s.x2, G(at.qkv.weight)), dqkv, s.x2)
-    dx = _S._dgrad_add(dqkv, s.wqkv, d2, s.wqkv_t)
+    part = None
+    if next_bn is not None:
+        dx, part = _S._dgrad_add(dqkv, s.wqkv, d2, s.wqkv_t, bnred=(next_bn[0], next_bn[1], len(next_bn) > 2 and bool(next_bn[2])))
+    else:
+        dx = _S._dgrad_add(dqkv, s.wqkv, d2, s.wqkv_t)
     _S.position_bias_backward(blk, s, bc)
-    return dx.view(b, h, w, c)
+    return dx.view(b, h, w, c) if next_bn is None else (dx.view(b, h, w, c), part)
+
+
+_FUSE_BNRED = os.environ.get("FRHIP_ALT_FUSE_BNRED", "1") == "1"      # 0: conv -> conv transitions only (the round-3 behaviour; A/B switch)
 
 
 class AlterNet(nn.Module):
@@ -258,13 +271,21 @@ class AlterNet(nn.Module):
         part = None
         for i in range(len(layers) - 1, -1, -1):
             mod, s = layers[i], sv.layers[i]
+            # the gradient leaving layer i enters the last BatchNorm of layer i-1 (bn2 of a conv block, norm2 of an attention block): that
+            # BatchNorm's backward sums ride in layer i's last data-gradient -- unless layer i-1 is an attention block under stochastic
+            # depth, whose reduction carries a per-sample factor (frhip_bn_bwd_reduce_rs) the producing kernel does not know
+            nxt = None
+            if i > 0 and _FUSE_BNRED:
+                ps = sv.layers[i - 1]
+                if isinstance(layers[i - 1], BasicBlock):
+                    nxt = (ps.y2, ps.st2)
+                elif ps.keep is None:
+                    nxt = (ps.po.view(ps.shape), ps.st2, False)
             if isinstance(mod, BasicBlock):
-                prev_is_block = i > 0 and isinstance(layers[i - 1], BasicBlock)
-                nxt = (sv.layers[i - 1].y2, sv.layers[i - 1].st2) if prev_is_block else None
                 res = basic_block_backward(mod, s, dout, dt, bc, part2=part, next_bn=nxt)
-                dout, part = res if nxt is not None else (res, None)
             else:
-                dout, part = attn_block_backward(mod, s, dout, dt, bc), None
+                res = attn_block_backward(mod, s, dout, dt, bc, part2=part, next_bn=nxt)
+            dout, part = res if nxt is not None else (res, None)
             if len(layers) - 1 - i == DEFER_EARLY_BLOCKS:
                 bc.run_deferred()                          # the head's early parameter update: beside the blocks, not beside the tail
         stem_backward(self, sv, dout, bc)
