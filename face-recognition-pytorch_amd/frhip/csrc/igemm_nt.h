@@ -76,6 +76,13 @@ struct EpiBnRed {
     const float* aff_scale;
     const float* aff_shift;
     int aff_relu;
+    // stochastic depth around the BatchNorm whose backward sums ride here (nets/AlterNet_SwinV2_FAN.py: x + drop_path(norm(f(x)))): the
+    // gradient that enters the BatchNorm is dx * rowkeep[row / rows_per] (0 for a dropped sample, keep_scale = 1 / keep-probability for
+    // a kept one).  The sums are taken over the kept samples' rows and multiplied by keep_scale -- what frhip_bn_bwd_reduce_rs computes in a
+    // pass of its own.  dx itself is stored unscaled.  rowkeep == NULL: no stochastic depth.
+    const float* rowkeep;
+    int rows_per;
+    float keep_scale;
 };
 
 // WM x WN waves; each wave owns (MT*16) pixel rows x 64 channels (4 MFMA tiles wide).
@@ -487,9 +494,12 @@ __device__ __forceinline__ void nt_epilogue_store_fast(const char* mine, int P, 
         // matrix pipe: the masked gradient tile stays in the wave's staging area, the saved BatchNorm input rows (already in
         // registers) go to a second one, and  sum d (y - mean) invstd = invstd * (sum d y - mean * sum d)  per channel from
         // ones x D and the diagonal of D^T Y.  What is left on the VALU is the mask (5 instructions per element; none without ReLU).
-        const bool masked = br.mscale != nullptr;
+        const bool masked = br.mscale != nullptr, rs = br.rowkeep != nullptr;
         const int n = ops.n;
         char* ydst = const_cast<char*>(src) + yoff;
+        // stochastic depth: sample of this lane's first row and the row's position inside it (rows advance by RPI per iteration)
+        int rs_sample = 0, rs_pos = 0;
+        if (rs) { const int mrow = ops.m0 + ops.rsub; rs_sample = mrow / br.rows_per; rs_pos = mrow - rs_sample * br.rows_per; }
         float ms[EPV], mb[EPV];
 #pragma unroll
         for (int e = 0; e < EPV; ++e) { ms[e] = masked ? br.mscale[n + e] : 0.f; mb[e] = masked ? br.mshift[n + e] : 1.f; }
@@ -502,6 +512,12 @@ __device__ __forceinline__ void nt_epilogue_store_fast(const char* mine, int P, 
             }
             put(it, v);
             const Vec16<T> yy = ops.yv[it];
+            uint32_t keep_bits = 0xffffffffu;               // all ones: the row's sample was kept (or no stochastic depth)
+            if (rs) {
+                while (rs_pos >= br.rows_per) { rs_pos -= br.rows_per; ++rs_sample; }
+                keep_bits = br.rowkeep[rs_sample] != 0.f ? 0xffffffffu : 0u;
+                rs_pos += RPI;
+            }
             if (masked) {
                 u32x4_t vb = __builtin_bit_cast(u32x4_t, v.v);
                 const u32x4_t yb = __builtin_bit_cast(u32x4_t, yy.v);
@@ -510,8 +526,13 @@ __device__ __forceinline__ void nt_epilogue_store_fast(const char* mine, int P, 
                     const float ylo = __uint_as_float(yb[w] << 16), yhi = __uint_as_float(yb[w] & 0xffff0000u);
                     const uint32_t klo = (ylo * ms[2 * w] + mb[2 * w] > 0.f) ? 0x0000ffffu : 0u;
                     const uint32_t khi = (yhi * ms[2 * w + 1] + mb[2 * w + 1] > 0.f) ? 0xffff0000u : 0u;
-                    vb[w] &= (klo | khi);
+                    vb[w] &= (klo | khi) & keep_bits;
                 }
+                *reinterpret_cast<u32x4_t*>(const_cast<char*>(src) + it * RPI * P) = vb;
+            } else if (rs) {
+                u32x4_t vb = __builtin_bit_cast(u32x4_t, v.v);
+#pragma unroll
+                for (int w = 0; w < 4; ++w) vb[w] &= keep_bits;
                 *reinterpret_cast<u32x4_t*>(const_cast<char*>(src) + it * RPI * P) = vb;
             } else if (has_res) {
                 *reinterpret_cast<Vec16<T>*>(const_cast<char*>(src) + it * RPI * P) = v;
@@ -527,6 +548,7 @@ __device__ __forceinline__ void nt_epilogue_store_fast(const char* mine, int P, 
             const int c = n0 + 16 * cb + j;
             a1[cb] = S[cb][0];
             a2[cb] = br.invstd[c] * (epi_diag(G[cb], lane) - br.mean[c] * a1[cb]);
+            if (rs) { a1[cb] *= br.keep_scale; a2[cb] *= br.keep_scale; }
         }
         if (acc) {
 #pragma unroll
@@ -702,10 +724,12 @@ __device__ __forceinline__ void nt_epilogue_store(const char* mine, int P, char*
                 }
                 epi_store_row(o + (size_t)br.map.row(m) * Nout + n, v);
                 const Vec16<T> yr = ops.y_row(it);
+                // stochastic depth: rows of a dropped sample contribute nothing, the kept ones keep_scale times their gradient
+                const float kf = br.rowkeep ? (br.rowkeep[m / br.rows_per] != 0.f ? br.keep_scale : 0.f) : 1.f;
 #pragma unroll
                 for (int e = 0; e < EPV; ++e) {
                     const float yy = yr.get(e);
-                    const float d = (yy * ms[e] + mb[e] > 0.f) ? v.get(e) : 0.f;      // the value as stored (rounded to T)
+                    const float d = (yy * ms[e] + mb[e] > 0.f) ? v.get(e) * kf : 0.f;      // the value as stored (rounded to T)
                     s1[e] += d; s2[e] += d * (yy - mu[e]) * is[e];
                 }
             }

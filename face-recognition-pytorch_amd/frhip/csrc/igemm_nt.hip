@@ -361,6 +361,24 @@ extern "C" int frhip_conv_dgrad_fused(int dtype, const void* dy, const void* wt,
                      "frhip_conv_dgrad_fused");
 }
 
+extern "C" int frhip_conv_dgrad_fused_rs(int dtype, const void* dy, const void* wt, void* dx, const void* residual,
+                                         int residual_stride, const void* y_bn, const float* mean, const float* invstd,
+                                         const float* mask_scale, const float* mask_shift, const float* rowscale, int rows_per,
+                                         float keep_scale, float* stats_partial, int n, int h, int wd, int c, int k, int r, int s,
+                                         int stride, int pad, hipStream_t stream) {
+    // frhip_conv_dgrad_fused whose BatchNorm sits under stochastic depth: the sums describe dx * rowscale[row / rows_per]
+    if (residual_stride != 1 && residual_stride != 2) { set_error("frhip_conv_dgrad_fused_rs: residual_stride must be 1 or 2"); return FRHIP_EINVAL; }
+    if (!y_bn || !mean || !invstd || !stats_partial || (mask_scale && !mask_shift) || !rowscale || rows_per <= 0 ||
+        (long long)n * h * wd % rows_per != 0) {
+        set_error("frhip_conv_dgrad_fused_rs: y_bn, mean, invstd, stats_partial, rowscale and a rows_per that divides the rows are required");
+        return FRHIP_EINVAL;
+    }
+    EpiBnRed br = {y_bn, mean, invstd, mask_scale, mask_shift, 0, 0, {0, 0, 0, 0, 0, 0}, nullptr, nullptr, 0};
+    br.rowkeep = rowscale; br.rows_per = rows_per; br.keep_scale = keep_scale;
+    if (residual && residual_stride == 2) { br.res_h = h; br.res_w = wd; }
+    return dgrad_run(dtype, dy, wt, dx, residual, stats_partial, br, n, h, wd, c, k, r, s, stride, pad, stream, "frhip_conv_dgrad_fused_rs");
+}
+
 extern "C" int frhip_conv_dgrad_bnred(int dtype, const void* dy, const void* wt, void* dx, const void* residual,
                                       const void* y_bn, const float* mean, const float* invstd, const float* mask_scale,
                                       const float* mask_shift, float* stats_partial, int n, int h, int wd, int c, int k,

@@ -74,8 +74,9 @@ def conv_dgrad(dy, wt, x_shape, r, s, stride, pad, residual=None, out=None, bnre
 
     residual_stride=2: `residual` is the compact [N,(H+1)/2,(W+1)/2,C] gradient of a stride-2 1x1 shortcut, added on the
     even pixels only.
-    bnred=(y_bn, st, relu_mask): dx is the upstream gradient of a BatchNorm with saved input y_bn and batch state st;
-    the BN-backward partial sums come out of the epilogue and (dx, partial) is returned -- pass partial to bn_backward."""
+    bnred=(y_bn, st, relu_mask[, rowscale, rows_per, keep_scale]): dx is the upstream gradient of a BatchNorm with saved input y_bn and
+    batch state st; the BN-backward partial sums come out of the epilogue and (dx, partial) is returned -- pass partial to bn_backward.
+    With rowscale (fp32 per sample: 0 or keep_scale) the BatchNorm sits under stochastic depth and the sums describe dx * rowscale[sample]."""
     n, h, wd, c = x_shape
     k = dy.shape[3]
     dx = out if out is not None else torch.empty(x_shape, dtype=dy.dtype, device=dy.device)
@@ -89,12 +90,22 @@ def conv_dgrad(dy, wt, x_shape, r, s, stride, pad, residual=None, out=None, bnre
         return dx
     part = y_bn = st = None
     relu_mask = False
+    rowscale = None
     if bnred is not None:
-        y_bn, st, relu_mask = bnred
+        y_bn, st, relu_mask = bnred[:3]
+        if len(bnred) > 3 and bnred[3] is not None:
+            rowscale, rows_per, keep_scale = bnred[3], int(bnred[4]), float(bnred[5])
+            assert rowscale.dtype == torch.float32 and rowscale.is_contiguous() and rowscale.numel() * rows_per == n * h * wd
         if tuple(y_bn.shape) != tuple(x_shape) or y_bn.dtype != dy.dtype:
             raise ValueError("conv_dgrad(bnred): y_bn must have the shape and dtype of dx")
         rows = lib().frhip_dgrad_stat_rows(dt_of(dy), n, h, wd, c, k, r, s, stride, pad)
         part = torch.empty((rows, 2, c), dtype=torch.float32, device=dy.device)
+    if rowscale is not None:
+        check(lib().frhip_conv_dgrad_fused_rs(dt_of(dy), _p(dy), _p(wt), _p(dx), _p(residual), residual_stride, _p(y_bn), _p(st.mean),
+                                              _p(st.invstd), _p(st.scale) if relu_mask else None, _p(st.shift) if relu_mask else None,
+                                              _p(rowscale), rows_per, keep_scale, _p(part), n, h, wd, c, k, r, s, stride, pad, _s()),
+              "frhip_conv_dgrad_fused_rs")
+        return dx, part
     check(lib().frhip_conv_dgrad_fused(dt_of(dy), _p(dy), _p(wt), _p(dx), _p(residual), residual_stride, _p(y_bn),
                                        _p(st.mean) if st else None, _p(st.invstd) if st else None,
                                        _p(st.scale) if relu_mask else None, _p(st.shift) if relu_mask else None, _p(part),
@@ -313,11 +324,13 @@ def bn_backward(dout, y, st, gamma, dgamma, dbeta, relu_mask=False, out=None, sc
     rows = y.numel() // c
     dev = y.device
     if rowscale is not None:
-        assert not relu_mask and part is None and rowscale.dtype == torch.float32 and rows == rowscale.numel() * rows_per
-        nb = _colreduce_blocks(rows, c, dt_of(y))
-        part = torch.empty((nb, 2, c), dtype=torch.float32, device=dev)
-        check(lib().frhip_bn_bwd_reduce_rs(dt_of(y), _p(dout), _p(y), _p(st.mean), _p(st.invstd), _p(rowscale), rows_per, rows, c,
-                                           _p(part), _s()), "frhip_bn_bwd_reduce_rs")
+        assert not relu_mask and rowscale.dtype == torch.float32 and rows == rowscale.numel() * rows_per
+        if part is None:           # else: the kernel that produced dout already took the sums (conv_dgrad(bnred=(..., rowscale, ...)))
+            nb = _colreduce_blocks(rows, c, dt_of(y))
+            part = torch.empty((nb, 2, c), dtype=torch.float32, device=dev)
+            check(lib().frhip_bn_bwd_reduce_rs(dt_of(y), _p(dout), _p(y), _p(st.mean), _p(st.invstd), _p(rowscale), rows_per, rows, c,
+                                               _p(part), _s()), "frhip_bn_bwd_reduce_rs")
+        nb = part.shape[0]
         coef = torch.empty((3, c), dtype=torch.float32, device=dev)
         if scratch is None:
             scratch = torch.empty((64 * 2 * c,), dtype=torch.float32, device=dev)

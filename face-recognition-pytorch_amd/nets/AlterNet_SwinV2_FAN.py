@@ -129,15 +129,14 @@ def attn_block_forward(blk, x, dt, training, save, wprep=None, q8=None, keep=Non
 
 
 def attn_block_backward(blk, s, dout, dt, bc, part2=None, next_bn=None):
-    """part2: the BatchNorm-backward partial sums of (dout, s.po) when the kernel that produced dout already reduced them (only without
-    stochastic depth: the per-sample factor is not known to that kernel).  next_bn=(y, st[, relu]): the BatchNorm that consumes the returned
+    """part2: the BatchNorm-backward partial sums of (dout, s.po) when the kernel that produced dout already reduced them (under stochastic
+    depth: with the per-sample factor, frhip_conv_dgrad_fused_rs).  next_bn=(y, st[, relu]): the BatchNorm that consumes the returned
     dx; its reduction then rides in the epilogue of the qkv data-gradient and (dx, partial) is returned (as nets.SwinV2.swin_block_backward)."""
     G = bc.G
     b, h, w, c = s.shape
     m = b * h * w
     at = blk.attn
     d2 = dout.reshape(m, c)
-    assert part2 is None or s.keep is None
     dpo = ops.bn_backward(d2, s.po, s.st2, blk.norm2.weight.data, G(blk.norm2.weight), G(blk.norm2.bias),
                           rowscale=s.keep, rows_per=h * w, part=part2)
     # proj.bias only shifts the input of a training-mode BatchNorm: analytically zero gradient (nets/SwinV2.py), left at zero
@@ -155,7 +154,8 @@ def attn_block_backward(blk, s, dout, dt, bc, part2=None, next_bn=None):
     bc.on_side(lambda: ops.gemm_tn(dqkv, s.x2, G(at.qkv.weight)), dqkv, s.x2)
     part = None
     if next_bn is not None:
-        dx, part = _S._dgrad_add(dqkv, s.wqkv, d2, s.wqkv_t, bnred=(next_bn[0], next_bn[1], len(next_bn) > 2 and bool(next_bn[2])))
+        dx, part = _S._dgrad_add(dqkv, s.wqkv, d2, s.wqkv_t,
+                                 bnred=(next_bn[0], next_bn[1], len(next_bn) > 2 and bool(next_bn[2])) + tuple(next_bn[3:]))
     else:
         dx = _S._dgrad_add(dqkv, s.wqkv, d2, s.wqkv_t)
     _S.position_bias_backward(blk, s, bc)
@@ -163,6 +163,7 @@ def attn_block_backward(blk, s, dout, dt, bc, part2=None, next_bn=None):
 
 
 _FUSE_BNRED = os.environ.get("FRHIP_ALT_FUSE_BNRED", "1") == "1"      # 0: conv -> conv transitions only (the round-3 behaviour; A/B switch)
+_FUSE_BNRED_RS = os.environ.get("FRHIP_ALT_FUSE_BNRED_RS", "1") == "1"   # 0: attention blocks under stochastic depth keep their own reduction pass
 
 
 class AlterNet(nn.Module):
@@ -281,6 +282,9 @@ class AlterNet(nn.Module):
                     nxt = (ps.y2, ps.st2)
                 elif ps.keep is None:
                     nxt = (ps.po.view(ps.shape), ps.st2, False)
+                elif _FUSE_BNRED_RS:
+                    # stochastic depth: the sums carry the per-sample factor (frhip_conv_dgrad_fused_rs)
+                    nxt = (ps.po.view(ps.shape), ps.st2, False, ps.keep, ps.shape[1] * ps.shape[2], 1.0 / (1.0 - layers[i - 1].drop_path_rate))
             if isinstance(mod, BasicBlock):
                 res = basic_block_backward(mod, s, dout, dt, bc, part2=part, next_bn=nxt)
             else:

@@ -300,7 +300,7 @@ def _dgrad_add(dy2d, w2d, residual2d, wt=None, bnred=None):
     wt = _transposed(w2d, wt)                       # [C][K]: K-contiguous rows of the transposed weight
     if bnred is not None:
         dx, part = ops.conv_dgrad(dy2d.view(m, 1, 1, k), wt.view(c, 1, 1, k), (m, 1, 1, c), 1, 1, 1, 0,
-                                  residual=residual2d.view(m, 1, 1, c), bnred=(bnred[0].view(m, 1, 1, c), bnred[1], bnred[2]))
+                                  residual=residual2d.view(m, 1, 1, c), bnred=(bnred[0].view(m, 1, 1, c),) + tuple(bnred[1:]))
         return dx.view(m, c), part
     return ops.conv_dgrad(dy2d.view(m, 1, 1, k), wt.view(c, 1, 1, k), (m, 1, 1, c), 1, 1, 1, 0,
                           residual=residual2d.view(m, 1, 1, c)).view(m, c)

@@ -636,8 +636,8 @@ def basic_block_backward(blk, s, dout, dt, bc, part2=None, next_bn=None):
     if early1:
         bc.wgrad(dy1, s.x, phys_grad(G(blk.conv1.weight)), 3, 3, 1, 1)
     if next_bn is not None:
-        dx = ops.conv_dgrad(dy1, w1t, s.x.shape, 3, 3, 1, 1, residual=shortcut, bnred=(next_bn[0], next_bn[1], len(next_bn) > 2 and bool(next_bn[2])),
-                            residual_stride=sc_stride)
+        dx = ops.conv_dgrad(dy1, w1t, s.x.shape, 3, 3, 1, 1, residual=shortcut,
+                            bnred=(next_bn[0], next_bn[1], len(next_bn) > 2 and bool(next_bn[2])) + tuple(next_bn[3:]), residual_stride=sc_stride)
     else:
         dx = ops.conv_dgrad(dy1, w1t, s.x.shape, 3, 3, 1, 1, residual=shortcut, residual_stride=sc_stride)
     if not early1:

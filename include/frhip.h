@@ -104,6 +104,15 @@ int frhip_conv_dgrad_fused(int dtype, const void* dy, const void* wt, void* dx, 
                            const void* y_bn, const float* mean, const float* invstd, const float* mask_scale,
                            const float* mask_shift, float* stats_partial, int n, int h, int wd, int c, int k,
                            int r, int s, int stride, int pad, frhip_stream_t stream);
+/* frhip_conv_dgrad_fused for a BatchNorm under stochastic depth (nets/AlterNet_SwinV2_FAN.py:407-450: x + drop_path(norm(f(x))), the
+ * BatchNorm's incoming gradient is dx * rowscale[sample]): rowscale[g] (fp32: 0 for a dropped sample, keep_scale = 1 / keep-probability for
+ * a kept one) covers the rows_per consecutive rows of sample g; the partial sums are those frhip_bn_bwd_reduce_rs would produce from the
+ * stored dx, dx itself is stored unscaled.  Replaces that separate pass over (dx, y_bn) in the attention blocks' backward. */
+int frhip_conv_dgrad_fused_rs(int dtype, const void* dy, const void* wt, void* dx, const void* residual, int residual_stride,
+                              const void* y_bn, const float* mean, const float* invstd, const float* mask_scale,
+                              const float* mask_shift, const float* rowscale, int rows_per, float keep_scale,
+                              float* stats_partial, int n, int h, int wd, int c, int k, int r, int s, int stride, int pad,
+                              frhip_stream_t stream);
 /* dw[k,r,s,c] (fp32, caller-zeroed) += sum over output pixels dy * x.  autograd of nn.Conv2d w.r.t. weight.
  * splits <= 0: library picks the split-K factor.  workspace (may be NULL): caller-owned scratch used by THIS call only
  * (one per stream); when splits * sizeof(dw) fits, each K split stores a private slab with plain stores and one reduce

@@ -99,3 +99,33 @@ def test_alternet50_bf16_training_step_tracks_the_reference_fixture(golden):
         if want.size >= 16384:              # (the 2 048-element position-bias MLP gradients of stage 2 sit at 0.79 after 40 bf16 blocks)
             cos = float(got @ want / (np.linalg.norm(got) * np.linalg.norm(want)))
             assert cos >= 0.80, (k, cos)
+
+
+def test_stochastic_depth_reductions_fused_into_the_producing_data_gradient(monkeypatch):
+    """AlterNet50 in training mode WITH stochastic depth (drop_path 0.1, the reference default): the BatchNorm-backward sums of an attention
+    block's norm2 ride in the data-gradient that produces its incoming gradient (frhip_conv_dgrad_fused_rs) instead of a pass of their own --
+    every parameter gradient must equal the unfused route's on the same per-sample keep draws."""
+    import nets.AlterNet_SwinV2_FAN as A
+    x = recipe.images(7501, 8, 192, 192).cuda()
+    gy = recipe.normal(7502, (8, 512), 0.05).cuda()
+    res = []
+    for fused in (True, False):
+        monkeypatch.setattr(A, "_FUSE_BNRED_RS", fused)
+        net = _alternet50("fp32", 7500).train()
+        net.dropout.p = 0.0
+        torch.manual_seed(7503)                      # the keep masks come from torch's device generator
+        y = net(x)
+        y.backward(gy)
+        torch.cuda.synchronize()
+        res.append((y.detach().float().cpu(), {k: p.grad.float().cpu() for k, p in net.named_parameters()}))
+    (ya, ga), (yb, gb) = res
+    assert torch.equal(ya, yb)                       # same forward, same keeps
+    dropped = 0
+    for k in ga:
+        if k.endswith(NOISE) or k == "fc.bias":          # analytically-zero gradients: round-off only
+            continue
+        a, b = ga[k].double(), gb[k].double()
+        denom = float(b.norm()) + 1e-12
+        assert float((a - b).norm()) <= 1e-3 * denom + 1e-7, (k, float((a - b).norm()) / denom)
+        dropped += 1
+    assert dropped > 250

@@ -699,3 +699,41 @@ def test_bf16_gelu_pair_stays_within_two_to_the_minus_ten_of_the_exact_erf_form(
         rnd_s = 2.0 ** -8 * slope.abs() if dtype == torch.bfloat16 else 0.0
         assert bool(((act - val).abs() <= dv + rnd_v).all()), float(((act - val).abs() - rnd_v).max())
         assert bool(((dh - slope).abs() <= ds + rnd_s).all()), float(((dh - slope).abs() - rnd_s).max())
+
+
+@pytest.mark.parametrize("case", [("bf16 3x3 whole tiles", torch.bfloat16, 32, 12, 256, 256, 3), ("fp32 3x3 ragged", torch.float32, 6, 6, 64, 64, 3),
+                                  ("bf16 1x1 qkv data-gradient", torch.bfloat16, 32, 12, 256, 768, 1), ("bf16 1x1 small maps", torch.bfloat16, 64, 6, 512, 1536, 1)])
+def test_dgrad_carries_batchnorm_backward_sums_under_stochastic_depth(case):
+    """frhip_conv_dgrad_fused_rs: the data-gradient whose result enters a BatchNorm under stochastic depth (AlterNet attention blocks:
+    x + drop_path(norm(f(x))), /root/reference/nets/AlterNet_SwinV2_FAN.py:407-450) emits that BatchNorm's backward sums with the per-sample
+    factor -- dropped samples' rows contribute nothing, kept ones 1 / keep-probability times their gradient -- exactly what the separate pass
+    frhip_bn_bwd_reduce_rs computes from the stored dx; dx itself is the unscaled data-gradient, bit for bit."""
+    ops = _ops()
+    from frhip._abi import lib
+    _, dtype, n, hw, c, k, r = case
+    pad = (r - 1) // 2
+    dy = q(rnd(61, (n, hw, hw, k)), dtype).to(dtype).cuda()
+    wt = q(rnd(62, (c, r, r, k), 0.05), dtype).to(dtype).cuda()
+    res = q(rnd(63, (n, hw, hw, c)), dtype).to(dtype).cuda()
+    y = q(rnd(64, (n, hw, hw, c)) * 1.3 + 0.2, dtype).to(dtype).cuda()
+    rows = n * hw * hw
+    st = ops.bn_finalize(ops.colstats(y.view(rows, c)), rows, torch.ones(c, device="cuda"), torch.zeros(c, device="cuda"), None, None)
+    kp = 0.9
+    gen = torch.Generator().manual_seed(65)
+    keep = ((torch.rand(n, generator=gen) < 0.6).float() / kp).cuda()          # 40 % dropped: both kinds of row in most tiles
+    dx, part = ops.conv_dgrad(dy, wt, (n, hw, hw, c), r, r, 1, pad, residual=res, bnred=(y, st, False, keep, hw * hw, 1.0 / kp))
+    plain = ops.conv_dgrad(dy, wt, (n, hw, hw, c), r, r, 1, pad, residual=res)
+    assert torch.equal(dx, plain)
+    nb = lib().frhip_colreduce_blocks(rows, c, ops.dt_of(y))
+    ref = torch.empty((nb, 2, c), dtype=torch.float32, device="cuda")
+    ops.check(lib().frhip_bn_bwd_reduce_rs(ops.dt_of(y), ops._p(dx), ops._p(y), ops._p(st.mean), ops._p(st.invstd), ops._p(keep), hw * hw, rows, c,
+                                           ops._p(ref), ops._s()), "frhip_bn_bwd_reduce_rs")
+    got, want = part.sum(0).cpu().numpy(), ref.sum(0).cpu().numpy()
+    # and float64 on the host
+    d = dx.float().cpu().double() * keep.cpu().double().repeat_interleave(hw * hw).view(n, hw, hw, 1)
+    xh = (y.float().cpu().double() - st.mean.cpu().double()) * st.invstd.cpu().double()
+    host = [d.sum((0, 1, 2)).numpy(), (d * xh).sum((0, 1, 2)).numpy()]
+    for i in (0, 1):
+        scale = float(np.abs(host[i]).max())
+        np.testing.assert_allclose(want[i], host[i], rtol=2e-3, atol=2e-3 * scale, err_msg="separate pass vs float64, sum %d" % i)
+        np.testing.assert_allclose(got[i], host[i], rtol=2e-3, atol=2e-3 * scale, err_msg="fused epilogue vs float64, sum %d" % i)
