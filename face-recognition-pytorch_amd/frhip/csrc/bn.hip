@@ -132,16 +132,49 @@ __device__ __forceinline__ void sum_parts(const float* __restrict__ parts, int n
     for (int l = 0; l < PL; ++l) { s1 += red[l][0][cl]; s2 += red[l][1][cl]; }
 }
 
+// The same fold by a 256-thread block of 16 channels x 16 lanes (grid = C / 16).  The 1024-thread blocks above need sixteen free wave
+// slots and their registers on ONE CU: beside the persistent linear / weight-gradient workgroups of the Swin and AlterNet steps a
+// finalize launch then waits for a whole workgroup of the other stream to retire (timeline, Swin34: bn_bwd_finalize 27.6 us per launch
+// inside the step against 5.1 us alone, 0.5 ms of the step on its critical path).  A 4-wave block fits the leftover slots at once.
+__device__ __forceinline__ void sum_parts16(const float* __restrict__ parts, int nparts, int C, int c, int pl,
+                                            float (*red)[2][16], float& s1, float& s2) {
+    float a1 = 0.f, a2 = 0.f;
+    if (c < C) {
+        int p = pl;
+        for (; p + 7 * 16 < nparts; p += 8 * 16) {
+            float x[8], y[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const float* r = parts + (size_t)(p + u * 16) * 2 * C; x[u] = r[c]; y[u] = r[C + c]; }
+            a1 += ((x[0] + x[1]) + (x[2] + x[3])) + ((x[4] + x[5]) + (x[6] + x[7]));
+            a2 += ((y[0] + y[1]) + (y[2] + y[3])) + ((y[4] + y[5]) + (y[6] + y[7]));
+        }
+        for (; p < nparts; p += 16) { a1 += parts[(size_t)p * 2 * C + c]; a2 += parts[(size_t)p * 2 * C + C + c]; }
+    }
+    red[pl][0][threadIdx.x & 15] = a1; red[pl][1][threadIdx.x & 15] = a2;
+    __syncthreads();
+    const int cl = threadIdx.x & 15;
+    s1 = 0.f; s2 = 0.f;
+#pragma unroll
+    for (int l = 0; l < 16; ++l) { s1 += red[l][0][cl]; s2 += red[l][1][cl]; }
+}
+
 // Finalise forward batch statistics.
-__global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restrict__ parts, int nparts, int C, float count,
+template <bool SMALL>
+__global__ __launch_bounds__(SMALL ? 256 : 1024) void bn_finalize_kernel(const float* __restrict__ parts, int nparts, int C, float count,
                                    const float* __restrict__ gamma, const float* __restrict__ beta,
                                    float* __restrict__ running_mean, float* __restrict__ running_var,
                                    float momentum, float eps, float* __restrict__ mean_out,
                                    float* __restrict__ invstd_out, float* __restrict__ scale, float* __restrict__ shift) {
     __shared__ float red[FIN_MAX_PL][2][64];
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63), pl = threadIdx.x >> 6;
+    int c, pl;
     float s1, s2;
-    sum_parts(parts, nparts, C, c, pl, red, s1, s2);
+    if constexpr (SMALL) {
+        c = blockIdx.x * 16 + (threadIdx.x & 15); pl = threadIdx.x >> 4;
+        sum_parts16(parts, nparts, C, c, pl, reinterpret_cast<float (*)[2][16]>(&red[0][0][0]), s1, s2);
+    } else {
+        c = blockIdx.x * 64 + (threadIdx.x & 63); pl = threadIdx.x >> 6;
+        sum_parts(parts, nparts, C, c, pl, red, s1, s2);
+    }
     if (pl != 0 || c >= C) return;
     const float mu = s1 / count;
     float var = s2 / count - mu * mu;
@@ -168,15 +201,22 @@ __global__ void bn_eval_kernel(int C, const float* __restrict__ gamma, const flo
 }
 
 // Finalise backward sums: dgamma, dbeta and the per-channel affine of  dy = ca*d_eff + cb*y + cc.
-__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __restrict__ parts, int nparts, int C, float count,
+template <bool SMALL>
+__global__ __launch_bounds__(SMALL ? 256 : 1024) void bn_bwd_finalize_kernel(const float* __restrict__ parts, int nparts, int C, float count,
                                        const float* __restrict__ gamma, const float* __restrict__ mean,
                                        const float* __restrict__ invstd, float* __restrict__ dgamma,
                                        float* __restrict__ dbeta, float* __restrict__ ca, float* __restrict__ cb,
                                        float* __restrict__ cc) {
     __shared__ float red[FIN_MAX_PL][2][64];
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63), pl = threadIdx.x >> 6;
+    int c, pl;
     float s1, s2;
-    sum_parts(parts, nparts, C, c, pl, red, s1, s2);
+    if constexpr (SMALL) {
+        c = blockIdx.x * 16 + (threadIdx.x & 15); pl = threadIdx.x >> 4;
+        sum_parts16(parts, nparts, C, c, pl, reinterpret_cast<float (*)[2][16]>(&red[0][0][0]), s1, s2);
+    } else {
+        c = blockIdx.x * 64 + (threadIdx.x & 63); pl = threadIdx.x >> 6;
+        sum_parts(parts, nparts, C, c, pl, red, s1, s2);
+    }
     if (pl != 0 || c >= C) return;
     dgamma[c] += s2; dbeta[c] += s1;                 // accumulate into (caller-zeroed) .grad
     const float gi = gamma[c] * invstd[c], m2 = s2 / count, m1 = s1 / count;
@@ -416,6 +456,9 @@ static const float* fold_partials(const float* partial, int& nparts, int c, floa
     return scratch;
 }
 static int fin_threads(int nparts) { return nparts > 64 ? 1024 : 256; }
+// FRHIP_BN_FIN_SMALL (default 1): folds of more than 64 rows by 256-thread blocks of 16 channels (0: 1024-thread blocks of 64 channels)
+static const int g_fin_small = getenv("FRHIP_BN_FIN_SMALL") ? atoi(getenv("FRHIP_BN_FIN_SMALL")) : 1;
+static bool fin_small(int nparts) { return g_fin_small == 1 ? nparts > 64 : (g_fin_small >= 2 ? nparts >= g_fin_small : false); }   // >= 2: a row threshold
 
 extern "C" int frhip_bn_finalize(const float* partial, int nparts, float* scratch, int c, float count,
                                  const float* gamma, const float* beta, float* running_mean, float* running_var,
@@ -423,8 +466,12 @@ extern "C" int frhip_bn_finalize(const float* partial, int nparts, float* scratc
                                  hipStream_t stream) {
     // scratch: 64*2*c floats
     const float* p = fold_partials(partial, nparts, c, scratch, stream);
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((c + 63) / 64), dim3(fin_threads(nparts)), 0, stream, p, nparts, c, count, gamma, beta,
-                       running_mean, running_var, momentum, eps, mean, invstd, scale, shift);
+    if (fin_small(nparts))
+        hipLaunchKernelGGL(bn_finalize_kernel<true>, dim3((c + 15) / 16), dim3(256), 0, stream, p, nparts, c, count, gamma, beta,
+                           running_mean, running_var, momentum, eps, mean, invstd, scale, shift);
+    else
+        hipLaunchKernelGGL(bn_finalize_kernel<false>, dim3((c + 63) / 64), dim3(fin_threads(nparts)), 0, stream, p, nparts, c, count, gamma, beta,
+                           running_mean, running_var, momentum, eps, mean, invstd, scale, shift);
     return check_launch("frhip_bn_finalize");
 }
 
@@ -439,8 +486,12 @@ extern "C" int frhip_bn_bwd_finalize(const float* partial, int nparts, float* sc
                                      const float* gamma, const float* mean, const float* invstd, float* dgamma,
                                      float* dbeta, float* ca, float* cb, float* cc, hipStream_t stream) {
     const float* p = fold_partials(partial, nparts, c, scratch, stream);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((c + 63) / 64), dim3(fin_threads(nparts)), 0, stream, p, nparts, c, count, gamma,
-                       mean, invstd, dgamma, dbeta, ca, cb, cc);
+    if (fin_small(nparts))
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel<true>, dim3((c + 15) / 16), dim3(256), 0, stream, p, nparts, c, count, gamma,
+                           mean, invstd, dgamma, dbeta, ca, cb, cc);
+    else
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel<false>, dim3((c + 63) / 64), dim3(fin_threads(nparts)), 0, stream, p, nparts, c, count, gamma,
+                           mean, invstd, dgamma, dbeta, ca, cb, cc);
     return check_launch("frhip_bn_bwd_finalize");
 }
 
