@@ -336,14 +336,23 @@ __global__ __launch_bounds__(EW_THREADS) void bn_bwd_apply_kernel(const T* __res
 
 // out[c] += sum_p partial[p][which][c]      (block = 64 channels x 16 lanes; was one thread per channel walking all rows:
 // 199 us per call on the Swin bias gradients with ~1000 partial rows)
-__global__ __launch_bounds__(1024) void sum_partials_kernel(const float* __restrict__ partial, int nparts, int C, int which,
-                                                            float* __restrict__ out) {
-    __shared__ float red[16][64];
-    const int cl = threadIdx.x & 63, pl = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + cl;
+__global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restrict__ partial, int nparts, int C, int which,
+                                                           float* __restrict__ out) {
+    // 16 channels x 16 lanes per block (256 threads: fits beside the other stream's persistent workgroups, see bn_finalize_kernel<true>)
+    __shared__ float red[16][16];
+    const int cl = threadIdx.x & 15, pl = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
     float acc = 0.f;
-    if (c < C)
-        for (int p = pl; p < nparts; p += 16) acc += partial[((size_t)p * 2 + which) * C + c];
+    if (c < C) {
+        int p = pl;
+        for (; p + 7 * 16 < nparts; p += 8 * 16) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = partial[((size_t)(p + u * 16) * 2 + which) * C + c];
+            acc += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+        }
+        for (; p < nparts; p += 16) acc += partial[((size_t)p * 2 + which) * C + c];
+    }
     red[pl][cl] = acc;
     __syncthreads();
     if (pl == 0 && c < C) {
@@ -587,7 +596,7 @@ extern "C" int frhip_bn_bwd_apply(int dtype, const void* dout, const void* y, co
 }
 
 extern "C" int frhip_sum_partials(const float* partial, int nparts, int c, int which, float* out_accum, hipStream_t stream) {
-    hipLaunchKernelGGL(sum_partials_kernel, dim3((c + 63) / 64), dim3(1024), 0, stream, partial, nparts, c, which, out_accum);
+    hipLaunchKernelGGL(sum_partials_kernel, dim3((c + 15) / 16), dim3(256), 0, stream, partial, nparts, c, which, out_accum);
     return check_launch("frhip_sum_partials");
 }
 

@@ -140,7 +140,8 @@ def attn_block_backward(blk, s, dout, dt, bc, part2=None, next_bn=None):
     dpo = ops.bn_backward(d2, s.po, s.st2, blk.norm2.weight.data, G(blk.norm2.weight), G(blk.norm2.bias),
                           rowscale=s.keep, rows_per=h * w, part=part2)
     # proj.bias only shifts the input of a training-mode BatchNorm: analytically zero gradient (nets/SwinV2.py), left at zero
-    bc.on_side(lambda: ops.gemm_tn(dpo, s.ao, G(at.proj.weight)), dpo, s.ao)
+    if not _PAIR_HANDOVER:                        # else: proj's and qkv's weight gradients go to the side stream in ONE hand-over below
+        bc.on_side(lambda: ops.gemm_tn(dpo, s.ao, G(at.proj.weight)), dpo, s.ao)
     dao = ops.gemm_nt(dpo, _S._transposed(s.wproj, s.wproj_t))
     dqkv, _, _, gsum = ops.winattn_bwd(s.qkv, dao, s.bias, s.scale, b, h, w, at.num_heads, blk.window_size,
                                        blk.shift_size, want_colsum=True, dbias=s.dbias, dscale=s.dscale,
@@ -151,7 +152,10 @@ def attn_block_backward(blk, s, dout, dt, bc, part2=None, next_bn=None):
     if gsum is not True:                             # bf16 MFMA kernel: already added into the two gradient accumulators
         G(at.q_bias).add_(gsum[:c])
         G(at.v_bias).add_(gsum[2 * c:])
-    bc.on_side(lambda: ops.gemm_tn(dqkv, s.x2, G(at.qkv.weight)), dqkv, s.x2)
+    if _PAIR_HANDOVER:
+        bc.on_side(lambda: (ops.gemm_tn(dpo, s.ao, G(at.proj.weight)), ops.gemm_tn(dqkv, s.x2, G(at.qkv.weight))), dpo, s.ao, dqkv, s.x2)
+    else:
+        bc.on_side(lambda: ops.gemm_tn(dqkv, s.x2, G(at.qkv.weight)), dqkv, s.x2)
     part = None
     if next_bn is not None:
         dx, part = _S._dgrad_add(dqkv, s.wqkv, d2, s.wqkv_t,
@@ -163,6 +167,7 @@ def attn_block_backward(blk, s, dout, dt, bc, part2=None, next_bn=None):
 
 
 _FUSE_BNRED = os.environ.get("FRHIP_ALT_FUSE_BNRED", "1") == "1"      # 0: conv -> conv transitions only (the round-3 behaviour; A/B switch)
+_PAIR_HANDOVER = os.environ.get("FRHIP_ALT_PAIR_HANDOVER", "1") == "1"   # proj's and qkv's weight gradients in ONE hand-over to the side stream
 _FUSE_BNRED_RS = os.environ.get("FRHIP_ALT_FUSE_BNRED_RS", "1") == "1"   # 0: attention blocks under stochastic depth keep their own reduction pass
 
 

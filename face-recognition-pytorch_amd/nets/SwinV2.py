@@ -292,6 +292,12 @@ def swin_block_forward(blk, x, dt, training, save, wprep=None):
     return out, s
 
 
+# Swin34, same box, three alternating runs: 14.98 ms with one hand-over per weight gradient, 15.29 ms with pairs (fc2's weight gradient then starts a
+# whole fc2 data-gradient later and the side queue ends the backward pass behind): off here.  The AlterNet attention blocks (two weight
+# gradients, no MLP) have their own switch (nets.AlterNet_SwinV2_FAN._PAIR_HANDOVER: 11.79 against 12.18 ms with pairs, on).
+_PAIR_HANDOVER = os.environ.get("FRHIP_PAIR_HANDOVER", "0") == "1"
+
+
 def _dgrad_add(dy2d, w2d, residual2d, wt=None, bnred=None):
     """dy [M,K] @ w [K,C] + residual [M,C], as a 1x1 data-gradient with the residual add fused.
     bnred=(y [.., C], BN state, relu): also the BN-backward partial sums of the result against y -> (dx, partial)"""
@@ -320,15 +326,23 @@ def swin_block_backward(blk, s, dout, dt, bc, next_bn=None, part3=None):
     # fc2.bias (and proj.bias below) only shift the input of a training-mode BatchNorm: their gradient, the column sums of
     # that BatchNorm's input gradient, is analytically zero (sum_rows dy = gamma * invstd * (sum d - N mean(d) - mean(d xhat)
     # * sum xhat) = 0); the reference gets 1e-8-sized round-off there.  Left at the arena's zero: no reduction pass.
-    bc.on_side(lambda: ops.gemm_tn(dmo, s.act, G(blk.mlp.fc2.weight).view(c, 4 * c)), dmo, s.act)
+    # Hand-overs to the side stream cost the MAIN queue ~6.5 us each (the event record in front of the next launch: timeline, 45 per Swin34
+    # step); handing the weight gradients over in PAIRS (_PAIR_HANDOVER) was measured slower here all the same, see above
+    if not _PAIR_HANDOVER:
+        bc.on_side(lambda: ops.gemm_tn(dmo, s.act, G(blk.mlp.fc2.weight).view(c, 4 * c)), dmo, s.act)
     # [M, 4C]: fc2's data-gradient with gelu'(hid) and fc1.bias's gradient (column sums) fused into its epilogue
     dhid, _ = ops.linear_dgrad_gelu(dmo, _transposed(s.w2, s.w2_t), s.hid, colsum_into=G(blk.mlp.fc1.bias))
-    bc.on_side(lambda: ops.gemm_tn(dhid, s.x1, G(blk.mlp.fc1.weight).view(4 * c, c)), dhid, s.x1)
+    if _PAIR_HANDOVER:
+        bc.on_side(lambda: (ops.gemm_tn(dmo, s.act, G(blk.mlp.fc2.weight).view(c, 4 * c)),
+                            ops.gemm_tn(dhid, s.x1, G(blk.mlp.fc1.weight).view(4 * c, c))), dmo, s.act, dhid, s.x1)
+    else:
+        bc.on_side(lambda: ops.gemm_tn(dhid, s.x1, G(blk.mlp.fc1.weight).view(4 * c, c)), dhid, s.x1)
     # dx1 is the upstream gradient of norm2: its backward reduction over (dx1, po) rides in this data-gradient's epilogue
     dx1, part2 = _dgrad_add(dhid, s.w1, d2, s.w1_t, bnred=(s.po, s.st2, False))
     # ---- attention branch: x1 = x + BN(proj(attn(qkv(x))))
     dpo = ops.bn_backward(dx1, s.po, s.st2, blk.norm2.weight.data, G(blk.norm2.weight), G(blk.norm2.bias), part=part2)
-    bc.on_side(lambda: ops.gemm_tn(dpo, s.ao, G(at.proj.weight)), dpo, s.ao)
+    if not _PAIR_HANDOVER:
+        bc.on_side(lambda: ops.gemm_tn(dpo, s.ao, G(at.proj.weight)), dpo, s.ao)
     dao = ops.gemm_nt(dpo, _transposed(s.wproj, s.wproj_t))
     dqkv, _, _, gsum = ops.winattn_bwd(s.qkv, dao, s.bias, s.scale, b, h, w, at.num_heads, want_colsum=True,
                                        dbias=s.dbias, dscale=s.dscale,      # d(bias), d(scale) accumulate in the batch's arena
@@ -339,7 +353,10 @@ def swin_block_backward(blk, s, dout, dt, bc, next_bn=None, part3=None):
     if gsum is not True:                             # bf16 MFMA kernel: already added into the two gradient accumulators
         G(at.q_bias).add_(gsum[:c])
         G(at.v_bias).add_(gsum[2 * c:])
-    bc.on_side(lambda: ops.gemm_tn(dqkv, s.x2, G(at.qkv.weight)), dqkv, s.x2)
+    if _PAIR_HANDOVER:
+        bc.on_side(lambda: (ops.gemm_tn(dpo, s.ao, G(at.proj.weight)), ops.gemm_tn(dqkv, s.x2, G(at.qkv.weight))), dpo, s.ao, dqkv, s.x2)
+    else:
+        bc.on_side(lambda: ops.gemm_tn(dqkv, s.x2, G(at.qkv.weight)), dqkv, s.x2)
     part = None
     if next_bn is not None:
         dx, part = _dgrad_add(dqkv, s.wqkv, dx1, s.wqkv_t, bnred=next_bn)

@@ -128,4 +128,4 @@ def test_stochastic_depth_reductions_fused_into_the_producing_data_gradient(monk
         denom = float(b.norm()) + 1e-12
         assert float((a - b).norm()) <= 1e-3 * denom + 1e-7, (k, float((a - b).norm()) / denom)
         dropped += 1
-    assert dropped > 250
+    assert dropped > 150
