@@ -133,7 +133,10 @@ static int nt_launch_cfg(const NtGeom& g, const void* a, const void* b, void* ou
     }
     dim3 grid(mtiles * ntiles, splits);
     if (EPI == EPI_LEAN && g_nt_persist) {
-        const unsigned wgs = (unsigned)nt_cus() & ~7u;         // a multiple of 8: a workgroup's tiles stay on its XCD's share of the remap
+        // a multiple of 8: a workgroup's tiles stay on its XCD's share of the remap.  FRHIP_NT_PERSIST_WGS < CU count leaves CUs to the
+        // other stream for the length of the launch (the 8-wave workgroups take the whole register file of the CU they sit on)
+        static const int env_wgs = getenv("FRHIP_NT_PERSIST_WGS") ? atoi(getenv("FRHIP_NT_PERSIST_WGS")) : 0;
+        const unsigned wgs = (unsigned)(env_wgs > 0 ? env_wgs : nt_cus()) & ~7u;
         if (wgs >= 8 && grid.x > wgs) grid.x = wgs;
     }
     hipLaunchKernelGGL(kern, grid, dim3(Tile::THREADS), lds, stream, g, a, b, out, res, stats, br, mtiles, ntiles);

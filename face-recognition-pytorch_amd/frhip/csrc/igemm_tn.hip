@@ -735,21 +735,40 @@ __device__ __forceinline__ f32x4_t slab_load(const float* p) {
     else return *reinterpret_cast<const f32x4_t*>(p);
 }
 
-__global__ __launch_bounds__(256) void slab_reduce_kernel(float* __restrict__ slabs, int count, int per_group,
-                                                          size_t step, float* __restrict__ out, size_t n4, int final) {
+// At most 32 VGPRs per lane (two accumulators, two loads in flight): the persistent 8-wave linear kernels of the main stream (240 VGPRs, two
+// waves per SIMD) leave exactly 32 registers per lane free on every CU, and with 46 this reduce -- 54 launches per Swin34 step on the side
+// stream -- waited for a whole linear launch to retire every time (47.9 us per launch inside the step against 7.0 us alone).
+#ifndef SLAB_WIDE
+#define SLAB_WIDE 0
+#endif
+#ifndef SLAB_VGPR
+#define SLAB_VGPR 32
+#endif
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(SLAB_VGPR)))
+void slab_reduce_kernel(float* __restrict__ slabs, int count, int per_group, size_t step, float* __restrict__ out, size_t n4, int final) {
     const int s0 = blockIdx.y * per_group, s1 = min(count, s0 + per_group);
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
-        f32x4_t a0 = f32x4_t{0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
+        f32x4_t a0 = f32x4_t{0.f, 0.f, 0.f, 0.f}, a1 = a0;
+        const float* src = slabs + (size_t)s0 * step + i * 4;
         int sp = s0;
+#if SLAB_WIDE        // A/B build (-DSLAB_WIDE=1 -DSLAB_VGPR=64): four loads in flight, 46 registers -- the round-3 kernel
+        f32x4_t a2 = a0, a3 = a0;
         for (; sp + 4 <= s1; sp += 4) {
-            const f32x4_t v0 = slab_load(slabs + (size_t)(sp + 0) * step + i * 4);
-            const f32x4_t v1 = slab_load(slabs + (size_t)(sp + 1) * step + i * 4);
-            const f32x4_t v2 = slab_load(slabs + (size_t)(sp + 2) * step + i * 4);
-            const f32x4_t v3 = slab_load(slabs + (size_t)(sp + 3) * step + i * 4);
+            const f32x4_t v0 = slab_load(src), v1 = slab_load(src + step), v2 = slab_load(src + 2 * step), v3 = slab_load(src + 3 * step);
+            src += 4 * step;
             a0 += v0; a1 += v1; a2 += v2; a3 += v3;
         }
-        for (; sp < s1; ++sp) a0 += *reinterpret_cast<const f32x4_t*>(slabs + (size_t)sp * step + i * 4);
-        f32x4_t acc = (a0 + a1) + (a2 + a3);
+        a0 += a2; a1 += a3;
+#endif
+#pragma unroll 1
+        for (; sp + 2 <= s1; sp += 2) {
+            const f32x4_t v0 = slab_load(src);
+            const f32x4_t v1 = slab_load(src + step);
+            src += 2 * step;
+            a0 += v0; a1 += v1;
+        }
+        if (sp < s1) a0 += *reinterpret_cast<const f32x4_t*>(src);
+        f32x4_t acc = a0 + a1;
         if (final) {
             acc += reinterpret_cast<const f32x4_t*>(out)[i];
             reinterpret_cast<f32x4_t*>(out)[i] = acc;
