@@ -14,7 +14,7 @@ cd $R
 # QUICK=2: the same plus the PMC traffic passes (a change in igemm_nt* / igemm_halo* / common.h moves the digest bench.py checks)
 QUICK=${QUICK:-0}
 # PMC traffic passes first: bench.py reports roofline.traffic only from a pass whose kernel-source digest matches this tree
-if [ "$QUICK" != 1 ]; then
+if [ "$QUICK" != 1 ]; then    # QUICK=0, 2, 3
 rm -rf $R/gpurun_out/pmc
 bash tools/pmc_traffic.sh > $OUT/pmc.log 2>&1
 python tools/pmc_traffic_report.py gpurun_out/pmc ${TAG:-r03} > $OUT/pmc_report.log 2>&1
@@ -35,7 +35,8 @@ python tools/trace_summary.py $(ls $OUT/swin/*kernel_trace.csv | head -1) > $OUT
 python tools/trace_summary.py $(ls $OUT/alt/*kernel_trace.csv | head -1) > $OUT/alt_step_anatomy.txt
 rm -f $OUT/serial/*kernel_trace.csv $OUT/swin/*kernel_trace.csv $OUT/alt/*kernel_trace.csv $OUT/stats/*kernel_trace.csv $OUT/overlap_trace.csv
 python tools/bench_eval.py ResNet50 512 > $OUT/eval.txt 2>&1 || true
-if [ "$QUICK" != 0 ]; then ls $OUT | head -40; exit 0; fi
+if [ "$QUICK" = 1 ] || [ "$QUICK" = 2 ]; then ls $OUT | head -40; exit 0; fi
+# QUICK=3: QUICK=2 plus the MFMA-utilisation counters below, without the diagnostic builds (in-kernel clock, ablation)
 # MFMA utilisation / LDS counters of the dominant kernels (256-channel 14x14 layer, B = 512), one rocprofv3 pass per counter group
 for what in fwd dgrad wgrad; do
   bash tools/pmc_run.sh $OUT/pmc_$what $what 14 256 256 > $OUT/pmc_$what.log 2>&1 || true
@@ -44,6 +45,7 @@ done
 FRHIP_T9_NARROW=0 FRHIP_T9_LDS_PAD=0 bash tools/pmc_run.sh $OUT/pmc_wgrad8 wgrad 14 256 256 > $OUT/pmc_wgrad8.log 2>&1 || true
 python tools/pmc_show.py $OUT/pmc_wgrad8 > $OUT/pmc_wgrad8.txt 2>/dev/null || true
 rm -rf $OUT/pmc_*/g*      # raw counter CSVs: summarised in pmc_*.txt
+if [ "$QUICK" = 3 ]; then ls $OUT | head -40; exit 0; fi
 # in-kernel clock of the halo kernels (diagnostic build: `python tools/clock_probe.py build` before the snapshot) and the timing-only
 # ablation of the 4-wave halo kernel (`ABL_ONLY=... python tools/ablate.py build`)
 CLOCK_SECS=1.5 python tools/clock_probe.py run > $OUT/clock.txt 2>&1 || true
