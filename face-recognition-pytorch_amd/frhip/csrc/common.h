@@ -40,6 +40,22 @@ __device__ __forceinline__ void glds16(__amdgpu_buffer_rsrc_t rsrc, void* lds_ba
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_ADDR(lds_base), 16, voff, 0, 0, AUX);
 }
 
+// The same load issued as inline assembly.  The builtin above is known to the compiler's wait-count pass as an LDS write it cannot
+// disambiguate: every later LDS read whose address it cannot prove distinct -- all ds_read_b64_tr_b16 reads -- gets an
+// s_waitcnt vmcnt(0) in front, which also waits for loads issued to land SEVERAL steps later and so serialises a multi-stage
+// operand pipeline (seen in the disassembly of the nine-tap weight-gradient kernel: one such wait per K step, right behind the
+// step's DMA issue).  A kernel that uses this form owns its vmcnt bookkeeping entirely (counted s_waitcnt + barrier before any
+// read of the landed data) and must not mix it with the builtin (the compiler does not know that M0 changed).
+// lds_addr: wave-uniform LDS byte address of the 1-KiB piece; descriptor: raw buffer, stride 0, out-of-range reads return 0.
+__device__ __forceinline__ u32x4_t make_rsrc_words(const void* p, uint32_t bytes) {
+    const uint64_t a = (uint64_t)(uintptr_t)p;
+    return u32x4_t{(uint32_t)a, (uint32_t)(a >> 32) & 0xffffu, bytes, 0x00020000u};
+}
+__device__ __forceinline__ void glds16_asm(u32x4_t rsrc, uint32_t lds_addr, uint32_t voff) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
+                 :: "s"(__builtin_amdgcn_readfirstlane(lds_addr)), "v"(voff), "s"(rsrc) : "memory");
+}
+
 // ---- element <-> float
 template <typename T> __device__ __forceinline__ float to_f32(T v);
 template <> __device__ __forceinline__ float to_f32<float>(float v) { return v; }

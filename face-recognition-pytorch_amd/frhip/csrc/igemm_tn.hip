@@ -642,6 +642,209 @@ void tn_taps9_kernel(TnGeom g, const void* __restrict__ p_ptr, const void* __res
         }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// "Rows" nine-tap weight gradient for 14 x 14 maps (3x3 / stride 1 / pad 1, bf16; the 256-channel layers of the ResNet body: 28 of the
+// 47 nine-tap launches of a step).  The kernel above walks the pixel stream in K steps of 64 consecutive pixels, so every tap's window
+// fragment is a different shifted read: 52 transposing reads and 36 padding selects per 72 MFMAs, which the ablation names as the binding
+// term.  Here a K step is ONE IMAGE ROW on v_mfma_f32_32x32x16_bf16 (K = 16 slots: 14 pixels + 2 pad), and that turns the
+// three vertical taps into REGISTER reuse: the fragment of input row r at column shift dx serves tap (+1, dx) at output row r - 1, tap
+// (0, dx) at row r and tap (-1, dx) at row r + 1.  Per row and wave: 2 transposed reads for the dy fragment + 6 for the three shifts of ONE
+// new input row feed 9 MFMAs of 32 x 32 x 16 (0.22 reads per 16x16x32-equivalent MFMA instead of 0.72), and no select at all:
+//   * LDS holds an image row at a pitch of 16 pixel slots; slots 14, 15 are zero-filled by the DMA itself (out-of-range lanes), so the pad
+//     K slots of the dy operand, the right neighbour of column 13 and the left neighbour of column 0 (slot 15 of the row before, or the
+//     zero tail of the dy tile in front of the window tile) are ordinary addresses that happen to hold zeros;
+//   * rows above / below the image are MFMAs that are not issued (the image loop is unrolled, the row index is a compile-time constant).
+// Workgroup = 64 co x 64 ci for all nine taps, four waves of 32 x 32 (144 accumulator registers); K split over whole images.
+// LDS: a ring of seven 8-KB slots, slot c = rows 2c, 2c + 1 of the current image (dy tile 4 KB | window tile 4 KB); a slot is refilled
+// with the next image's rows as soon as every wave has consumed it, which leaves a load 8 - 12 row steps (>= 2 500 cycles) to land.
+// Four barriers per image (after rows 3, 7, 11, 13).  16-byte chunks are XOR-swizzled by bit 1 of the pixel slot (x 4) on the source
+// side: the 4 pixel x 64 byte footprint of one LDS cycle of a transposed read then covers all 64 banks once.
+#ifndef R14_PIN
+#define R14_PIN 0
+#endif
+struct R14 {
+    static constexpr int SLOT = 8192, QOFF = 4096, NSLOT = 7, LDS = NSLOT * SLOT + 128, ROWB = 2048;
+};
+__device__ __forceinline__ int r14_swz(int p) { return ((p >> 1) & 1) << 2; }
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+
+// (256, 2): at most 256 registers per lane, arch + accumulator, so that a forward / data-gradient wave fits the same SIMD
+__global__ __launch_bounds__(256, 2)
+void tn_rows14_kernel(TnGeom g, const void* __restrict__ p_ptr, const void* __restrict__ q_ptr, float* __restrict__ out,
+                      int co_tiles, int ci_tiles) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = lane_id(), wave = wave_id();
+    const TnSlot slot = tn_slot(co_tiles * ci_tiles);
+    const uint32_t lin = (uint32_t)slot.tile;
+    const int ci_tile = (int)(lin % (uint32_t)ci_tiles), co_tile = (int)(lin / (uint32_t)ci_tiles);
+    const int img_begin = slot.split * g.ksteps_per_split;                     // here a "K step" of the geometry is one image
+    const int nimg = min(g.ksteps, img_begin + g.ksteps_per_split) - img_begin;
+    const int wco = wave >> 1, wci = wave & 1;
+    const int co0 = co_tile * 64, ci0 = ci_tile * 64;
+
+    f32x16_t acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+
+    // pixel slot 0 of every dy tile and the 128 bytes behind the last slot are read (as pad K slots, against zeros of the other operand)
+    // before the first load into them may have landed: they must not hold NaN patterns left by an earlier workgroup
+    if (wave == 0) *reinterpret_cast<f32x4_t*>(smem + (lane >> 3) * R14::SLOT + (lane & 7) * 16) = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    const u32x4_t rp = make_rsrc_words(p_ptr, g.p_bytes);
+    const u32x4_t rq = make_rsrc_words(q_ptr, g.q_bytes);
+    const uint32_t lds0 = (uint32_t)(uintptr_t)LDS_ADDR(smem);
+
+    // ---- loader: a chunk = 28 consecutive pixels (two image rows) of both operands; wave w moves the 1-KiB piece w (pixel slots 8w .. 8w+7,
+    //      row j = slot >> 4, column = slot & 15; columns 14, 15: out-of-range offset = zero fill) of the dy tile and of the window tile.
+    //      Chunks follow one another in the pixel stream, so the running offsets advance by a constant.
+    uint32_t offp, offq;
+    {
+        const int prow = wave * 8 + (lane >> 3), j = prow >> 4, col = prow & 15;
+        const int ce = ((lane & 7) ^ r14_swz(prow)) * 8;
+        const uint32_t pix = (uint32_t)(img_begin * 196 + 14 * j + col);
+        offp = (col < 14 && co0 + ce < g.ldp) ? (pix * (uint32_t)g.ldp + (uint32_t)(co0 + ce)) * 2u : OOB_OFFSET;
+        offq = (col < 14 && ci0 + ce < g.C) ? (pix * (uint32_t)g.C + (uint32_t)(ci0 + ce)) * 2u : OOB_OFFSET;
+    }
+    const uint32_t incp = (uint32_t)(28 * g.ldp) * 2u, incq = (uint32_t)(28 * g.C) * 2u;
+    int chunks_left = 7 * nimg;
+    auto dma = [&](auto slot_c) {               // next chunk of the stream into ring slot SLOT
+        constexpr int S = decltype(slot_c)::value;
+        const bool on = chunks_left > 0;        // past the split's last image: zero fill, no traffic (the DMA count per wave stays fixed)
+        if constexpr (!(FRHIP_ABL & 8)) {
+            glds16_asm(rp, lds0 + (uint32_t)(S * R14::SLOT + wave * 1024), on ? offp : OOB_OFFSET);
+            glds16_asm(rq, lds0 + (uint32_t)(S * R14::SLOT + R14::QOFF + wave * 1024), on ? offq : OOB_OFFSET);
+        }
+        offp += incp; offq += incq; --chunks_left;        // an out-of-range lane offset stays out of range: tensors are < 2 GiB
+    };
+
+    // ---- fragment addresses (slot 0, row 0 of the chunk; slot and row are instruction immediates).  16-lane group G reads a 4 pixel x 16
+    //      channel block: channels 16 (G & 1) .. of the wave's 32, pixels 8 (G >> 1) + 4 half + (0..3)
+    const int G = lane >> 4, fj = lane & 15, fq = fj >> 2, fp = fj & 3;
+    uint32_t a_ad[2], b_ad[3][2];
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        const int px = 8 * (G >> 1) + 4 * half + fq;
+        const int ca = wco * 4 + 2 * (G & 1) + (fp >> 1), cb = wci * 4 + 2 * (G & 1) + (fp >> 1);
+        a_ad[half] = lds0 + (uint32_t)(px * 128 + ((ca ^ r14_swz(px)) << 4) + 8 * (fp & 1));
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const int pq = px + d - 1;          // -1: the last (zero) pixel slot of the dy tile in front of the window tile
+            b_ad[d][half] = lds0 + (uint32_t)(R14::QOFF + pq * 128 + ((cb ^ r14_swz(pq)) << 4) + 8 * (fp & 1));
+        }
+    }
+    typedef __attribute__((ext_vector_type(8))) short i16x8_t;
+    auto tr8 = [&](auto off_c, const uint32_t (&ad)[2]) {
+        constexpr int OFF = decltype(off_c)::value;
+        typedef __attribute__((address_space(3))) i16x4_t* lds_p;
+        if constexpr (FRHIP_ABL & 4) {
+            bf16x8_t f; asm volatile("" : "=v"(f) : "v"(ad[0]), "v"(ad[1])); return f;
+        } else {
+            i16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)((__attribute__((address_space(3))) char*)(uintptr_t)ad[0] + OFF));
+            i16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)((__attribute__((address_space(3))) char*)(uintptr_t)ad[1] + OFF));
+            return __builtin_bit_cast(bf16x8_t, (i16x8_t)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+        }
+    };
+
+    bf16x8_t af[2];            // dy fragment of row h in af[h & 1]
+    bf16x8_t rf[4][3];         // window fragments: stream row s (= row + 14 * image) in rf[s & 3][dx + 1]
+    auto load_a = [&](auto row_c) {             // row 0..15 (14, 15: rows 0, 1 of the next image)
+        constexpr int R = decltype(row_c)::value % 14;
+        af[decltype(row_c)::value & 1] = tr8(std::integral_constant<int, (R >> 1) * R14::SLOT + (R & 1) * R14::ROWB>{}, a_ad);
+    };
+    auto load_r = [&](auto row_c, auto ph_c) {
+        constexpr int R = decltype(row_c)::value % 14, SL = (decltype(row_c)::value + decltype(ph_c)::value) & 3;
+        typedef std::integral_constant<int, (R >> 1) * R14::SLOT + (R & 1) * R14::ROWB> Off;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) rf[SL][d] = tr8(Off{}, b_ad[d]);
+    };
+    auto row_step = [&](auto h_c, auto ph_c) {
+        constexpr int H = decltype(h_c)::value, PH = decltype(ph_c)::value;
+        // operands of the NEXT row first: they land behind this row's MFMAs
+        load_a(std::integral_constant<int, H + 1>{});
+        load_r(std::integral_constant<int, H + 2>{}, ph_c);
+#pragma unroll
+        for (int dy = -1; dy <= 1; ++dy) {
+            if (H + dy < 0 || H + dy > 13) continue;        // row outside the image: zero padding = no MFMA
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                if constexpr (FRHIP_ABL & 2) { bf16x8_t fa = af[H & 1], fb = rf[(H + dy + PH) & 3][d]; asm volatile("" :: "v"(fa), "v"(fb)); }
+                else acc[(dy + 1) * 3 + d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[H & 1], rf[(H + dy + PH) & 3][d], acc[(dy + 1) * 3 + d], 0, 0, 0);
+            }
+        }
+#if R14_PIN == 1
+        // one transposed read behind each of the first eight MFMAs
+#pragma unroll
+        for (int z = 0; z < 8; ++z) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
+#endif
+    };
+    auto fence = [&](auto n_c) {                // all but the n newest loads of this wave have landed; then everyone's
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(decltype(n_c)::value) : "memory");
+        if constexpr (!(FRHIP_ABL & 1)) __builtin_amdgcn_s_barrier();
+    };
+    auto image = [&](auto ph_c) {
+        typedef std::integral_constant<int, 4> N4; typedef std::integral_constant<int, 6> N6;
+        row_step(std::integral_constant<int, 0>{}, ph_c); row_step(std::integral_constant<int, 1>{}, ph_c);
+        row_step(std::integral_constant<int, 2>{}, ph_c); row_step(std::integral_constant<int, 3>{}, ph_c);
+        fence(N4{});            // rows 4 .. 7 read chunks 2, 3, 4; chunks 0, 1 are consumed
+        dma(std::integral_constant<int, 0>{}); dma(std::integral_constant<int, 1>{});
+        row_step(std::integral_constant<int, 4>{}, ph_c); row_step(std::integral_constant<int, 5>{}, ph_c);
+        row_step(std::integral_constant<int, 6>{}, ph_c); row_step(std::integral_constant<int, 7>{}, ph_c);
+        fence(N4{});            // rows 8 .. 11 read chunks 4, 5, 6
+        dma(std::integral_constant<int, 2>{}); dma(std::integral_constant<int, 3>{});
+        row_step(std::integral_constant<int, 8>{}, ph_c); row_step(std::integral_constant<int, 9>{}, ph_c);
+        row_step(std::integral_constant<int, 10>{}, ph_c); row_step(std::integral_constant<int, 11>{}, ph_c);
+        fence(N6{});            // rows 12, 13 read chunk 6 and chunk 0 of the next image
+        dma(std::integral_constant<int, 4>{}); dma(std::integral_constant<int, 5>{});
+        row_step(std::integral_constant<int, 12>{}, ph_c); row_step(std::integral_constant<int, 13>{}, ph_c);
+        fence(N6{});            // rows 0 .. 3 of the next image read its chunks 0, 1, 2
+        dma(std::integral_constant<int, 6>{});
+    };
+
+    // ---- prologue: the first image's seven chunks; chunks 0, 1, 2 must have landed before row 0 starts
+    dma(std::integral_constant<int, 0>{}); dma(std::integral_constant<int, 1>{}); dma(std::integral_constant<int, 2>{});
+    dma(std::integral_constant<int, 3>{}); dma(std::integral_constant<int, 4>{}); dma(std::integral_constant<int, 5>{});
+    dma(std::integral_constant<int, 6>{});
+    fence(std::integral_constant<int, 8>{});
+    load_a(std::integral_constant<int, 0>{});
+    load_r(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+    load_r(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{});
+    // two images per trip (the fragment ring is back in phase after 28 rows).  An odd count runs one phantom image at the end: its loads are
+    // switched off (zero fill), its MFMAs add zeros -- no second exit from the loop, whose register state would differ from the first
+    for (int im = 0; im < nimg; im += 2) {
+        image(std::integral_constant<int, 0>{});
+        image(std::integral_constant<int, 2>{});
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // zero-fill loads of the ring's tail: nothing may land after the workgroup has left
+
+    // ---- epilogue: the slab layout of tn_taps9_kernel ([co / 4][j][ci][4 floats], k = 9 e + t = 4 j + r).  32 x 32 D layout: register v of
+    //      lane l is row 8 (v >> 2) + 4 (l >> 5) + (v & 3), column l & 31 -- four consecutive output channels per register quad
+    if constexpr (FRHIP_ABL & 16) {
+        if (g.M >= 0) {
+#pragma unroll
+            for (int t = 0; t < 9; ++t) asm volatile("" :: "v"(acc[t]));
+            return;
+        }
+    }
+    float* dst = out + (size_t)slot.split * g.slab_stride;
+    const int ci = ci0 + wci * 32 + (lane & 31);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int q = (co0 + wco * 32 + 8 * i + 4 * (lane >> 5)) >> 2;
+#pragma unroll
+        for (int j = 0; j < 9; ++j) {
+            f32x4_t v;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { const int k = 4 * j + r; v[r] = acc[k % 9][4 * i + k / 9]; }
+            *reinterpret_cast<f32x4_t*>(dst + (((size_t)q * 9 + j) * g.C + ci) * 4) = v;
+        }
+    }
+}
+
 static int g_tn_taps9 = 1;
 // Which tile the nine-tap weight gradients run on.  The weight gradients live on the side stream next to the main stream's
 // forward / data-gradient / BatchNorm kernels, and what counts is what the two streams can do on one CU AT THE SAME TIME:
@@ -725,6 +928,23 @@ static int tn_taps9_launch(const TnGeom& g, const void* p, const void* q, float*
     const int lds = (Cfg::NW == 4 && g_t9_lds_pad > Cfg::LDS) ? g_t9_lds_pad : Cfg::LDS;
     hipLaunchKernelGGL(kern, dim3(co_tiles * ci_tiles * splits), dim3(64 * Cfg::NW), lds, stream, g, p, q, out, co_tiles, ci_tiles);
     return check_launch("igemm_tn(taps9)");
+}
+
+// rows kernel (14 x 14 maps): K split over whole images, one workgroup per CU beside a forward / data-gradient workgroup (the 82-KB request)
+static int g_t9_rows = getenv("FRHIP_T9_ROWS") ? atoi(getenv("FRHIP_T9_ROWS")) : 1;
+static int tn_rows14_launch(const TnGeom& g, const void* p, const void* q, float* out, int splits, hipStream_t stream) {
+    const int co_tiles = g.Kc / 64, ci_tiles = g.C / 64;
+    const int lds = g_t9_lds_pad > R14::LDS ? g_t9_lds_pad : R14::LDS;
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(tn_rows14_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
+            set_error("igemm_tn(rows14): cannot raise dynamic LDS to %d bytes", lds);
+            return FRHIP_ELAUNCH;
+        }
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(tn_rows14_kernel, dim3(co_tiles * ci_tiles * splits), dim3(256), lds, stream, g, p, q, out, co_tiles, ci_tiles);
+    return check_launch("igemm_tn(rows14)");
 }
 
 // Sum of K-split slabs, float4 per thread, no atomics (deterministic).  blockIdx.y = g owns slabs g*per_group ..:
@@ -921,6 +1141,28 @@ static int tn_run(int dtype, const void* p, const void* q, float* out, int n, in
     if (out_elems > 0x7fffffffULL) { set_error("%s: output too large", who); return FRHIP_EINVAL; }
     int rc;
     // The nine-tap kernel covers every 3x3/s1/p1 bf16 layer (g_tn_taps9: 0 off, 1/2 on); wide = 128-co tiles.
+    if (g_t9_rows && g_t9_narrow && !xf_scale && t9_applicable(dtype, w, c, r, s, stride, pad, M, ldp) && h == 14 && w == 14 &&
+        (c % 64) == 0 && (kc % 64) == 0 && ws) {
+        // K split over images: whole rounds of one workgroup per CU; the epilogue (nine store passes of 36 KB per wave) costs about two images
+        const long long tiles = 1LL * (kc / 64) * (c / 64);
+        int best = 1; double best_t = 1e30;
+        for (int sp = 1; sp <= n && sp <= 1024; ++sp) {
+            const long long rounds = (tiles * sp + 255) / 256;
+            const double t = (double)rounds * ((double)((n + sp - 1) / sp) + 2.0);
+            if (t < best_t * 0.98) { best_t = t; best = sp; }
+        }
+        int sp = splits > 0 ? splits : best;
+        if (sp > n) sp = n;
+        const int per = (n + sp - 1) / sp;
+        sp = (n + per - 1) / per;
+        TnGeom gi = g;
+        gi.ksteps = n; gi.ksteps_per_split = per;
+        float* dst = tn_pick_dst(gi, out, sp, out_elems, ws, ws_bytes);
+        if (gi.slab_stride) {
+            rc = tn_rows14_launch(gi, p, q, dst, sp, stream);
+            return rc ? rc : t9_finish(gi, out, sp, out_elems, ws, stream);
+        }
+    }
     if (t9_applicable(dtype, w, c, r, s, stride, pad, M, ldp)) {
         const bool wide = kc > 64 && !g_t9_narrow;
         const int co_t = wide ? 128 : 64;
