@@ -51,9 +51,18 @@ __device__ __forceinline__ u32x4_t make_rsrc_words(const void* p, uint32_t bytes
     const uint64_t a = (uint64_t)(uintptr_t)p;
     return u32x4_t{(uint32_t)a, (uint32_t)(a >> 32) & 0xffffu, bytes, 0x00020000u};
 }
+#ifndef FRHIP_DMA_ASM
+#define FRHIP_DMA_ASM 1      // 0: A/B build -- the same call sites through the builtin (and the compiler's waits)
+#endif
 __device__ __forceinline__ void glds16_asm(u32x4_t rsrc, uint32_t lds_addr, uint32_t voff) {
+#if FRHIP_DMA_ASM
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
                  :: "s"(__builtin_amdgcn_readfirstlane(lds_addr)), "v"(voff), "s"(rsrc) : "memory");
+#else
+    const void* p = reinterpret_cast<const void*>((uintptr_t)rsrc[0] | ((uintptr_t)rsrc[1] << 32));
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(__builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, rsrc[2], 0x00020000),
+                                             (__attribute__((address_space(3))) void*)(uintptr_t)__builtin_amdgcn_readfirstlane(lds_addr), 16, voff, 0, 0, 0);
+#endif
 }
 
 // ---- element <-> float

@@ -168,8 +168,11 @@ __global__ __launch_bounds__(TN_THREADS, 2) void tn_kernel(TnGeom g, const void*
 #pragma unroll
         for (int b = 0; b < NT; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-    const __amdgpu_buffer_rsrc_t rp = make_rsrc(p_ptr, g.p_bytes);
-    const __amdgpu_buffer_rsrc_t rq = make_rsrc(q_ptr, g.q_bytes);
+    // inline-assembly loads (glds16_asm, common.h): the builtin made the compiler wait for the NEXT step's loads (vmcnt(0)) before the
+    // first transposed read of the current step -- load and compute never overlapped
+    const u32x4_t rp = make_rsrc_words(p_ptr, g.p_bytes);
+    const u32x4_t rq = make_rsrc_words(q_ptr, g.q_bytes);
+    const uint32_t lds_base = (uint32_t)(uintptr_t)LDS_ADDR(smem);
 
     // DMA lane roles: piece covers ROWS_PER_PIECE rows; lane -> row sub, physical chunk
     const int sub = lane / Tile::CHUNKS, phys = lane % Tile::CHUNKS;
@@ -195,8 +198,8 @@ __global__ __launch_bounds__(TN_THREADS, 2) void tn_kernel(TnGeom g, const void*
     }
 
     auto stage = [&](int buf, int ks) {
-        char* sp = smem + buf * Tile::STAGE_BYTES;
-        char* sq = sp + Tile::TILE_BYTES;
+        const uint32_t sp = lds_base + (uint32_t)(buf * Tile::STAGE_BYTES);
+        const uint32_t sq = sp + (uint32_t)Tile::TILE_BYTES;
 #pragma unroll
         for (int j = 0; j < Tile::PIECES; ++j) {
             const int piece = wave * Tile::PIECES + j;
@@ -209,8 +212,8 @@ __global__ __launch_bounds__(TN_THREADS, 2) void tn_kernel(TnGeom g, const void*
                 if ((unsigned)hi < (unsigned)g.H && (unsigned)wi < (unsigned)g.W && ci0 + ce < g.C)
                     offq = ((uint32_t)(pixbase[j] + hi * g.W + wi) * (uint32_t)g.C + (uint32_t)(ci0 + ce)) * (uint32_t)sizeof(T);
             }
-            glds16(rp, sp + piece * 1024, offp);
-            glds16(rq, sq + piece * 1024, offq);
+            glds16_asm(rp, sp + (uint32_t)(piece * 1024), offp);
+            glds16_asm(rq, sq + (uint32_t)(piece * 1024), offq);
             // advance this row by one K step (64 pixels)
             int wo = rwo[j] + g.adv_wo, ho = rho[j] + g.adv_ho, nb = g.adv_n;
             if (wo >= g.Wo) { wo -= g.Wo; ++ho; }
@@ -338,8 +341,12 @@ void tn_taps9_kernel(TnGeom g, const void* __restrict__ p_ptr, const void* __res
     if (threadIdx.x < 4 * NST)
         *reinterpret_cast<f32x4_t*>(smem + (threadIdx.x >> 2) * Cfg::STAGE + Cfg::ZERO + (threadIdx.x & 3) * 16) = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-    const __amdgpu_buffer_rsrc_t rp = make_rsrc(p_ptr, g.p_bytes);
-    const __amdgpu_buffer_rsrc_t rq = make_rsrc(q_ptr, g.q_bytes);
+    // operand loads as inline assembly (glds16_asm, common.h): with the builtin the compiler put an s_waitcnt vmcnt(0) in front of the first
+    // transposed read of every K step -- right behind the step's own DMA issue, so the NST-stage pipeline below never had more than the
+    // current step's loads in flight
+    const u32x4_t rp = make_rsrc_words(p_ptr, g.p_bytes);
+    const u32x4_t rq = make_rsrc_words(q_ptr, g.q_bytes);
+    const uint32_t lds_base = (uint32_t)(uintptr_t)LDS_ADDR(smem);
 
     // ---- loader: 1-KiB pieces.  dy: P_RPP rows of P_RB bytes per piece; window: 8 rows of 128 B per piece.
     uint32_t offp[Cfg::P_PIECES], offq[Cfg::QPW_MAX];
@@ -360,16 +367,16 @@ void tn_taps9_kernel(TnGeom g, const void* __restrict__ p_ptr, const void* __res
         offq[j] = (uint32_t)(((ks_begin * TN_KP - g.W - 1 + row) * g.C + ci0 + ce) * 2);   // negative pixel -> out of range
     }
     auto stage = [&](int buf) {
-        char* sp = smem + buf * Cfg::STAGE;
-        char* sq = sp + Cfg::P_BYTES;
+        const uint32_t sp = lds_base + (uint32_t)(buf * Cfg::STAGE);
+        const uint32_t sq = sp + (uint32_t)Cfg::P_BYTES;
 #pragma unroll
         for (int j = 0; j < Cfg::P_PIECES; ++j) {
-            glds16<T9_AUX>(rp, sp + (wave * Cfg::P_PIECES + j) * 1024, okp[j] ? offp[j] : OOB_OFFSET);
+            glds16_asm(rp, sp + (uint32_t)((wave * Cfg::P_PIECES + j) * 1024), okp[j] ? offp[j] : OOB_OFFSET);
             offp[j] += incp;
         }
 #pragma unroll
         for (int j = 0; j < Cfg::QPW_MAX; ++j) {
-            glds16<T9_AUX>(rq, sq + (wave + Cfg::NW * j) * 1024, okq[j] ? offq[j] : OOB_OFFSET);
+            glds16_asm(rq, sq + (uint32_t)((wave + Cfg::NW * j) * 1024), okq[j] ? offq[j] : OOB_OFFSET);
             offq[j] += incq;
         }
     };
