@@ -664,11 +664,12 @@ void tn_taps9_kernel(TnGeom g, const void* __restrict__ p_ptr, const void* __res
 //   * rows above / below the image are MFMAs that are not issued (the image loop is unrolled, the row index is a compile-time constant).
 // Workgroup = 64 co x 64 ci for all nine taps, four waves of 32 x 32 (144 accumulator registers); K split over whole images.
 // LDS: a ring of seven 8-KB slots, slot c = rows 2c, 2c + 1 of the current image (dy tile 4 KB | window tile 4 KB); a slot is refilled
-// with the next image's rows as soon as every wave has consumed it, which leaves a load 8 - 12 row steps (>= 2 500 cycles) to land.
-// Four barriers per image (after rows 3, 7, 11, 13).  16-byte chunks are XOR-swizzled by bit 1 of the pixel slot (x 4) on the source
+// with the next image's rows as soon as every wave has consumed it (one barrier per two rows), which leaves a load ten row steps
+// (~2 900 cycles) to land.  16-byte chunks are XOR-swizzled by bit 1 of the pixel slot (x 4) on the source
 // side: the 4 pixel x 64 byte footprint of one LDS cycle of a transposed read then covers all 64 banks once.
 #ifndef R14_PIN
-#define R14_PIN 0
+#define R14_PIN 0         // 1: one transposed read pinned behind each MFMA (left alone the compiler issues them in bursts in front of a fence): 103 -> 96 us
+                          // stand-alone, but +0.1 ms on the step -- the steadier stream takes more from the co-resident main-stream workgroup
 #endif
 struct R14 {
     static constexpr int SLOT = 8192, QOFF = 4096, NSLOT = 7, LDS = NSLOT * SLOT + 128, ROWB = 2048;
@@ -793,30 +794,27 @@ void tn_rows14_kernel(TnGeom g, const void* __restrict__ p_ptr, const void* __re
         asm volatile("s_waitcnt vmcnt(%0)" :: "n"(decltype(n_c)::value) : "memory");
         if constexpr (!(FRHIP_ABL & 1)) __builtin_amdgcn_s_barrier();
     };
+    auto chunk = [&](auto c_c, auto ph_c) {
+        constexpr int C = decltype(c_c)::value;
+        row_step(std::integral_constant<int, 2 * C>{}, ph_c);
+        row_step(std::integral_constant<int, 2 * C + 1>{}, ph_c);
+        // rows 2C + 2, 2C + 3 read chunk C + 2 (issued ten row steps ago; the four chunks issued after it may still be in flight);
+        // every wave has consumed chunk C: its slot takes the next image's rows (first read ten row steps from now)
+        fence(std::integral_constant<int, 8>{});
+        dma(c_c);
+    };
     auto image = [&](auto ph_c) {
-        typedef std::integral_constant<int, 4> N4; typedef std::integral_constant<int, 6> N6;
-        row_step(std::integral_constant<int, 0>{}, ph_c); row_step(std::integral_constant<int, 1>{}, ph_c);
-        row_step(std::integral_constant<int, 2>{}, ph_c); row_step(std::integral_constant<int, 3>{}, ph_c);
-        fence(N4{});            // rows 4 .. 7 read chunks 2, 3, 4; chunks 0, 1 are consumed
-        dma(std::integral_constant<int, 0>{}); dma(std::integral_constant<int, 1>{});
-        row_step(std::integral_constant<int, 4>{}, ph_c); row_step(std::integral_constant<int, 5>{}, ph_c);
-        row_step(std::integral_constant<int, 6>{}, ph_c); row_step(std::integral_constant<int, 7>{}, ph_c);
-        fence(N4{});            // rows 8 .. 11 read chunks 4, 5, 6
-        dma(std::integral_constant<int, 2>{}); dma(std::integral_constant<int, 3>{});
-        row_step(std::integral_constant<int, 8>{}, ph_c); row_step(std::integral_constant<int, 9>{}, ph_c);
-        row_step(std::integral_constant<int, 10>{}, ph_c); row_step(std::integral_constant<int, 11>{}, ph_c);
-        fence(N6{});            // rows 12, 13 read chunk 6 and chunk 0 of the next image
-        dma(std::integral_constant<int, 4>{}); dma(std::integral_constant<int, 5>{});
-        row_step(std::integral_constant<int, 12>{}, ph_c); row_step(std::integral_constant<int, 13>{}, ph_c);
-        fence(N6{});            // rows 0 .. 3 of the next image read its chunks 0, 1, 2
-        dma(std::integral_constant<int, 6>{});
+        chunk(std::integral_constant<int, 0>{}, ph_c); chunk(std::integral_constant<int, 1>{}, ph_c);
+        chunk(std::integral_constant<int, 2>{}, ph_c); chunk(std::integral_constant<int, 3>{}, ph_c);
+        chunk(std::integral_constant<int, 4>{}, ph_c); chunk(std::integral_constant<int, 5>{}, ph_c);
+        chunk(std::integral_constant<int, 6>{}, ph_c);
     };
 
-    // ---- prologue: the first image's seven chunks; chunks 0, 1, 2 must have landed before row 0 starts
+    // ---- prologue: the first image's seven chunks; chunks 0, 1 must have landed before row 0 starts (rows 0, 1 read rows 1 .. 3)
     dma(std::integral_constant<int, 0>{}); dma(std::integral_constant<int, 1>{}); dma(std::integral_constant<int, 2>{});
     dma(std::integral_constant<int, 3>{}); dma(std::integral_constant<int, 4>{}); dma(std::integral_constant<int, 5>{});
     dma(std::integral_constant<int, 6>{});
-    fence(std::integral_constant<int, 8>{});
+    fence(std::integral_constant<int, 10>{});
     load_a(std::integral_constant<int, 0>{});
     load_r(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
     load_r(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{});
