@@ -674,15 +674,48 @@ void tn_taps9_kernel(TnGeom g, const void* __restrict__ p_ptr, const void* __res
 struct R14 {
     static constexpr int SLOT = 8192, QOFF = 4096, NSLOT = 7, LDS = NSLOT * SLOT + 128, ROWB = 2048;
 };
+// slabs of the previous launch of a chain (count = 0: none): `count` slabs `step` floats apart, writer's layout, to be ADDED to dw[kc4 * 4][9][C]
+struct R14Prev { const float* slabs; float* dw; int count; size_t step; int kc4, C; };
+__device__ __forceinline__ f32x4_t slab_load(const float* p);
 __device__ __forceinline__ int r14_swz(int p) { return ((p >> 1) & 1) << 2; }
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 
 // (256, 2): at most 256 registers per lane, arch + accumulator, so that a forward / data-gradient wave fits the same SIMD
 __global__ __launch_bounds__(256, 2)
 void tn_rows14_kernel(TnGeom g, const void* __restrict__ p_ptr, const void* __restrict__ q_ptr, float* __restrict__ out,
-                      int co_tiles, int ci_tiles) {
+                      int co_tiles, int ci_tiles, R14Prev prev) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = lane_id(), wave = wave_id();
+    // ---- chained launches: the K-split slabs of the PREVIOUS weight gradient of this stream are summed here, 1 / gridDim of them per
+    //      workgroup, before this launch's own work -- instead of a reduce launch between the two.  Inside the training step that launch
+    //      (576 small workgroups, 8 us alone) took 50 - 65 us: the main stream's workgroups keep every CU's register file full and it
+    //      got on only as they retired, while the weight gradients -- one resident workgroup per CU -- waited behind it.
+    if (prev.count > 0) {
+        const uint32_t n4 = (uint32_t)prev.kc4 * 9u * (uint32_t)prev.C;
+        const uint32_t per = (n4 + gridDim.x - 1) / gridDim.x;
+        const uint32_t lo = blockIdx.x * per, hi = min(n4, lo + per);
+        for (uint32_t i = lo + threadIdx.x; i < hi; i += 256) {
+            f32x4_t a0 = f32x4_t{0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
+            int sp = 0;
+            for (; sp + 4 <= prev.count; sp += 4) {         // same order of additions as slab9_final_kernel
+                const f32x4_t v0 = slab_load(prev.slabs + (size_t)(sp + 0) * prev.step + (size_t)i * 4);
+                const f32x4_t v1 = slab_load(prev.slabs + (size_t)(sp + 1) * prev.step + (size_t)i * 4);
+                const f32x4_t v2 = slab_load(prev.slabs + (size_t)(sp + 2) * prev.step + (size_t)i * 4);
+                const f32x4_t v3 = slab_load(prev.slabs + (size_t)(sp + 3) * prev.step + (size_t)i * 4);
+                a0 += v0; a1 += v1; a2 += v2; a3 += v3;
+            }
+            for (; sp < prev.count; ++sp) a0 += slab_load(prev.slabs + (size_t)sp * prev.step + (size_t)i * 4);
+            const f32x4_t sum = (a0 + a1) + (a2 + a3);
+            const uint32_t ci = i % (uint32_t)prev.C, qj = i / (uint32_t)prev.C;
+            const uint32_t j = qj % 9u, q = qj / 9u;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const uint32_t k = 4 * j + r, e = k / 9, t = k - 9 * e;
+                float* o = prev.dw + ((size_t)(4 * q + e) * 9 + t) * prev.C + ci;
+                *o += sum[r];
+            }
+        }
+    }
     const TnSlot slot = tn_slot(co_tiles * ci_tiles);
     const uint32_t lin = (uint32_t)slot.tile;
     const int ci_tile = (int)(lin % (uint32_t)ci_tiles), co_tile = (int)(lin / (uint32_t)ci_tiles);
@@ -937,7 +970,8 @@ static int tn_taps9_launch(const TnGeom& g, const void* p, const void* q, float*
 
 // rows kernel (14 x 14 maps): K split over whole images, one workgroup per CU beside a forward / data-gradient workgroup (the 82-KB request)
 static int g_t9_rows = getenv("FRHIP_T9_ROWS") ? atoi(getenv("FRHIP_T9_ROWS")) : 1;
-static int tn_rows14_launch(const TnGeom& g, const void* p, const void* q, float* out, int splits, hipStream_t stream) {
+static int tn_rows14_launch(const TnGeom& g, const void* p, const void* q, float* out, int splits, hipStream_t stream,
+                            const R14Prev& prev = R14Prev{nullptr, nullptr, 0, 0, 0, 0}) {
     const int co_tiles = g.Kc / 64, ci_tiles = g.C / 64;
     const int lds = g_t9_lds_pad > R14::LDS ? g_t9_lds_pad : R14::LDS;
     static bool attr_done = false;
@@ -948,7 +982,7 @@ static int tn_rows14_launch(const TnGeom& g, const void* p, const void* q, float
         }
         attr_done = true;
     }
-    hipLaunchKernelGGL(tn_rows14_kernel, dim3(co_tiles * ci_tiles * splits), dim3(256), lds, stream, g, p, q, out, co_tiles, ci_tiles);
+    hipLaunchKernelGGL(tn_rows14_kernel, dim3(co_tiles * ci_tiles * splits), dim3(256), lds, stream, g, p, q, out, co_tiles, ci_tiles, prev);
     return check_launch("igemm_tn(rows14)");
 }
 
@@ -1111,6 +1145,26 @@ static bool t9_applicable(int dtype, int w, int c, int r, int s, int stride, int
            1LL * (M + 64 + 2LL * w + 2) * (ldp > c ? ldp : c) * es < 0x7fffffffLL;
 }
 
+static bool r14_applicable(int dtype, int h, int w, int c, int kc, int r, int s, int stride, int pad, long long M, int ldp) {
+    return g_t9_rows && g_t9_narrow && t9_applicable(dtype, w, c, r, s, stride, pad, M, ldp) && h == 14 && w == 14 && (c % 64) == 0 && (kc % 64) == 0;
+}
+// K split of the rows kernel over images: whole rounds of one workgroup per CU; the epilogue (nine store passes of 36 KB per wave) costs
+// about two images.  Sets g.ksteps (= images) / ksteps_per_split and returns the split count.
+static int r14_plan(TnGeom& g, int n, int splits) {
+    const long long tiles = 1LL * (g.Kc / 64) * (g.C / 64);
+    int best = 1; double best_t = 1e30;
+    for (int sp = 1; sp <= n && sp <= 1024; ++sp) {
+        const long long rounds = (tiles * sp + 255) / 256;
+        const double t = (double)rounds * ((double)((n + sp - 1) / sp) + 2.0);
+        if (t < best_t * 0.98) { best_t = t; best = sp; }
+    }
+    int sp = splits > 0 ? splits : best;
+    if (sp > n) sp = n;
+    const int per = (n + sp - 1) / sp;
+    g.ksteps = n; g.ksteps_per_split = per;
+    return (n + per - 1) / per;
+}
+
 static int tn_run(int dtype, const void* p, const void* q, float* out, int n, int h, int w, int c, int kc, int ldp,
                   int r, int s, int stride, int pad, int splits, float* ws, size_t ws_bytes, hipStream_t stream,
                   const char* who, bool overwrite = false, const float* xf_scale = nullptr, const float* xf_shift = nullptr) {
@@ -1146,22 +1200,9 @@ static int tn_run(int dtype, const void* p, const void* q, float* out, int n, in
     if (out_elems > 0x7fffffffULL) { set_error("%s: output too large", who); return FRHIP_EINVAL; }
     int rc;
     // The nine-tap kernel covers every 3x3/s1/p1 bf16 layer (g_tn_taps9: 0 off, 1/2 on); wide = 128-co tiles.
-    if (g_t9_rows && g_t9_narrow && !xf_scale && t9_applicable(dtype, w, c, r, s, stride, pad, M, ldp) && h == 14 && w == 14 &&
-        (c % 64) == 0 && (kc % 64) == 0 && ws) {
-        // K split over images: whole rounds of one workgroup per CU; the epilogue (nine store passes of 36 KB per wave) costs about two images
-        const long long tiles = 1LL * (kc / 64) * (c / 64);
-        int best = 1; double best_t = 1e30;
-        for (int sp = 1; sp <= n && sp <= 1024; ++sp) {
-            const long long rounds = (tiles * sp + 255) / 256;
-            const double t = (double)rounds * ((double)((n + sp - 1) / sp) + 2.0);
-            if (t < best_t * 0.98) { best_t = t; best = sp; }
-        }
-        int sp = splits > 0 ? splits : best;
-        if (sp > n) sp = n;
-        const int per = (n + sp - 1) / sp;
-        sp = (n + per - 1) / per;
+    if (!xf_scale && ws && r14_applicable(dtype, h, w, c, kc, r, s, stride, pad, M, ldp)) {
         TnGeom gi = g;
-        gi.ksteps = n; gi.ksteps_per_split = per;
+        int sp = r14_plan(gi, n, splits);
         float* dst = tn_pick_dst(gi, out, sp, out_elems, ws, ws_bytes);
         if (gi.slab_stride) {
             rc = tn_rows14_launch(gi, p, q, dst, sp, stream);
@@ -1262,6 +1303,48 @@ extern "C" int frhip_conv_wgrad(int dtype, const void* dy, const void* x, float*
     // dw[k][r][s][c] (fp32, caller-zeroed) += sum over output pixels of dy[m][k] * x[pix(m,r,s)][c]
     return tn_run(dtype, dy, x, dw, n, h, w, c, k, k, r, s, stride, pad, splits, workspace, workspace_bytes, stream,
                   "frhip_conv_wgrad");
+}
+
+// ---- chained weight gradients (rows kernel): launch i sums the K-split slabs of launch i - 1 in its prologue ----------------------
+extern "C" int frhip_conv_wgrad_chain_ok(int dtype, int n, int h, int w, int c, int k, int r, int s, int stride, int pad) {
+    return (n >= 2 && frhip::r14_applicable(dtype, h, w, c, k, r, s, stride, pad, 1LL * n * h * w, k)) ? 1 : 0;
+}
+
+extern "C" int frhip_conv_wgrad_chain(int dtype, const void* dy, const void* x, int n, int h, int w, int c, int k,
+                                      float* slabs, size_t slab_bytes, float* prev_dw, const float* prev_slabs, int prev_k, int prev_c,
+                                      int prev_splits, int* splits_out, hipStream_t stream) {
+    if (!frhip_conv_wgrad_chain_ok(dtype, n, h, w, c, k, 3, 3, 1, 1) || !slabs || !splits_out) {
+        set_error("frhip_conv_wgrad_chain: shape not served by the rows kernel (bf16 3x3 stride 1 on 14 x 14 maps, c and k multiples of 64, n >= 2)");
+        return FRHIP_EINVAL;
+    }
+    if (prev_splits > 0 && (!prev_dw || !prev_slabs || prev_k <= 0 || prev_c <= 0 || (prev_k % 4) || prev_slabs == slabs)) {
+        set_error("frhip_conv_wgrad_chain: bad previous-launch descriptor (its slabs must not be this launch's)");
+        return FRHIP_EINVAL;
+    }
+    TnGeom g;
+    g.H = h; g.W = w; g.C = c; g.R = 3; g.S = 3; g.stride = 1; g.pad = 1; g.Ho = h; g.Wo = w;
+    const long long M = 1LL * n * h * w;
+    g.M = (int)M; g.Kc = k; g.ldp = k;
+    g.p_bytes = (uint32_t)(M * k * 2); g.q_bytes = (uint32_t)(M * c * 2);
+    g.d_howo = make_fastdiv((uint32_t)(h * w)); g.d_wo = make_fastdiv((uint32_t)w);
+    g.adv_n = g.adv_ho = g.adv_wo = 0;
+    g.xf_scale = g.xf_shift = nullptr; g.mask_tab = nullptr; g.mask_period = 0;
+    const int sp = r14_plan(g, n, 0);
+    const size_t out_elems = (size_t)k * 9 * c;
+    if (sp < 2 || (size_t)sp * out_elems * sizeof(float) > slab_bytes) {
+        set_error("frhip_conv_wgrad_chain: %d K splits of %zu bytes do not fit the slab buffer", sp, out_elems * sizeof(float));
+        return FRHIP_EINVAL;
+    }
+    g.slab_stride = (int)out_elems;
+    R14Prev prev{prev_slabs, prev_dw, prev_splits > 0 ? prev_splits : 0, (size_t)prev_k * 9 * prev_c, prev_k / 4, prev_c};
+    *splits_out = sp;
+    return tn_rows14_launch(g, dy, x, slabs, sp, stream, prev);
+}
+
+extern "C" int frhip_conv_wgrad_chain_finish(float* dw, float* slabs, int k, int c, int splits, hipStream_t stream) {
+    if (!dw || !slabs || k <= 0 || c <= 0 || (k % 4) || splits <= 0) { set_error("frhip_conv_wgrad_chain_finish: bad descriptor"); return FRHIP_EINVAL; }
+    TnGeom g; g.Kc = k; g.C = c; g.slab_stride = k * 9 * c;
+    return t9_finish(g, dw, splits, (size_t)k * 9 * c, slabs, stream);
 }
 
 extern "C" int frhip_gemm_tn_overwrite(int dtype, const void* p, const void* q, float* out, int m, int kc, int ldp, int c,

@@ -1,6 +1,8 @@
 """Tensor-level wrappers over the C ABI (torch is used for device memory + the current HIP stream only)."""
 import weakref
 
+import ctypes
+
 import torch
 
 from . import _abi
@@ -167,6 +169,42 @@ def conv_wgrad(dy, x, dw, r, s, stride, pad, splits=0):
     check(lib().frhip_conv_wgrad(dt_of(x), _p(dy), _p(x), _p(dw), n, h, wd, c, k, r, s, stride, pad, splits,
                                  _p(ws), ws.numel() * 4, _s()), "frhip_conv_wgrad")
     return dw
+
+
+CHAIN_SLAB_BYTES = 128 << 20
+_CHAIN_SLABS = {}
+
+
+def chain_slabs(device):
+    """two K-split slab buffers per (device, stream) for chained weight gradients: launch i writes one while it sums the other"""
+    key = (torch.device(device).index, _s())
+    bufs = _CHAIN_SLABS.get(key)
+    if bufs is None:
+        bufs = _CHAIN_SLABS[key] = [torch.empty(CHAIN_SLAB_BYTES // 4, dtype=torch.float32, device=device) for _ in range(2)]
+    return bufs
+
+
+def conv_wgrad_chain_ok(dy, x, r, s, stride, pad):
+    n, h, wd, c = x.shape
+    return x.dtype == torch.bfloat16 and bool(lib().frhip_conv_wgrad_chain_ok(dt_of(x), n, h, wd, c, dy.shape[3], r, s, stride, pad))
+
+
+def conv_wgrad_chain(dy, x, dw, slabs, prev=None):
+    """3x3 / stride-1 weight gradient on 14 x 14 maps as one link of a chain (frhip_conv_wgrad_chain): its K-split slabs go to
+    `slabs`, the slabs of the previous link `prev` are added to THAT link's dw in this launch's prologue.  Returns this link's
+    descriptor (dw, slabs, k, c, splits): hand it to the next link or to conv_wgrad_chain_finish."""
+    n, h, wd, c = x.shape
+    k = dy.shape[3]
+    sp = ctypes.c_int(0)
+    pdw, pslabs, pk, pc, psp = prev if prev is not None else (None, None, 0, 0, 0)
+    check(lib().frhip_conv_wgrad_chain(dt_of(x), _p(dy), _p(x), n, h, wd, c, k, _p(slabs), slabs.numel() * 4, _p(pdw), _p(pslabs), pk, pc, psp,
+                                       ctypes.byref(sp), _s()), "frhip_conv_wgrad_chain")
+    return (dw, slabs, k, c, sp.value)
+
+
+def conv_wgrad_chain_finish(link):
+    dw, slabs, k, c, sp = link
+    check(lib().frhip_conv_wgrad_chain_finish(_p(dw), _p(slabs), k, c, sp, _s()), "frhip_conv_wgrad_chain_finish")
 
 
 def conv_wgrad_bnrelu(dy, x, st, dw, r, s, stride, pad, splits=0):

@@ -12,6 +12,13 @@ import torch.nn as nn
 from frhip import ops
 
 _OVERLAP_WGRAD = os.environ.get("FRHIP_OVERLAP_WGRAD", "1") == "1"
+# consecutive 3x3 weight gradients on 14 x 14 maps as a chain: each launch sums its predecessor's K-split slabs in its prologue (no reduce
+# launch between them; ops.conv_wgrad_chain).  0 (default): every weight gradient followed by its own reduce launch.  Measured, ResNet50 step,
+# one box, alternating: 23.71 ms without / 23.85 with (and 23.85 / 24.24 with the hand-over behind the data-gradient, FRHIP_WGRAD_LATE_MAXC=256).
+# The reduce launch (8 us alone, 50 - 65 us beside the main stream, which keeps the CUs' register files full) delays the next weight
+# gradient so that it runs beside the HBM-bound BatchNorm-backward pass instead of beside the whole data-gradient: the chain removes 27
+# launches and 1.4 ms of side-queue time and the main stream's convolutions slow down by more (in-step conv launch 145 -> 154 us).
+_WGRAD_CHAIN = os.environ.get("FRHIP_WGRAD_CHAIN", "0") == "1"
 _STEM_FUSED_REDUCE = os.environ.get("FRHIP_STEM_FUSED_REDUCE", "1") == "1"     # 0: the stem's own recompute reduction pass
 # bn1-apply + ReLU folded into conv2's operand path (forward and weight gradient; the activated tensor is never written).
 # Built, bit-identical to the separate pass, and OFF by default: measured on the ResNet50 step (B = 512, same box, two A/B
@@ -272,6 +279,7 @@ class BackwardCtx:
         self.reduced_from = self.flat.numel()          # arena[reduced_from:] has been handed to RCCL
         self.works = []
         self.before_join = []                          # deferred gradient work (e.g. the batched position-bias backward)
+        self._chain, self._chain_flip = None, 0        # pending link of the chained 14 x 14 weight gradients (ops.conv_wgrad_chain)
 
     def G(self, p):
         return self.grads[p]
@@ -293,13 +301,34 @@ class BackwardCtx:
             fn = lambda: ops.conv_wgrad(dy, ops.bn_apply(x, bnrelu, relu=True), gview, r, s, stride, pad)      # noqa: E731
         elif bnrelu is not None:
             fn = lambda: ops.conv_wgrad_bnrelu(dy, x, bnrelu, gview, r, s, stride, pad)       # noqa: E731
+        elif _WGRAD_CHAIN and ops.conv_wgrad_chain_ok(dy, x, r, s, stride, pad):
+            fn = lambda: self._chain_link(dy, x, gview)                                       # noqa: E731
         else:
             fn = lambda: ops.conv_wgrad(dy, x, gview, r, s, stride, pad)                      # noqa: E731
         self.on_side(fn, dy, x, gview, bnrelu)
 
+    def _chain_link(self, dy, x, gview):
+        """one link of the chain of 14 x 14 weight gradients (ops.conv_wgrad_chain): the previous link's K-split slabs are summed in this
+        launch's prologue; runs on the weight-gradient stream"""
+        bufs = ops.chain_slabs(x.device)
+        self._chain = ops.conv_wgrad_chain(dy, x, gview, bufs[self._chain_flip], self._chain)
+        self._chain_flip ^= 1
+
+    def flush_chain(self):
+        """the last link's slabs, with the ordinary reduce launches (on the weight-gradient stream, before anyone reads the gradients)"""
+        if self._chain is None:
+            return
+        link, self._chain = self._chain, None
+        if self.side is None:
+            ops.conv_wgrad_chain_finish(link)
+        else:
+            with torch.cuda.stream(self.side):
+                ops.conv_wgrad_chain_finish(link)
+
     def _reduce(self, lo, hi):
         if hi <= lo:
             return
+        self.flush_chain()                              # the slice must be final: the last chained weight gradient still owes its reduce
         chunk = self.flat[lo:hi]
         # RCCL averages in the collective; other backends (gloo in tests) sum and join() scales
         op = dist.ReduceOp.AVG if dist.get_backend() == "nccl" else dist.ReduceOp.SUM
@@ -334,6 +363,7 @@ class BackwardCtx:
         for fn in self.before_join:
             fn()
         self.before_join = []
+        self.flush_chain()
         if self.allreduce:
             self._reduce(0, self.reduced_from)
             self.reduced_from = 0

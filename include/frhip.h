@@ -120,6 +120,19 @@ int frhip_conv_dgrad_fused_rs(int dtype, const void* dy, const void* wt, void* d
 int frhip_conv_wgrad(int dtype, const void* dy, const void* x, float* dw, int n, int h, int w, int c,
                      int k, int r, int s, int stride, int pad, int splits, float* workspace, size_t workspace_bytes,
                      frhip_stream_t stream);
+/* Chained weight gradients of 3x3 / stride-1 bf16 convolutions on 14 x 14 maps (the rows kernel): launch i adds the K-split slabs of
+ * launch i - 1 to THAT launch's dw in its own prologue, so no reduce launch sits between two weight gradients of a stream (inside the
+ * training step the separate reduce -- 8 us alone -- took 50 - 65 us: it got onto the CUs only as the other stream's workgroups retired).
+ * frhip_conv_wgrad_chain_ok: 1 when the shape is served.  frhip_conv_wgrad_chain writes this launch's slabs to `slabs` (>= *splits_out *
+ * k*9*c floats; must differ from prev_slabs), stores the split count in *splits_out (host memory) and does NOT touch this launch's dw:
+ * pass (dw, slabs, k, c, *splits_out) as the prev_* arguments of the next launch on the same stream, or to
+ * frhip_conv_wgrad_chain_finish, which adds them with the ordinary reduce kernels.  prev_splits = 0: nothing to add.
+ * Same sums in the same order as frhip_conv_wgrad on these shapes (bit-identical dw). */
+int frhip_conv_wgrad_chain_ok(int dtype, int n, int h, int w, int c, int k, int r, int s, int stride, int pad);
+int frhip_conv_wgrad_chain(int dtype, const void* dy, const void* x, int n, int h, int w, int c, int k, float* slabs,
+                           size_t slab_bytes, float* prev_dw, const float* prev_slabs, int prev_k, int prev_c, int prev_splits,
+                           int* splits_out, frhip_stream_t stream);
+int frhip_conv_wgrad_chain_finish(float* dw, float* slabs, int k, int c, int splits, frhip_stream_t stream);
 /* nn.Linear forward with its epilogue fused (nets/SwinV2.py:16-32 Mlp, :150-176 qkv / proj): out[m][n] = a[m][k] . w[n][k] +
  * bias[n] (bias may be NULL), stored in `dtype`; act_out (may be NULL) = gelu(out), exact erf form, of the stored value;
  * stats_partial (may be NULL): per-tile BatchNorm partial sums of `out`, rows = frhip_conv_stat_rows(dtype, m, n, 1,1,k,1,1,1,0) */

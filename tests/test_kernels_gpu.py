@@ -742,3 +742,46 @@ def test_dgrad_carries_batchnorm_backward_sums_under_stochastic_depth(case):
         scale = float(np.abs(host[i]).max())
         np.testing.assert_allclose(want[i], host[i], rtol=2e-3, atol=2e-3 * scale, err_msg="separate pass vs float64, sum %d" % i)
         np.testing.assert_allclose(got[i], host[i], rtol=2e-3, atol=2e-3 * scale, err_msg="fused epilogue vs float64, sum %d" % i)
+
+
+@pytest.mark.parametrize("case", [(1, 64, 64), (2, 64, 128), (3, 128, 64), (8, 256, 256), (37, 128, 192), (64, 256, 512)])
+def test_rows_weight_gradient_of_14x14_maps_matches_fp32(case):
+    """tn_rows14_kernel (one image row per K step, vertical taps reuse fragments in registers): 3x3 / stride-1 weight gradient of
+    nn.Conv2d on 14 x 14 maps (/root/reference/nets/resnet.py:23-46, the 256-channel stage) against fp32 autograd arithmetic on the
+    same bf16-rounded operands -- odd image counts (the two-image loop runs a phantom image), one image per K split, rectangular c / k."""
+    ops = _ops()
+    n, c, k = case
+    x = q(rnd(901 + n, (n, 14, 14, c)), torch.bfloat16)
+    dy = q(rnd(902 + n, (n, 14, 14, k)), torch.bfloat16)
+    dw = torch.zeros(k, 3, 3, c, device="cuda")
+    ops.conv_wgrad(dy.bfloat16().cuda(), x.bfloat16().cuda(), dw, 3, 3, 1, 1)
+    ref = torch.nn.grad.conv2d_weight(x.permute(0, 3, 1, 2).double(), (k, c, 3, 3), dy.permute(0, 3, 1, 2).double(), padding=1).permute(0, 2, 3, 1)
+    assert float((dw.cpu().double() - ref).abs().max()) <= 3e-6 * float(ref.abs().max())
+    ops.conv_wgrad(dy.bfloat16().cuda(), x.bfloat16().cuda(), dw, 3, 3, 1, 1)            # accumulates
+    assert float((dw.cpu().double() - 2 * ref).abs().max()) <= 6e-6 * float(ref.abs().max())
+
+
+def test_chained_weight_gradients_equal_the_unchained_ones_bit_for_bit():
+    """frhip_conv_wgrad_chain: every link adds its predecessor's K-split slabs in its prologue, the last link is closed by
+    frhip_conv_wgrad_chain_finish -- the same sums in the same order as frhip_conv_wgrad, on a chain that changes shape from link to link
+    and accumulates into non-zero gradients."""
+    ops = _ops()
+    shapes = [(24, 256, 256), (24, 256, 512), (24, 64, 64), (5, 128, 64), (24, 256, 256)]
+    bufs = ops.chain_slabs(torch.device("cuda", 0))
+    link, want, got = None, [], []
+    for i, (n, c, k) in enumerate(shapes):
+        x = rnd(911 + i, (n, 14, 14, c)).bfloat16().cuda()
+        dy = rnd(921 + i, (n, 14, 14, k)).bfloat16().cuda()
+        assert ops.conv_wgrad_chain_ok(dy, x, 3, 3, 1, 1)
+        base = rnd(931 + i, (k, 3, 3, c)).cuda()
+        want.append(ops.conv_wgrad(dy, x, base.clone(), 3, 3, 1, 1))
+        got.append(base.clone())
+        link = ops.conv_wgrad_chain(dy, x, got[-1], bufs[i & 1], link)
+        if i:
+            assert torch.equal(got[i - 1], want[i - 1])                  # closed by this launch's prologue
+        assert torch.equal(got[i], base)                                 # this link's own gradient: untouched until the next link / finish
+    ops.conv_wgrad_chain_finish(link)
+    assert torch.equal(got[-1], want[-1])
+    x = rnd(1, (4, 28, 28, 64)).bfloat16().cuda()
+    assert not ops.conv_wgrad_chain_ok(rnd(2, (4, 28, 28, 64)).bfloat16().cuda(), x, 3, 3, 1, 1)
+    assert not ops.conv_wgrad_chain_ok(rnd(2, (4, 14, 14, 64)).bfloat16().cuda()[:, :7, :7], x[:, :14, :14], 3, 3, 2, 1)
