@@ -491,6 +491,25 @@ extern "C" int frhip_bn_eval_affine(int c, const float* gamma, const float* beta
     return check_launch("frhip_bn_eval_affine");
 }
 
+// Stand-in BatchNorm state for the stem's backward reduction over the POOLED map (nets/_backbone.py stem_reduction_operands):
+// mean := beta, invstd := gamma / (gamma^2 + (k beta)^2 + 1e-20) (a regularised 1 / gamma), scale := 1, shift := 0 -- one launch
+// instead of eight one-workgroup torch kernels on the main stream in front of the stem's backward pass.  Separately rounded operations
+// (no contraction): the same values as the torch expression it replaces.
+__global__ void bn_standin_kernel(int c, const float* __restrict__ gamma, const float* __restrict__ beta, float k,
+                                  float* __restrict__ mean, float* __restrict__ invstd, float* __restrict__ scale, float* __restrict__ shift) {
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= c) return;
+    const float g = gamma[i], b = beta[i], kb = __fmul_rn(k, b);
+    const float den = __fadd_rn(__fadd_rn(__fmul_rn(g, g), __fmul_rn(kb, kb)), 1e-20f);
+    mean[i] = b; invstd[i] = __fdiv_rn(g, den); scale[i] = 1.f; shift[i] = 0.f;
+}
+extern "C" int frhip_bn_standin_state(int c, const float* gamma, const float* beta, float k, float* mean, float* invstd,
+                                      float* scale, float* shift, hipStream_t stream) {
+    if (c <= 0 || !gamma || !beta || !mean || !invstd || !scale || !shift) { frhip::set_error("frhip_bn_standin_state: bad arguments"); return FRHIP_EINVAL; }
+    hipLaunchKernelGGL(bn_standin_kernel, dim3((c + 63) / 64), dim3(64), 0, stream, c, gamma, beta, k, mean, invstd, scale, shift);
+    return check_launch("frhip_bn_standin_state");
+}
+
 extern "C" int frhip_bn_bwd_finalize(const float* partial, int nparts, float* scratch, int c, float count,
                                      const float* gamma, const float* mean, const float* invstd, float* dgamma,
                                      float* dbeta, float* ca, float* cb, float* cc, hipStream_t stream) {

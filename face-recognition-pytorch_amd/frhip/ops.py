@@ -309,6 +309,18 @@ class BNState:
     __slots__ = ("mean", "invstd", "scale", "shift", "count")
 
 
+def bn_standin_state(gamma, beta, k, count):
+    """BNState(mean = beta, invstd = gamma / (gamma^2 + (k beta)^2 + 1e-20), scale = 1, shift = 0): frhip_bn_standin_state, one launch"""
+    c = gamma.numel()
+    st = BNState()
+    buf = torch.empty((4, c), dtype=torch.float32, device=gamma.device)
+    st.mean, st.invstd, st.scale, st.shift = buf[0], buf[1], buf[2], buf[3]
+    st.count = count
+    check(lib().frhip_bn_standin_state(c, _p(gamma), _p(beta), float(k), _p(st.mean), _p(st.invstd), _p(st.scale), _p(st.shift), _s()),
+          "frhip_bn_standin_state")
+    return st
+
+
 def bn_finalize(part, count, gamma, beta, running_mean, running_var, momentum=0.1, eps=1e-5, scratch=None):
     c = gamma.numel()
     dev = gamma.device

@@ -488,13 +488,8 @@ def stem_reduction_operands(net, sv):
     noise, the quotient would amplify rounding error without bound; it goes to zero instead."""
     if getattr(sv, "col", 0) is not None or getattr(sv, "p0", None) is None or not _STEM_FUSED_REDUCE:
         return None
-    gamma, beta = net.bn1.weight.data, net.bn1.bias.data
     k = 2.0 ** -7 if sv.p0.dtype == torch.bfloat16 else 2.0 ** -20
-    st = ops.BNState()
-    st.mean = beta.contiguous()
-    st.invstd = (gamma / (gamma * gamma + (k * beta) ** 2 + 1e-20)).contiguous()
-    st.scale, st.shift, st.count = torch.ones_like(gamma), torch.zeros_like(gamma), sv.st0.count
-    return sv.p0, st, True
+    return sv.p0, ops.bn_standin_state(net.bn1.weight.data, net.bn1.bias.data, k, sv.st0.count), True
 
 
 def stem_backward(net, sv, dout, bc, part=None):

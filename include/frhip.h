@@ -170,6 +170,10 @@ int frhip_bn_finalize(const float* partial, int nparts, float* scratch, int c, f
                       frhip_stream_t stream);
 int frhip_bn_eval_affine(int c, const float* gamma, const float* beta, const float* running_mean,
                          const float* running_var, float eps, float* scale, float* shift, frhip_stream_t stream);
+/* stand-in BatchNorm state with which the generic BatchNorm-backward reduction over the stem's POOLED map (bn1 -> relu -> maxpool,
+ * nets/resnet.py:232-235) yields the stem's reduction: mean = beta, invstd = gamma / (gamma^2 + (k beta)^2 + 1e-20), scale = 1, shift = 0 */
+int frhip_bn_standin_state(int c, const float* gamma, const float* beta, float k, float* mean, float* invstd, float* scale,
+                           float* shift, frhip_stream_t stream);
 /* out = act(y*scale+shift [+ res | + res*res_scale+res_shift]);  BasicBlock tail: nets/resnet.py:92, :96-101 */
 int frhip_bn_apply(int dtype, const void* y, const float* scale, const float* shift, const void* res,
                    const float* res_scale, const float* res_shift, int relu, void* out, int rows, int c,

@@ -785,3 +785,18 @@ def test_chained_weight_gradients_equal_the_unchained_ones_bit_for_bit():
     x = rnd(1, (4, 28, 28, 64)).bfloat16().cuda()
     assert not ops.conv_wgrad_chain_ok(rnd(2, (4, 28, 28, 64)).bfloat16().cuda(), x, 3, 3, 1, 1)
     assert not ops.conv_wgrad_chain_ok(rnd(2, (4, 14, 14, 64)).bfloat16().cuda()[:, :7, :7], x[:, :14, :14], 3, 3, 2, 1)
+
+
+def test_standin_batchnorm_state_of_the_stem_equals_the_torch_expression():
+    """frhip_bn_standin_state (one launch in front of the stem's backward pass, nets/_backbone.py stem_reduction_operands): mean = beta,
+    invstd = gamma / (gamma^2 + (k beta)^2 + 1e-20), scale = 1, shift = 0 -- the bits of the eight torch kernels it replaces, dead and
+    near-dead channels included."""
+    ops = _ops()
+    gamma = rnd(941, (64,)).cuda()
+    beta = rnd(942, (64,)).cuda()
+    gamma[3], gamma[7], beta[7], gamma[11] = 0.0, 1e-12, 0.0, -2e-9
+    for k in (2.0 ** -7, 2.0 ** -20):
+        st = ops.bn_standin_state(gamma, beta, k, 1234.0)
+        assert torch.equal(st.mean, beta) and st.count == 1234.0
+        assert torch.equal(st.invstd, gamma / (gamma * gamma + (k * beta) ** 2 + 1e-20))
+        assert torch.equal(st.scale, torch.ones_like(gamma)) and torch.equal(st.shift, torch.zeros_like(gamma))
