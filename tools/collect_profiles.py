@@ -37,7 +37,8 @@ have_pmc = any(os.path.exists(os.path.join(F, "pmc_%s.txt" % w)) for w in ("fwd"
 with open(os.path.join(P, TAG + "_pmc_mfma_util.txt") if have_pmc else os.devnull, "w") as out:       # QUICK=1 runs keep the committed counters
     out.write("# rocprofv3 --pmc <group> --kernel-trace -- python3 tools/pmc_one.py fwd|dgrad|wgrad 14 256 256   (B = 512, 256-channel 14x14 layer, bf16)\n"
               "# groups: tools/pmc_run.sh.  MFMA utilisation = SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CU_CYCLES / 4 (four SIMDs per CU).\n"
-              "# wgrad = the 4-wave co-resident tile the step uses; wgrad8 = the stand-alone-fastest 8-wave tile (FRHIP_T9_NARROW=0).\n")
+              "# wgrad = the 4-wave co-resident kernel the step uses (14 x 14: tn_rows14_kernel, 32x32x16 MFMAs of which 14 of 16 K slots carry pixels);\n"
+              "# wgrad8 = the 8-wave pixel-stream tile (FRHIP_T9_NARROW=0; the stand-alone-fastest choice until round 4).\n")
     for what in ("fwd", "dgrad", "wgrad", "wgrad8"):
         f = os.path.join(F, "pmc_%s.txt" % what)
         if not os.path.exists(f):
@@ -51,7 +52,7 @@ with open(os.path.join(P, TAG + "_pmc_mfma_util.txt") if have_pmc else os.devnul
                 k, v = line.split()
                 vals[cur][k] = float(v)
         for k, v in vals.items():
-            if ("halo_kernel" in k or "halo_wide_kernel" in k or "taps9" in k) and v.get("SQ_BUSY_CU_CYCLES"):
+            if ("halo_kernel" in k or "halo_wide_kernel" in k or "taps9" in k or "rows14" in k) and v.get("SQ_BUSY_CU_CYCLES"):
                 out.write("\n[%s] %s\n" % (what, k[:110]))
                 out.write("  MFMA utilisation            %.3f\n" % (v["SQ_VALU_MFMA_BUSY_CYCLES"] / v["SQ_BUSY_CU_CYCLES"] / 4))
                 wc = v["SQ_WAVE_CYCLES"]
