@@ -78,6 +78,11 @@ def test_rccl_branches_equal_the_gloo_route_in_a_one_rank_group():
                 assert np.array_equal(a[k], b[k]), k
             else:
                 # identity collectives: what remains is the run-to-run order of the fp32 atomics some weight-gradient kernels
-                # accumulate with (measured 1.6e-7 absolute on conv1.weight after two steps); a wrong collective (SUM for AVG, a
-                # missing x world_size, a stale reduce-scatter slice) is an O(1) error
-                np.testing.assert_allclose(a[k], b[k], rtol=1e-4, atol=2e-6, err_msg=k)
+                # accumulate with (measured 1.6e-7 absolute on conv1.weight after two steps) -- and, rarely, what such a difference does
+                # when it decides a ReLU / max-pool arg-max in the second step (seen once: ONE of conv1.weight's 1 728 gradient elements
+                # off by 2.3e-6, 1.5e-3 of the tensor's largest).  A wrong collective (SUM for AVG, a missing x world_size, a stale
+                # reduce-scatter slice) is an O(1) error in every element: so all but 1 % of the elements to round-off, all to 2 %
+                x, y = np.asarray(a[k], np.float64), np.asarray(b[k], np.float64)
+                off = np.abs(x - y) > 2e-6 + 1e-4 * np.abs(y)
+                assert off.mean() <= 0.01, (k, float(off.mean()))
+                assert np.abs(x - y).max() <= 2e-2 * max(np.abs(y).max(), 1e-12), (k, float(np.abs(x - y).max()))
