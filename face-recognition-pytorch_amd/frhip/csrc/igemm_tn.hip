@@ -249,7 +249,10 @@ __global__ __launch_bounds__(TN_THREADS, 2) void tn_kernel(TnGeom g, const void*
         for (int ks = ks_begin; ks < ks_end - 1; ++ks) {
             stage(cur ^ 1, ks + 1);
             compute(cur);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // lgkmcnt(0): this wave's LDS reads of stage `cur` have RETURNED before the barrier behind which that stage is overwritten.  The
+            // compiler no longer orders LDS reads against the (inline-assembly) loads; in the fp32 mode, whose K step is hundreds of 4-byte LDS
+            // reads, a read still queued when the next load landed showed as 10 x the run-to-run spread in the early layers' gradients
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             cur ^= 1;
         }
@@ -577,9 +580,10 @@ void tn_taps9_kernel(TnGeom g, const void* __restrict__ p_ptr, const void* __res
             compute(buf_c);
             if (it + 1 < nks) {
                 // the next stage (it + 1) must have landed; younger stages issued so far: it + 2 .. min(it + NST - 1, nks - 1)
-                if (NST >= 4 && it + 3 < nks) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * Cfg::DMA_PER_STAGE) : "memory");
-                else if (NST >= 3 && it + 2 < nks) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(Cfg::DMA_PER_STAGE) : "memory");
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                // lgkmcnt(0): this wave's reads of the stage refilled behind the barrier have returned (see the per-tap kernel)
+                if (NST >= 4 && it + 3 < nks) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(2 * Cfg::DMA_PER_STAGE) : "memory");
+                else if (NST >= 3 && it + 2 < nks) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(Cfg::DMA_PER_STAGE) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
                 xform_stage((BUF + 1) % NST, ks_begin + it + 1);
                 if constexpr (!(FRHIP_ABL & 1)) __builtin_amdgcn_s_barrier();
             }
@@ -824,7 +828,8 @@ void tn_rows14_kernel(TnGeom g, const void* __restrict__ p_ptr, const void* __re
 #endif
     };
     auto fence = [&](auto n_c) {                // all but the n newest loads of this wave have landed; then everyone's
-        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(decltype(n_c)::value) : "memory");
+        // lgkmcnt(0): this wave's reads of the slot refilled behind the barrier have returned, not merely been issued
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(decltype(n_c)::value) : "memory");
         if constexpr (!(FRHIP_ABL & 1)) __builtin_amdgcn_s_barrier();
     };
     auto chunk = [&](auto c_c, auto ph_c) {
