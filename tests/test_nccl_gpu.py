@@ -77,12 +77,13 @@ def test_rccl_branches_equal_the_gloo_route_in_a_one_rank_group():
             if k.startswith("index"):
                 assert np.array_equal(a[k], b[k]), k
             else:
-                # identity collectives: what remains is the run-to-run order of the fp32 atomics some weight-gradient kernels
-                # accumulate with (measured 1.6e-7 absolute on conv1.weight after two steps) -- and, rarely, what such a difference does
-                # when it decides a ReLU / max-pool arg-max in the second step (seen once: ONE of conv1.weight's 1 728 gradient elements
-                # off by 2.3e-6, 1.5e-3 of the tensor's largest).  A wrong collective (SUM for AVG, a missing x world_size, a stale
-                # reduce-scatter slice) is an O(1) error in every element: so all but 1 % of the elements to round-off, all to 2 %
+                # identity collectives: what remains is the run-to-run order of the fp32 atomics some weight-gradient kernels accumulate
+                # with, and what that does to a batch the net has memorised by the second step (loss 2.7e-3): conv1.weight's gradient is a
+                # difference of large Gram-matrix terms, and two runs of the SAME backend differ by 1.5e-6 ... 3.3e-6 on it (max 6e-3), with
+                # anything from 0.2 % to 35 % of its elements beyond 2e-6 (tools/noise_probe.py; measured 1.6e-7 in round 3, before the
+                # weight-gradient kernels got faster).  A wrong collective (SUM for AVG, a missing x world_size, a stale reduce-scatter
+                # slice) is an O(1) error in every element of every tensor: bound the tensor's relative L2 distance and its largest deviation
                 x, y = np.asarray(a[k], np.float64), np.asarray(b[k], np.float64)
-                off = np.abs(x - y) > 2e-6 + 1e-4 * np.abs(y)
-                assert off.mean() <= 0.01, (k, float(off.mean()))
-                assert np.abs(x - y).max() <= 2e-2 * max(np.abs(y).max(), 1e-12), (k, float(np.abs(x - y).max()))
+                scale = max(float(np.abs(y).max()), 1e-12)
+                assert float(np.linalg.norm(x - y)) <= 1e-2 * max(float(np.linalg.norm(y)), 1e-12), (k, float(np.linalg.norm(x - y)), float(np.linalg.norm(y)))
+                assert float(np.abs(x - y).max()) <= 2e-2 * scale, (k, float(np.abs(x - y).max()), scale)
