@@ -249,9 +249,9 @@ __global__ __launch_bounds__(TN_THREADS, 2) void tn_kernel(TnGeom g, const void*
         for (int ks = ks_begin; ks < ks_end - 1; ++ks) {
             stage(cur ^ 1, ks + 1);
             compute(cur);
-            // lgkmcnt(0): this wave's LDS reads of stage `cur` have RETURNED before the barrier behind which that stage is overwritten.  The
-            // compiler no longer orders LDS reads against the (inline-assembly) loads; in the fp32 mode, whose K step is hundreds of 4-byte LDS
-            // reads, a read still queued when the next load landed showed as 10 x the run-to-run spread in the early layers' gradients
+            // lgkmcnt(0): this wave's LDS reads of stage `cur` have RETURNED before the barrier behind which that stage is overwritten.  With
+            // the builtin the compiler placed this wait itself; it does not know that the inline-assembly loads write LDS, so the source has
+            // to say it (the fp32 mode's K step is hundreds of 4-byte LDS reads: a deep queue for the next load to overtake)
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             cur ^= 1;

@@ -78,10 +78,10 @@ def test_rccl_branches_equal_the_gloo_route_in_a_one_rank_group():
                 assert np.array_equal(a[k], b[k]), k
             else:
                 # identity collectives: what remains is the run-to-run order of the fp32 atomics some weight-gradient kernels accumulate
-                # with, and what that does to a batch the net has memorised by the second step (loss 2.7e-3): conv1.weight's gradient is a
-                # difference of large Gram-matrix terms, and two runs of the SAME backend differ by 1.5e-6 ... 3.3e-6 on it (max 6e-3), with
-                # anything from 0.2 % to 35 % of its elements beyond 2e-6 (tools/noise_probe.py; measured 1.6e-7 in round 3, before the
-                # weight-gradient kernels got faster).  A wrong collective (SUM for AVG, a missing x world_size, a stale reduce-scatter
+                # with, and what that does to a batch the net has memorised by the second step (loss 2.7e-3): two runs of the SAME backend
+                # differ by 1.5e-6 ... 3.3e-6 on conv1.weight's gradient (max 6e-3), with anything from 0.2 % to 35 % of its elements beyond
+                # 2e-6 -- the spread is bimodal, one or two runs in eight land on an alternative ReLU / arg-max outcome (tools/noise_probe.py).
+                # A wrong collective (SUM for AVG, a missing x world_size, a stale reduce-scatter
                 # slice) is an O(1) error in every element of every tensor: bound the tensor's relative L2 distance and its largest deviation
                 x, y = np.asarray(a[k], np.float64), np.asarray(b[k], np.float64)
                 scale = max(float(np.abs(y).max()), 1e-12)

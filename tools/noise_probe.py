@@ -32,12 +32,14 @@ out = {k: p.grad.float().cpu().numpy() for k, p in enc.named_parameters() if k i
 np.savez(sys.argv[1], **out)
 ''' % (ROOT, ROOT)
 
+N = int(os.environ.get("RUNS", "3"))
 with tempfile.TemporaryDirectory() as td:
     files = []
-    for i in range(3):
+    for i in range(N):
         f = os.path.join(td, "r%d.npz" % i)
         subprocess.check_call([sys.executable, "-c", CHILD, f], env=dict(os.environ))
         files.append(dict(np.load(f)))
     for k in files[0]:
-        d = max(np.abs(files[0][k] - files[j][k]).max() for j in (1, 2))
-        print("%-24s max|diff| %.3e   max|g| %.3e   rel %.2e   (FRHIP_LIB_PATH=%s)" % (k, d, np.abs(files[0][k]).max(), d / np.abs(files[0][k]).max(), os.environ.get("FRHIP_LIB_PATH", "-")))
+        d = [np.abs(files[0][k] - files[j][k]).max() / np.abs(files[0][k]).max() for j in range(1, N)]
+        print("%-24s max|g| %.3e   rel. distance of runs 1.. to run 0: %s   (FRHIP_LIB_PATH=%s)" % (
+            k, np.abs(files[0][k]).max(), " ".join("%.1e" % v for v in d), os.environ.get("FRHIP_LIB_PATH", "-")))
