@@ -1291,6 +1291,138 @@ static int tn_run(int dtype, const void* p, const void* q, float* out, int n, in
     return rc ? rc : tn_finish(g, out, splits, out_elems, ws, stream);
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// Head: gradient of the class centres with the normalise-backward fused (nets/PartialFC.py:464-484 autograd of F.normalize(weight) and
+// F.linear): d_w[c][:] = (g[c][:] - what[c][:] <g[c], what[c]>) * out_scale / ||w_c||, g = dT^T E (contraction over the n samples).
+// The per-tap kernel + frhip_l2norm_bwd wrote g (250 MB at 122 000 classes) and read it back with what: 163 + 104 us on the main stream in
+// front of the backbone's backward pass.  Here a workgroup owns 64 classes x all 512 dimensions (4 waves x (64 x 128), 128 accumulator
+// registers), so every class row is complete in one workgroup: g never leaves the chip.  K step = 32 samples; a stage = nine 4-KB blocks
+// [32 samples][128 B] (block 0: the 64 classes of dT, blocks 1..8: 64 dimensions of E each), both operands K-strided as in tn_kernel
+// (transposed LDS reads, source-side XOR swizzle); two stages, inline-assembly loads.  bf16, D = 512 only.
+struct Hdw {
+    static constexpr int CT = 64, KS = 32, BLK = KS * 128, NBLK = 9, STAGE = NBLK * BLK, LDS = 2 * STAGE;      // 72 KB: two workgroups per CU
+    static constexpr int EP = 132 * 4;                                                                          // epilogue row pitch (bytes): 128 floats + pad
+};
+__global__ __launch_bounds__(256, 2)
+void head_dw_kernel(const void* __restrict__ dt_ptr, int ldt, const void* __restrict__ e_ptr, const bf16_t* __restrict__ what,
+                    const float* __restrict__ wnorm, float* __restrict__ dw, int n, int classes, uint32_t dt_bytes, uint32_t e_bytes,
+                    float out_scale) {
+    typedef bf16_t T;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = lane_id(), wave = wave_id();
+    const int c0 = blockIdx.x * Hdw::CT;
+    const u32x4_t rp = make_rsrc_words(dt_ptr, dt_bytes);
+    const u32x4_t rq = make_rsrc_words(e_ptr, e_bytes);
+    const uint32_t lds_base = (uint32_t)(uintptr_t)LDS_ADDR(smem);
+
+    f32x4_t acc[4][8];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 8; ++b) acc[a][b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    // loader: wave w moves piece w (sample rows 8w .. 8w+7 of the step) of every block
+    const int prow = wave * 8 + (lane >> 3);
+    const int ce = ((lane & 7) ^ tn_swz<128>(prow)) * 8;                  // first element of this lane's (logical) 16-byte chunk
+    const uint32_t offp0 = (c0 + ce < ldt) ? (uint32_t)((prow * ldt + c0 + ce) * 2) : OOB_OFFSET;
+    const uint32_t offq0 = (uint32_t)((prow * 512 + ce) * 2);
+    const uint32_t incp = (uint32_t)(Hdw::KS * ldt * 2), incq = (uint32_t)(Hdw::KS * 512 * 2);
+    const int nks = (n + Hdw::KS - 1) / Hdw::KS;
+    auto stage = [&](int buf, int ks) {
+        const uint32_t sb = lds_base + (uint32_t)(buf * Hdw::STAGE + wave * 1024);
+        // rows past n lie beyond the tensors' bytes -> zero fill
+        glds16_asm(rp, sb, offp0 == OOB_OFFSET ? OOB_OFFSET : offp0 + (uint32_t)ks * incp);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) glds16_asm(rq, sb + (uint32_t)((1 + b) * Hdw::BLK), offq0 + (uint32_t)ks * incq + (uint32_t)(b * 128));
+    };
+    auto compute = [&](int buf) {
+        const char* st = smem + buf * Hdw::STAGE;
+        bf16x8_t pf[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) pf[a] = TnFrag<T, 128>::load(st, 0, a * 16, lane);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const bf16x8_t qf = TnFrag<T, 128>::load(st + (1 + 2 * wave + (b >> 2)) * Hdw::BLK, 0, (b & 3) * 16, lane);
+#pragma unroll
+            for (int a = 0; a < 4; ++a) Mma<T>::run(pf[a], qf, acc[a][b]);
+        }
+    };
+    stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    int cur = 0;
+    for (int ks = 0; ks < nks - 1; ++ks) {
+        stage(cur ^ 1, ks + 1);
+        compute(cur);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");       // next stage landed; this stage's reads returned before it is refilled
+        __builtin_amdgcn_s_barrier();
+        cur ^= 1;
+    }
+    compute(cur);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    // ---- epilogue, sixteen classes at a time: the wave's 16 x 128 slice through LDS (row = class), per-row dot product with what over the
+    //      wave's 128 dimensions, summed over the four waves, then d_w = (g - what * dot) * out_scale / ||w||
+    float* red = reinterpret_cast<float*>(smem + 4 * 16 * Hdw::EP);       // [4 waves][16 rows]
+    char* mine = smem + wave * 16 * Hdw::EP;
+    const int fi = lane & 15, fg = lane >> 4;
+    const int r = lane >> 2, seg = lane & 3;                               // read phase: row r of the sixteen, 32-dimension segment seg
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+#pragma unroll
+        for (int b = 0; b < 8; ++b)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) *reinterpret_cast<float*>(mine + (4 * fg + e) * Hdw::EP + (b * 16 + fi) * 4) = acc[a][b][e];
+        const int c = c0 + a * 16 + r;
+        const bool live = c < classes;
+        f32x4_t g[8];
+        bf16x8_t h[4];
+#pragma unroll
+        for (int v = 0; v < 8; ++v) g[v] = *reinterpret_cast<const f32x4_t*>(mine + r * Hdw::EP + (seg * 32 + v * 4) * 4);
+        const size_t off = (size_t)(live ? c : 0) * 512 + wave * 128 + seg * 32;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) h[v] = *reinterpret_cast<const bf16x8_t*>(what + off + v * 8);
+        float dot = 0.f;
+#pragma unroll
+        for (int v = 0; v < 8; ++v)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dot += g[v][e] * (float)h[v >> 1][(v & 1) * 4 + e];
+        dot += __shfl_xor(dot, 1);
+        dot += __shfl_xor(dot, 2);
+        if (seg == 0) red[wave * 16 + r] = dot;
+        __syncthreads();
+        const float total = (red[r] + red[16 + r]) + (red[32 + r] + red[48 + r]);
+        if (live) {
+            const float inv = out_scale / wnorm[c];
+#pragma unroll
+            for (int v = 0; v < 8; ++v) {
+                f32x4_t o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = (g[v][e] - (float)h[v >> 1][(v & 1) * 4 + e] * total) * inv;
+                *reinterpret_cast<f32x4_t*>(dw + off + v * 4) = o;
+            }
+        }
+        __syncthreads();                                                   // red and the staging rows are rewritten by the next sixteen classes
+    }
+}
+
+static int head_dw_launch(const void* dt, int ldt, const void* ehat, const void* what, const float* wnorm, float* dw, int n, int classes,
+                          float out_scale, hipStream_t stream) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(head_dw_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, Hdw::LDS) != hipSuccess) {
+            set_error("frhip_head_dw: cannot raise dynamic LDS to %d bytes", Hdw::LDS);
+            return FRHIP_ELAUNCH;
+        }
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(head_dw_kernel, dim3((classes + Hdw::CT - 1) / Hdw::CT), dim3(256), Hdw::LDS, stream, dt, ldt, ehat, (const bf16_t*)what,
+                       wnorm, dw, n, classes, (uint32_t)((size_t)n * ldt * 2), (uint32_t)((size_t)n * 512 * 2), out_scale);
+    return check_launch("frhip_head_dw");
+}
+
 }  // namespace frhip
 
 using namespace frhip;
@@ -1350,6 +1482,20 @@ extern "C" int frhip_conv_wgrad_chain_finish(float* dw, float* slabs, int k, int
     if (!dw || !slabs || k <= 0 || c <= 0 || (k % 4) || splits <= 0) { set_error("frhip_conv_wgrad_chain_finish: bad descriptor"); return FRHIP_EINVAL; }
     TnGeom g; g.Kc = k; g.C = c; g.slab_stride = k * 9 * c;
     return t9_finish(g, dw, splits, (size_t)k * 9 * c, slabs, stream);
+}
+
+extern "C" int frhip_head_dw_ok(int dtype, int n, int classes, int d) {
+    return (dtype == FRHIP_DT_BF16 && d == 512 && n > 0 && classes > 0 && (long long)n * ((classes + 7) / 8 * 8) * 2 < 0x7fffffffLL) ? 1 : 0;
+}
+
+extern "C" int frhip_head_dw(int dtype, const void* dt, int ldt, const void* ehat, const void* what, const float* wnorm, float* dw,
+                             int n, int classes, int d, float out_scale, hipStream_t stream) {
+    if (!frhip_head_dw_ok(dtype, n, classes, d) || !dt || !ehat || !what || !wnorm || !dw || ldt < classes || (ldt % 8) ||
+        (long long)n * ldt * 2 >= 0x7fffffffLL) {
+        set_error("frhip_head_dw: bf16, d == 512, ldt >= classes in whole eights and dT below 2 GiB are required");
+        return FRHIP_EINVAL;
+    }
+    return head_dw_launch(dt, ldt, ehat, what, wnorm, dw, n, classes, out_scale, stream);
 }
 
 extern "C" int frhip_gemm_tn_overwrite(int dtype, const void* p, const void* q, float* out, int m, int kc, int ldp, int c,

@@ -666,6 +666,19 @@ def l2norm_bwd(dxhat, xhat, norms, out_scale=1.0):
     return dx
 
 
+def head_dw(dt, ehat, what, wnorm, out_scale=1.0):
+    """class-centre gradient d_w [classes, 512] fp32 from dT [n, ldt], the normalised embeddings and centres and the centres' norms in one
+    launch (frhip_head_dw), or None when the shape is not served (fp32 mode, d != 512): the caller then runs gemm_tn + l2norm_bwd"""
+    n, d = ehat.shape
+    classes = what.shape[0]
+    if not lib().frhip_head_dw_ok(dt_of(ehat), n, classes, d):
+        return None
+    dw = torch.empty((classes, d), dtype=torch.float32, device=ehat.device)
+    check(lib().frhip_head_dw(dt_of(ehat), _p(dt), dt.shape[1], _p(ehat), _p(what), _p(wnorm), _p(dw), n, classes, d, out_scale, _s()),
+          "frhip_head_dw")
+    return dw
+
+
 def head_fwd(ehat, what, labels_i32, s, m):
     n, d = ehat.shape
     classes = what.shape[0]

@@ -40,6 +40,7 @@ import os
 _FORCE_COLLECTIVES = os.environ.get("FRHIP_FORCE_COLLECTIVES", "0") == "1"
 _PFC_SAMPLE_KERNEL = os.environ.get("FRHIP_PFC_SAMPLE_KERNEL", "1") == "1"
 _EARLY_HEAD_UPDATE = os.environ.get("FRHIP_EARLY_HEAD_UPDATE", "1") == "1"
+_HEAD_DW_FUSED = os.environ.get("FRHIP_HEAD_DW_FUSED", "1") == "1"       # 0: class-centre gradient as GEMM + normalise-backward pass
 
 
 # --------------------------------------------------------------------------------------------- kernels
@@ -84,6 +85,9 @@ class HipHeadKernels:
         d_e = ops.l2norm_bwd(d_eh, ehat, enorm, out_scale=e_scale)
         if on_de is not None:
             on_de(d_e)
+        d_w = ops.head_dw(dt, ehat, what, wnorm) if _HEAD_DW_FUSED else None      # GEMM + normalise-backward in one launch (bf16, d = 512)
+        if d_w is not None:
+            return d_e, d_w
         d_wh = torch.empty((classes, d), dtype=torch.float32, device=ehat.device)
         ops.gemm_tn(dt, ehat, d_wh, kc=classes, overwrite=True)      # 250 MB at 122 000 classes: stored once, never zero-filled
         return d_e, ops.l2norm_bwd(d_wh, what, wnorm)

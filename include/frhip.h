@@ -239,6 +239,13 @@ int frhip_gather_rows(const float* src, const int64_t* index, float* dst, int n,
 int frhip_scatter_rows(const float* src, const int64_t* index, float* dst, int n, int d, frhip_stream_t stream);
 
 /* ---- margin-softmax head.  nets/PartialFC.py:198-207, nets/ArcFace.py:76-91, nets/PartialFC.py:441-484 ---- */
+/* Head: gradient of the class centres in ONE launch (autograd of F.normalize(weight) + F.linear, nets/PartialFC.py:464-484):
+ * dw[c][:] = (g[c][:] - what[c][:] * <g[c], what[c]>) * out_scale / wnorm[c] with g = dT^T ehat (dT [n][ldt] from frhip_head_bwd_dt,
+ * ehat [n][512], what [classes][512] all `dtype`; wnorm, dw fp32) -- replaces frhip_gemm_tn_overwrite + frhip_l2norm_bwd, whose
+ * intermediate g (250 MB at 122 000 classes) crossed HBM twice.  bf16 and d == 512 only (frhip_head_dw_ok). */
+int frhip_head_dw_ok(int dtype, int n, int classes, int d);
+int frhip_head_dw(int dtype, const void* dt, int ldt, const void* ehat, const void* what, const float* wnorm, float* dw,
+                  int n, int classes, int d, float out_scale, frhip_stream_t stream);
 /* F.normalize rows (also model/FR_PartialFC.py:171) */
 int frhip_l2norm_rows(int dtype, const float* x, void* xhat, float* norms, int rows, int d, float eps,
                       frhip_stream_t stream);

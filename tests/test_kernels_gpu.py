@@ -800,3 +800,29 @@ def test_standin_batchnorm_state_of_the_stem_equals_the_torch_expression():
         assert torch.equal(st.mean, beta) and st.count == 1234.0
         assert torch.equal(st.invstd, gamma / (gamma * gamma + (k * beta) ** 2 + 1e-20))
         assert torch.equal(st.scale, torch.ones_like(gamma)) and torch.equal(st.shift, torch.zeros_like(gamma))
+
+
+@pytest.mark.parametrize("case", [(512, 1000), (96, 130), (40, 64), (8, 70), (1024, 2052)])
+def test_fused_class_centre_gradient_matches_the_two_pass_form(case):
+    """frhip_head_dw: d_w = normalise-backward(dT^T ehat) in one launch (autograd of F.normalize(weight) + F.linear,
+    /root/reference/nets/PartialFC.py:464-484) against frhip_gemm_tn_overwrite + frhip_l2norm_bwd on the same operands and against fp64:
+    sample counts that are not whole K steps, class counts that are not whole tiles, a padded dT pitch."""
+    ops = _ops()
+    n, classes = case
+    ldt = (classes + 7) // 8 * 8
+    dt = torch.full((n, ldt), float("nan"), dtype=torch.bfloat16, device="cuda")              # the padding columns must not matter
+    dt[:, :classes] = (rnd(961, (n, classes)) * 0.01).bfloat16().cuda()
+    e = rnd(962, (n, 512))
+    ehat = (e / e.norm(dim=1, keepdim=True)).bfloat16().cuda()
+    w = rnd(963, (classes, 512)) * 0.05
+    what, wnorm = ops.l2norm_rows(w.cuda(), torch.bfloat16)
+    got = ops.head_dw(dt, ehat, what, wnorm)
+    assert got is not None and got.shape == (classes, 512)
+    g = torch.empty((classes, 512), dtype=torch.float32, device="cuda")
+    ops.gemm_tn(dt, ehat, g, kc=classes, overwrite=True)
+    ref = ops.l2norm_bwd(g, what, wnorm)
+    assert float((got - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
+    g64 = dt[:, :classes].double().t() @ ehat.double()
+    h64 = what.double()
+    want = (g64 - h64 * (g64 * h64).sum(1, keepdim=True)) / wnorm.double()[:, None]
+    assert float((got.double() - want).abs().max()) <= 2e-5 * float(want.abs().max())
